@@ -1,0 +1,160 @@
+/* sr_hip.h - C ABI of libsr_hip.so, the MI355X (gfx950) encode + retrieval hot path
+ * of scaling-retriever.
+ *
+ * Every entry point replaces one piece of the reference's Python hot path; the
+ * reference interface it stands in for is cited as file:line into
+ * HansiZeng/scaling-retriever.  Plain C types only: opaque handles, device
+ * pointers (what torch's tensor.data_ptr() returns), sizes, and a hipStream_t
+ * passed as void*.  All functions return 0 on success, non-zero on error
+ * (sr_last_error() then holds a message for the calling thread).  The library
+ * never frees caller memory; output buffers are caller-allocated.
+ *
+ * Threading: the reference calls its scorer from 4 Python threads with the GIL
+ * released (scaling_retriever/indexer.py:325,459), so search entry points are
+ * re-entrant: each handle owns its workspace and serialises concurrent calls on
+ * an internal mutex (the GPU runs a whole query batch per call; threads are a
+ * CPU artefact of the reference).  Different handles never share mutable state.
+ */
+#ifndef SR_HIP_H
+#define SR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_ERR_INVALID 1
+#define SR_ERR_HIP 2
+#define SR_ERR_NOMEM 3
+#define SR_ERR_UNSUPPORTED 4
+
+#define SR_DTYPE_F32 0
+#define SR_DTYPE_BF16 1
+
+typedef void* sr_stream; /* hipStream_t; NULL = default stream */
+
+const char* sr_last_error(void);
+int sr_version(void);
+/* Largest k supported by the fused top-k (LDS sort width). */
+int sr_max_topk(void);
+
+/* ------------------------------------------------------------------ dense ---
+ * Replaces DenseFlatIndexer.init_index / index_data / search_knn
+ * (scaling_retriever/indexer.py:191-217) over faiss.IndexFlatIP:
+ * exact fp32 inner products, k best per query, sorted descending; ties broken
+ * by ascending doc index; rows padded with (-FLT_MAX, -1) when ntotal < k.   */
+typedef struct sr_dense_index sr_dense_index;
+
+int sr_dense_index_create(sr_dense_index** out, int dim);
+/* Registers a segment of `n_rows` fp32 row-major [n_rows, dim] embeddings that
+ * already live in device memory (non-owning view; caller keeps it alive).
+ * Global doc index of local row r is id_base + r * id_stride (id_stride = W and
+ * id_base = rank reproduces the reference's g_row = row*W + rank sharding,
+ * indexer.py:262).  Global indices must fit in 32 bits.                      */
+int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int64_t n_rows,
+                       int64_t id_base, int64_t id_stride);
+int64_t sr_dense_index_ntotal(const sr_dense_index* idx);
+/* d_queries: fp32 [nq, dim] on device.  d_out_scores fp32 [nq, k],
+ * d_out_ids int64 [nq, k] (global doc indices).                              */
+int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k,
+                    float* d_out_scores, int64_t* d_out_ids, sr_stream stream);
+/* Workspace ceiling in bytes for candidate buffers (default 4 GiB). */
+int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes);
+int sr_dense_index_destroy(sr_dense_index* idx);
+
+/* ----------------------------------------------------------------- sparse ---
+ * Replaces SparseRetrieval.numba_score_float + select_topk
+ * (scaling_retriever/indexer.py:315-344): per query, term-serial
+ * scores[doc] += q_t * v (unfused fp32 multiply-add, ascending query-term
+ * order), keep docs with score > threshold, k best; sorted descending, ties by
+ * ascending doc index.  The index is the IndexDictOfArray posting lists
+ * (scaling_retriever/utils/inverted_index.py:15-105) laid out as CSR by term. */
+typedef struct sr_sparse_index sr_sparse_index;
+
+/* d_indptr int64 [n_terms+1], d_doc_ids int32 [nnz], d_vals fp32 [nnz], all on
+ * device (non-owning views).  Inside each posting list doc ids must be strictly
+ * ascending (checked).  n_docs = IndexDictOfArray.nb_docs().                  */
+int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_indptr,
+                           const int32_t* d_doc_ids, const float* d_vals,
+                           int64_t n_terms, int64_t n_docs, sr_stream stream);
+/* Queries as CSR: d_q_indptr int64 [nq+1], d_q_cols int32, d_q_vals fp32 (term
+ * order inside a query = accumulation order).  Outputs [nq, k] padded with
+ * (0, -1); d_out_counts int32 [nq] = number of valid entries per row.
+ * Global doc index = id_base + doc * id_stride.                              */
+int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
+                     const float* d_q_vals, int64_t nq, int k, float threshold,
+                     int64_t id_base, int64_t id_stride,
+                     float* d_out_scores, int64_t* d_out_ids, int32_t* d_out_counts,
+                     sr_stream stream);
+int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t bytes);
+int sr_sparse_index_destroy(sr_sparse_index* idx);
+
+/* ------------------------------------------------------------ top-k merge ---
+ * The one exchange step of doc-sharded retrieval: merge `n_lists` per-shard
+ * top-k lists (after the RCCL gather) into the global top-k per query.
+ * d_scores fp32 [n_lists, nq, k], d_ids int64 [n_lists, nq, k] (ids < 0 = pad).
+ * Outputs as sr_dense_search (pad_score fills unused slots).                  */
+int sr_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int64_t nq, int k,
+                  float pad_score, float* d_out_scores, int64_t* d_out_ids, sr_stream stream);
+
+/* ---------------------------------------------------------------- encoder ---
+ * Replaces LlamaBiDense / LlamaBiSparse .encode / .query_encode / .doc_encode
+ * (scaling_retriever/modeling/llm_encoder.py:66-70,186-196,424-443) and the
+ * LlamaBiModel forward they call (modeling/bidirectional_llama.py:67-188 over
+ * transformers' LlamaModel).                                                  */
+typedef struct sr_model sr_model;
+
+typedef struct {
+    int32_t vocab_size, hidden_size, intermediate_size, num_layers;
+    int32_t num_heads, num_kv_heads, head_dim;
+    float rms_norm_eps;
+    float rope_theta;
+    int32_t rope_llama3;              /* 0 = default rope, 1 = "llama3" scaling */
+    float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+    int32_t rope_original_max_pos;
+    int32_t tie_word_embeddings;      /* lm_head shares embed_tokens */
+    int32_t has_lm_head;              /* 0: LlamaBiModel (dense), 1: LlamaBiForMNTP (sparse) */
+    int32_t max_batch_tokens;         /* workspace sizing: max packed tokens per encode call */
+    int32_t max_batch_seqs;
+} sr_model_config;
+
+int sr_model_create(sr_model** out, const sr_model_config* cfg);
+/* Copies one checkpoint tensor (HF Llama naming, e.g.
+ * "model.layers.3.self_attn.q_proj.weight") from device memory into the
+ * model's internal layout.  dtype = SR_DTYPE_F32 or SR_DTYPE_BF16.           */
+int sr_model_set_weight(sr_model* m, const char* name, const void* d_ptr, int dtype,
+                        int64_t rows, int64_t cols, sr_stream stream);
+/* Verifies all tensors were provided. */
+int sr_model_finalize(sr_model* m);
+/* d_input_ids / d_attention_mask: int64 [B, L] on device (the tokenizer
+ * collator's output, data_collator.py:177-190).  d_out: fp32 [B, hidden].    */
+int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
+                    int32_t B, int32_t L, float* d_out, sr_stream stream);
+/* d_out: fp32 [B, vocab]. */
+int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
+                     int32_t B, int32_t L, float* d_out, sr_stream stream);
+/* Debug/test hook: last_hidden_state (after the final norm) of the packed
+ * tokens of the last encode call, fp32 [n_tokens, hidden]; returns n_tokens
+ * through *n_tokens.                                                         */
+int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_rows, int64_t* n_tokens, sr_stream stream);
+int sr_model_destroy(sr_model* m);
+
+/* peft merge_and_unload for one Linear (llm_encoder.py:116-122,502-508):
+ * W[out,in] += scale * B[out,r] @ A[r,in], fp32 in place, scale = alpha / r. */
+int sr_lora_merge(float* d_W, const float* d_A, const float* d_B, int64_t out_features,
+                  int64_t in_features, int32_t r, float scale, sr_stream stream);
+
+/* nonzero -> (row, col, val) compaction of sparse reps [B, V]
+ * (indexer.py:259-260 torch.nonzero + gather; _generate_query_vecs :393-399).
+ * d_row_ptr int64 [B+1] receives CSR row offsets, d_cols int32 / d_vals fp32
+ * [capacity] the entries (cols ascending inside a row, like torch.nonzero).
+ * *h_nnz gets the total (call synchronises the stream). Returns SR_ERR_NOMEM
+ * if capacity is too small (then *h_nnz holds the needed size).               */
+int sr_sparse_compact(const float* d_reps, int64_t B, int64_t V, int64_t* d_row_ptr,
+                      int32_t* d_cols, float* d_vals, int64_t capacity, int64_t* h_nnz,
+                      sr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_HIP_H */

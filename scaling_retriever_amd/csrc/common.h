@@ -1,0 +1,89 @@
+// Shared helpers for libsr_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/sr_hip.h"
+
+void sr_set_error(const char* fmt, ...);
+
+#define SR_CHECK_HIP(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            sr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return SR_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define SR_CHECK_LAUNCH() SR_CHECK_HIP(hipGetLastError())
+
+#define SR_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            sr_set_error(__VA_ARGS__);   \
+            return SR_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define SR_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != SR_OK) return rc_; \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- order-preserving float <-> uint32 (larger float => larger uint) ----
+__host__ __device__ inline uint32_t sr_f2ord(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+__host__ __device__ inline float sr_ord2f(uint32_t o) {
+    union { float f; uint32_t u; } c;
+    c.u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return c.f;
+}
+// 64-bit candidate key: larger key = better (higher score, then LOWER doc index).
+__host__ __device__ inline uint64_t sr_make_key(float score, uint32_t gid) {
+    return ((uint64_t)sr_f2ord(score) << 32) | (uint64_t)(~gid);
+}
+__host__ __device__ inline float sr_key_score(uint64_t k) { return sr_ord2f((uint32_t)(k >> 32)); }
+__host__ __device__ inline uint32_t sr_key_gid(uint64_t k) { return ~(uint32_t)(k & 0xffffffffu); }
+
+// ---- bf16 helpers (round-to-nearest-even via hardware cvt at -O3) ----
+__device__ inline float bf16_to_f32(unsigned short h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ inline unsigned short f32_to_bf16(float f) {
+    // plain cast path keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+// ---- fused top-k workspace shared by the dense and sparse scorers ----
+struct TopkWS {
+    int64_t nq_cap = 0;      // allocated queries
+    int k = 0;               // allocated k
+    int64_t cand_cap = 0;    // allocated candidate slots per query
+    uint64_t* run_keys = nullptr;   // [nq_cap, k]   running top-k, unsorted
+    int* run_count = nullptr;       // [nq_cap]
+    float* tau = nullptr;           // [nq_cap]     score of the current k-th best (-inf until k kept)
+    uint64_t* cand_keys = nullptr;  // [nq_cap, cand_cap]
+    int* cand_count = nullptr;      // [nq_cap]
+    int ensure(int64_t nq, int k, int64_t cand_cap);
+    void release();
+};
+// tau := -inf, counts := 0 for the first nq queries
+int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s);
+// merge candidates into the running top-k (per query), update tau, clear candidates
+int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s);
+// sort the running top-k descending and write [nq, k] outputs (+ optional counts)
+int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_scores,
+                  int64_t* d_out_ids, int32_t* d_out_counts, hipStream_t s);
+
+#define SR_MAX_TOPK 4096

@@ -1,0 +1,281 @@
+// Dense brute-force scoring Q . D^T with fused top-k filtering (gfx950).
+//
+// Replaces faiss.IndexFlatIP.search as used by DenseFlatIndexer.search_knn
+// (scaling_retriever/indexer.py:191-217).  Exact fp32: products are accumulated
+// by v_mfma_f32_32x32x2_f32 (f32 in / f32 acc), which is bit-for-bit a k-ordered
+// fmaf chain.  Per 8-wide k group s the chain visits k = 8s+j (lane half 0) then
+// 8s+4+j (half 1) for j = 0..3 - oracle/scoring.py::mfma_korder restates it.
+//
+// Layout: D row-major [N, H] fp32 in HBM (72.4 GB at N = 8 841 823, H = 2048),
+// Q row-major [nq, H].  Docs are the MFMA A rows, queries the B columns, so in
+// the accumulator a lane owns ONE query column (lane & 31) and 16 doc rows per
+// 32x32 block: the tau compare is lane-local.  Scores never go to HBM; survivors
+// (score >= tau[q]) are appended as 64-bit keys to the per-query candidate buffer
+// (topk.hip).  A doc chunk = one launch; tau is raised between chunks.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+struct DenseArgs {
+    const float* D;       // segment base
+    const float* Q;
+    int64_t row_begin;    // first doc row of this launch (within the segment)
+    int64_t row_end;      // one past the last doc row of this launch
+    int H;
+    int nq;
+    const float* tau;
+    uint64_t* cand_keys;
+    int* cand_count;
+    int64_t cand_cap;
+    uint32_t id_base, id_stride;
+};
+
+// Tile = (32*WM*WAVES_M docs) x (32*WN*WAVES_N queries), 4 waves, BK = 16.
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N, BK = 16, LDK = BK + 4;
+    constexpr int A_CHUNKS = TM * (BK / 4), B_CHUNKS = TN * (BK / 4);
+    constexpr int A_PER_T = (A_CHUNKS + 255) / 256, B_PER_T = (B_CHUNKS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][TM][LDK]
+    float* Bs = smem + 2 * TM * LDK;   // [2][TN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * TM;
+    const int q0 = blockIdx.y * TN;
+    const int H = a.H;
+
+    f32x4 ra[A_PER_T], rb[B_PER_T];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int c = tid + i * 256;
+            const int r = c >> 2, kc = c & 3;
+            const int64_t row = row0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < A_CHUNKS && row < a.row_end) v = *reinterpret_cast<const f32x4*>(a.D + row * H + k0 + kc * 4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            const int c = tid + i * 256;
+            const int r = c >> 2, kc = c & 3;
+            const int q = q0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < B_CHUNKS && q < a.nq) v = *reinterpret_cast<const f32x4*>(a.Q + (int64_t)q * H + k0 + kc * 4);
+            rb[i] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int c = tid + i * 256;
+            if (c < A_CHUNKS) *reinterpret_cast<f32x4*>(&As[(buf * TM + (c >> 2)) * LDK + (c & 3) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            const int c = tid + i * 256;
+            if (c < B_CHUNKS) *reinterpret_cast<f32x4*>(&Bs[(buf * TN + (c >> 2)) * LDK + (c & 3) * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int nk = H / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const int arow = wm * WM * 32 + (lane & 31);
+    const int brow = wn * WN * 32 + (lane & 31);
+    const int koff = 4 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 af[WM], bf[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+                af[m] = *reinterpret_cast<const f32x4*>(&As[(buf * TM + arow + m * 32) * LDK + 8 * s + koff]);
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(buf * TN + brow + n * 32) * LDK + 8 * s + koff]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane-local tau filter, append survivors -------------------
+    const int half = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int q = q0 + wn * WN * 32 + n * 32 + (lane & 31);
+        if (q >= a.nq) continue;
+        const float tq = a.tau[q];
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm * WM * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                cnt += (row < a.row_end && acc[m][n][r] >= tq) ? 1 : 0;
+            }
+        if (cnt == 0) continue;
+        int pos = atomicAdd(&a.cand_count[q], cnt);
+        uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm * WM * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float sc = acc[m][n][r];
+                if (row < a.row_end && sc >= tq) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, a.id_base + (uint32_t)row * a.id_stride);
+                    ++pos;
+                }
+            }
+    }
+}
+
+// --------------------------------------------------------------------- host ---
+struct DenseSegment {
+    const float* rows;
+    int64_t n;
+    int64_t id_base, id_stride;
+};
+
+struct sr_dense_index {
+    int dim = 0;
+    std::vector<DenseSegment> segs;
+    int64_t ntotal = 0;
+    int64_t ws_limit = 4ll << 30;
+    TopkWS ws;
+    std::mutex mu;
+};
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+static int launch_dense(const DenseArgs& a, int64_t rows, hipStream_t s) {
+    constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
+    constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * 20;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div64(rows, TM), (unsigned)ceil_div64(a.nq, TN));
+    hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN>), grid, dim3(256), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_create(sr_dense_index** out, int dim) {
+    SR_REQUIRE(out, "sr_dense_index_create: null out");
+    SR_REQUIRE(dim > 0 && dim % 16 == 0, "sr_dense_index_create: dim=%d must be a positive multiple of 16", dim);
+    *out = new sr_dense_index();
+    (*out)->dim = dim;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int64_t n_rows, int64_t id_base,
+                                  int64_t id_stride) {
+    SR_REQUIRE(idx, "sr_dense_index_add: null index");
+    SR_REQUIRE(n_rows >= 0 && id_stride >= 1 && id_base >= 0, "sr_dense_index_add: bad sizes");
+    if (n_rows == 0) return SR_OK;
+    SR_REQUIRE(d_rows, "sr_dense_index_add: null rows");
+    SR_REQUIRE(((uintptr_t)d_rows & 15) == 0, "sr_dense_index_add: rows must be 16-byte aligned");
+    SR_REQUIRE(id_base + (n_rows - 1) * id_stride < 0xffffffffll, "sr_dense_index_add: global doc index exceeds 32 bits");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->segs.push_back({d_rows, n_rows, id_base, id_stride});
+    idx->ntotal += n_rows;
+    return SR_OK;
+}
+
+extern "C" int64_t sr_dense_index_ntotal(const sr_dense_index* idx) { return idx ? idx->ntotal : -1; }
+
+extern "C" int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes) {
+    SR_REQUIRE(idx && bytes >= (1 << 20), "sr_dense_index_set_workspace_limit: bad argument");
+    idx->ws_limit = bytes;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
+    if (!idx) return SR_OK;
+    idx->ws.release();
+    delete idx;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
+                               int64_t* d_out_ids, sr_stream stream) {
+    SR_REQUIRE(idx, "sr_dense_search: null index");
+    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_dense_search: bad nq=%lld", (long long)nq);
+    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_dense_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_queries && d_out_scores && d_out_ids, "sr_dense_search: null pointer");
+    SR_REQUIRE(((uintptr_t)d_queries & 15) == 0, "sr_dense_search: queries must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(idx->mu);
+
+    // tile config by query count; chunk = docs per launch (= candidate capacity per query)
+    int cfg;
+    int TN;
+    if (nq > 128) { cfg = 0; TN = 256; }
+    else if (nq > 64) { cfg = 1; TN = 128; }
+    else if (nq > 32) { cfg = 2; TN = 64; }
+    else { cfg = 3; TN = 32; }
+    const int TM = 256;
+    const int64_t qtiles = ceil_div64(nq, TN);
+    // enough workgroups per launch to fill 256 CUs several times over
+    int64_t chunk = TM * ceil_div64(2048, qtiles);
+    if (chunk < 16384) chunk = 16384;
+    int64_t max_cap = idx->ws_limit / (8 * nq);
+    max_cap = (max_cap / TM) * TM;
+    if (max_cap < TM) max_cap = TM;
+    if (chunk > max_cap) chunk = max_cap;
+    SR_TRY(idx->ws.ensure(nq, k, chunk));
+    SR_TRY(topk_reset(idx->ws, nq, s));
+
+    for (const DenseSegment& seg : idx->segs) {
+        for (int64_t r0 = 0; r0 < seg.n; r0 += chunk) {
+            const int64_t r1 = r0 + chunk < seg.n ? r0 + chunk : seg.n;
+            DenseArgs a;
+            a.D = seg.rows;
+            a.Q = d_queries;
+            a.row_begin = r0;
+            a.row_end = r1;
+            a.H = idx->dim;
+            a.nq = (int)nq;
+            a.tau = idx->ws.tau;
+            a.cand_keys = idx->ws.cand_keys;
+            a.cand_count = idx->ws.cand_count;
+            a.cand_cap = idx->ws.cand_cap;
+            a.id_base = (uint32_t)seg.id_base;
+            a.id_stride = (uint32_t)seg.id_stride;
+            switch (cfg) {
+                case 0: SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s))); break;
+                case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
+                case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
+                default: SR_TRY((launch_dense<4, 1, 2, 1>(a, r1 - r0, s))); break;
+            }
+            SR_TRY(topk_compact(idx->ws, nq, k, s));
+        }
+    }
+    SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    return SR_OK;
+}

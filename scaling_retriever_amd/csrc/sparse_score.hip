@@ -1,0 +1,294 @@
+// Inverted-index scoring with LDS-resident score tiles and fused top-k (gfx950).
+//
+// Replaces SparseRetrieval.numba_score_float + select_topk
+// (scaling_retriever/indexer.py:315-344).  The reference zeroes an N-sized fp32
+// array per query, scatter-adds q_t * v over each query term's posting list in
+// term order, then scans it for score > threshold.  Here the doc space is cut
+// into tiles of SP_TILE docs; one workgroup owns (query, tile): its slice of the
+// score array lives in LDS, each query term contributes the contiguous run of its
+// (doc-sorted) posting list that falls in the tile - found through a per-term
+// skip table - and the tile is filtered against max(threshold, tau[q]) straight
+// from LDS.  No N-sized array ever touches HBM: traffic = 8 B per touched
+// posting.  Terms are applied in the query's term order with a barrier between
+// them and an unfused multiply-add, so every per-doc sum is bit-identical to the
+// reference's term-serial fp32 accumulation.
+#include "common.h"
+#include <mutex>
+
+#define SP_TILE 8192
+#define SP_TERMS 256  // query terms staged per batch
+
+struct SparseArgs {
+    const int64_t* indptr;
+    const int32_t* doc_ids;
+    const float* vals;
+    const int32_t* skip;  // [n_terms, n_tiles + 1] offsets relative to indptr[t]
+    int n_tiles;
+    int64_t n_docs;
+    const int64_t* q_indptr;
+    const int32_t* q_cols;
+    const float* q_vals;
+    int64_t q_base;   // first query of this batch
+    int tile_begin;   // first tile of this launch
+    float threshold;
+    const float* tau;     // indexed by (q - q_base)
+    uint64_t* cand_keys;
+    int* cand_count;
+    int64_t cand_cap;
+    uint32_t id_base, id_stride;
+};
+
+__global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
+#pragma clang fp contract(off)
+    __shared__ float sc[SP_TILE];
+    __shared__ int64_t seg_b[SP_TERMS];
+    __shared__ int seg_n[SP_TERMS];
+    __shared__ float seg_w[SP_TERMS];
+    __shared__ int wave_tot[4];
+    __shared__ int s_base;
+
+    const int tid = threadIdx.x;
+    const int ql = blockIdx.x;                 // query within batch
+    const int64_t q = a.q_base + ql;
+    const int tile = a.tile_begin + blockIdx.y;
+    const int64_t doc0 = (int64_t)tile * SP_TILE;
+    const int n_here = (int)((a.n_docs - doc0) < SP_TILE ? (a.n_docs - doc0) : SP_TILE);
+
+    for (int d = tid; d < SP_TILE; d += 256) sc[d] = 0.f;
+
+    const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
+    for (int64_t t0 = tb; t0 < te; t0 += SP_TERMS) {
+        const int nt = (int)((te - t0) < SP_TERMS ? (te - t0) : SP_TERMS);
+        __syncthreads();  // previous batch fully applied (also covers the zero fill)
+        if (tid < nt) {
+            const int term = a.q_cols[t0 + tid];
+            const int32_t* sk = a.skip + (int64_t)term * (a.n_tiles + 1) + tile;
+            const int b = sk[0], e = sk[1];
+            seg_b[tid] = a.indptr[term] + b;
+            seg_n[tid] = e - b;
+            seg_w[tid] = a.q_vals[t0 + tid];
+        }
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const int n = seg_n[j];
+            if (n == 0) continue;  // uniform: nothing written, no barrier needed
+            const int64_t b = seg_b[j];
+            const float w = seg_w[j];
+            for (int p = tid; p < n; p += 256) {
+                const int d = a.doc_ids[b + p] - (int)doc0;
+                const float prod = w * a.vals[b + p];
+                sc[d] = sc[d] + prod;  // doc ids are unique inside one posting list
+            }
+            __syncthreads();  // term-serial: next term may touch the same docs
+        }
+    }
+    __syncthreads();
+
+    // ---- filter the tile: score > threshold and score >= tau -----------------
+    const float tq = a.tau[ql];
+    const float thr = a.threshold;
+    int cnt = 0;
+    for (int d = tid; d < n_here; d += 256) {
+        const float s = sc[d];
+        cnt += (s > thr && s >= tq) ? 1 : 0;
+    }
+    // block exclusive scan of cnt
+    int incl = cnt;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) wbase += wave_tot[w];
+        total += wave_tot[w];
+    }
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(&a.cand_count[ql], total);
+    __syncthreads();
+    int pos = s_base + wbase + incl - cnt;
+    uint64_t* dst = a.cand_keys + (int64_t)ql * a.cand_cap;
+    for (int d = tid; d < n_here; d += 256) {
+        const float s = sc[d];
+        if (s > thr && s >= tq) {
+            if (pos < a.cand_cap) dst[pos] = sr_make_key(s, a.id_base + (uint32_t)(doc0 + d) * a.id_stride);
+            ++pos;
+        }
+    }
+}
+
+// ---- index build: skip table + validation -----------------------------------
+// skip[t][b] = number of postings of term t with doc id < b * SP_TILE  (lower bound)
+__global__ void sparse_skip_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
+                                   int64_t n_terms, int n_tiles, int32_t* __restrict__ skip) {
+    const int64_t t = blockIdx.x;
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    const int64_t len = e - b;
+    for (int tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x) {
+        const int64_t bound = (int64_t)tile * SP_TILE;
+        int64_t lo = 0, hi = len;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)doc_ids[b + mid] < bound) lo = mid + 1; else hi = mid;
+        }
+        skip[t * (n_tiles + 1) + tile] = (int32_t)lo;
+    }
+}
+
+// flags[0] |= 1 if a posting list is not strictly ascending, |= 2 if a doc id is out of range,
+// |= 4 if indptr is not monotone
+__global__ void sparse_validate_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
+                                       int64_t n_terms, int64_t n_docs, int* __restrict__ flags) {
+    const int64_t t = blockIdx.x;
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    if (e < b) { if (threadIdx.x == 0) atomicOr(flags, 4); return; }
+    int bad = 0;
+    for (int64_t p = b + threadIdx.x; p < e; p += blockDim.x) {
+        const int32_t d = doc_ids[p];
+        if (d < 0 || (int64_t)d >= n_docs) bad |= 2;
+        if (p > b && doc_ids[p - 1] >= d) bad |= 1;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+struct sr_sparse_index {
+    const int64_t* indptr = nullptr;
+    const int32_t* doc_ids = nullptr;
+    const float* vals = nullptr;
+    int64_t n_terms = 0, n_docs = 0;
+    int n_tiles = 0;
+    int32_t* skip = nullptr;
+    int64_t ws_limit = 4ll << 30;
+    TopkWS ws;
+    std::mutex mu;
+};
+
+extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_indptr, const int32_t* d_doc_ids,
+                                      const float* d_vals, int64_t n_terms, int64_t n_docs, sr_stream stream) {
+    SR_REQUIRE(out, "sr_sparse_index_create: null out");
+    SR_REQUIRE(n_terms >= 1 && n_docs >= 1, "sr_sparse_index_create: need n_terms >= 1 and n_docs >= 1");
+    SR_REQUIRE(n_docs < 0xffffffffll, "sr_sparse_index_create: n_docs exceeds 32 bits");
+    SR_REQUIRE(d_indptr, "sr_sparse_index_create: null indptr");
+    hipStream_t s = (hipStream_t)stream;
+    sr_sparse_index* idx = new sr_sparse_index();
+    idx->indptr = d_indptr;
+    idx->doc_ids = d_doc_ids;
+    idx->vals = d_vals;
+    idx->n_terms = n_terms;
+    idx->n_docs = n_docs;
+    idx->n_tiles = (int)ceil_div64(n_docs, SP_TILE);
+    int* d_flags = nullptr;
+    int h_flags = 0;
+    int rc = SR_OK;
+    do {
+        if (hipMalloc(&idx->skip, sizeof(int32_t) * (size_t)n_terms * (size_t)(idx->n_tiles + 1)) != hipSuccess ||
+            hipMalloc(&d_flags, sizeof(int)) != hipSuccess) {
+            sr_set_error("sr_sparse_index_create: out of device memory for the skip table (%lld x %d)",
+                         (long long)n_terms, idx->n_tiles + 1);
+            rc = SR_ERR_NOMEM;
+            break;
+        }
+        if (hipMemsetAsync(d_flags, 0, sizeof(int), s) != hipSuccess) { rc = SR_ERR_HIP; break; }
+        hipLaunchKernelGGL(sparse_validate_kernel, dim3((unsigned)n_terms), dim3(256), 0, s, d_indptr, d_doc_ids,
+                           n_terms, n_docs, d_flags);
+        hipLaunchKernelGGL(sparse_skip_kernel, dim3((unsigned)n_terms), dim3(64), 0, s, d_indptr, d_doc_ids, n_terms,
+                           idx->n_tiles, idx->skip);
+        if (hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            sr_set_error("sr_sparse_index_create: %s", hipGetErrorString(hipGetLastError()));
+            rc = SR_ERR_HIP;
+            break;
+        }
+        if (h_flags) {
+            sr_set_error("sr_sparse_index_create: invalid index (%s%s%s)",
+                         (h_flags & 1) ? "posting list not strictly ascending by doc id; " : "",
+                         (h_flags & 2) ? "doc id out of [0, n_docs); " : "", (h_flags & 4) ? "indptr not monotone" : "");
+            rc = SR_ERR_INVALID;
+        }
+    } while (0);
+    if (d_flags) (void)hipFree(d_flags);
+    if (rc != SR_OK) {
+        if (idx->skip) (void)hipFree(idx->skip);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t bytes) {
+    SR_REQUIRE(idx && bytes >= (1 << 20), "sr_sparse_index_set_workspace_limit: bad argument");
+    idx->ws_limit = bytes;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
+    if (!idx) return SR_OK;
+    idx->ws.release();
+    if (idx->skip) (void)hipFree(idx->skip);
+    delete idx;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
+                                const float* d_q_vals, int64_t nq, int k, float threshold, int64_t id_base,
+                                int64_t id_stride, float* d_out_scores, int64_t* d_out_ids, int32_t* d_out_counts,
+                                sr_stream stream) {
+    SR_REQUIRE(idx, "sr_sparse_search: null index");
+    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_sparse_search: bad nq");
+    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_sparse_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
+    SR_REQUIRE(id_stride >= 1 && id_base >= 0 && id_base + (idx->n_docs - 1) * id_stride < 0xffffffffll,
+               "sr_sparse_search: global doc index exceeds 32 bits");
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_q_indptr && d_out_scores && d_out_ids, "sr_sparse_search: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(idx->mu);
+
+    // query batches bound the candidate workspace: cap (slots per query) = docs per launch
+    const int64_t q_batch = nq < 1024 ? nq : 1024;
+    int64_t max_tiles = idx->ws_limit / (8 * q_batch * SP_TILE);
+    if (max_tiles < 1) max_tiles = 1;
+    if (max_tiles > 64) max_tiles = 64;
+    if (max_tiles > idx->n_tiles) max_tiles = idx->n_tiles;
+    SR_TRY(idx->ws.ensure(q_batch, k, max_tiles * SP_TILE));
+
+    for (int64_t qb = 0; qb < nq; qb += q_batch) {
+        const int64_t nqb = (nq - qb) < q_batch ? (nq - qb) : q_batch;
+        SR_TRY(topk_reset(idx->ws, nqb, s));
+        int64_t step = 1;  // tiles per launch grow geometrically: tau tightens early
+        for (int64_t t0 = 0; t0 < idx->n_tiles;) {
+            int64_t nt = step < max_tiles ? step : max_tiles;
+            if (t0 + nt > idx->n_tiles) nt = idx->n_tiles - t0;
+            SparseArgs a;
+            a.indptr = idx->indptr;
+            a.doc_ids = idx->doc_ids;
+            a.vals = idx->vals;
+            a.skip = idx->skip;
+            a.n_tiles = idx->n_tiles;
+            a.n_docs = idx->n_docs;
+            a.q_indptr = d_q_indptr;
+            a.q_cols = d_q_cols;
+            a.q_vals = d_q_vals;
+            a.q_base = qb;
+            a.tile_begin = (int)t0;
+            a.threshold = threshold;
+            a.tau = idx->ws.tau;
+            a.cand_keys = idx->ws.cand_keys;
+            a.cand_count = idx->ws.cand_count;
+            a.cand_cap = idx->ws.cand_cap;
+            a.id_base = (uint32_t)id_base;
+            a.id_stride = (uint32_t)id_stride;
+            hipLaunchKernelGGL(sparse_score_kernel, dim3((unsigned)nqb, (unsigned)nt), dim3(256), 0, s, a);
+            SR_CHECK_LAUNCH();
+            SR_TRY(topk_compact(idx->ws, nqb, k, s));
+            t0 += nt;
+            step *= 2;
+        }
+        SR_TRY(topk_finalize(idx->ws, nqb, k, 0.f, d_out_scores + qb * k, d_out_ids + qb * k,
+                             d_out_counts ? d_out_counts + qb : nullptr, s));
+    }
+    return SR_OK;
+}

@@ -1,0 +1,284 @@
+// Fused top-k machinery shared by the dense and sparse scorers (gfx950).
+//
+// The score kernels never materialise [nq, N] scores.  Each one filters its
+// tile against a per-query threshold tau (score of the current k-th best) and
+// appends survivors as 64-bit keys (ordered score bits << 32 | ~doc index) to a
+// per-query candidate buffer.  After every doc chunk, topk_compact_kernel folds
+// the candidates into the running (unsorted) top-k with an LDS radix select and
+// raises tau.  topk_sort_kernel sorts the k survivors once at the end.
+//
+// Result = top-k by (score desc, doc index asc): deterministic, independent of
+// tile scheduling.  Stands in for faiss' heap top-k (indexer.py:211) and for
+// np.argpartition in select_topk (indexer.py:315-322).
+#include "common.h"
+#include <mutex>
+
+// ------------------------------------------------------------------ reset ---
+__global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, int64_t nq) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) {
+        run_count[i] = 0;
+        cand_count[i] = 0;
+        tau[i] = -INFINITY;
+    }
+}
+
+// ---------------------------------------------------------------- compact ---
+// One workgroup (256 threads) per query.
+__global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
+                                                           float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
+                                                           int* __restrict__ cand_count, int k, int64_t cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int* hist = reinterpret_cast<int*>(smem_raw);          // [256]
+    int* scan = hist + 256;                                 // [256]
+    int* ctrl = scan + 256;                                 // [8]
+    uint32_t* hole_pos = reinterpret_cast<uint32_t*>(ctrl + 8);  // [k]
+    uint32_t* filler_idx = hole_pos + k;                          // [k]
+
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int nc = cand_count[q];
+    if (nc == 0) return;
+    if ((int64_t)nc > cand_cap) nc = (int)cand_cap;  // unreachable by construction (cap >= docs per chunk)
+    const int nr = run_count[q];
+    uint64_t* run = run_keys + (int64_t)q * k;
+    const uint64_t* cand = cand_keys + (int64_t)q * cand_cap;
+    const int n = nr + nc;
+
+    if (n <= k) {
+        for (int i = tid; i < nc; i += 256) run[nr + i] = cand[i];
+        if (n == k) {
+            // tau = smallest kept score
+            uint64_t mn = ~0ull;
+            for (int i = tid; i < n; i += 256) {
+                uint64_t key = i < nr ? run[i] : cand[i - nr];
+                mn = key < mn ? key : mn;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                uint64_t o = __shfl_xor(mn, off);
+                mn = o < mn ? o : mn;
+            }
+            uint64_t* red = reinterpret_cast<uint64_t*>(hist);
+            if ((tid & 63) == 0) red[tid >> 6] = mn;
+            __syncthreads();
+            if (tid == 0) {
+                uint64_t m = red[0];
+                for (int w = 1; w < 4; ++w) m = red[w] < m ? red[w] : m;
+                tau[q] = sr_key_score(m);
+            }
+        }
+        if (tid == 0) {
+            run_count[q] = n;
+            cand_count[q] = 0;
+        }
+        return;
+    }
+
+    // radix select (MSB first, 8 bits per pass) of the k-th largest key of the union
+    uint64_t prefix = 0;
+    int remaining = k;
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const uint64_t key = i < nr ? run[i] : cand[i - nr];
+            if (pass == 7 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
+        }
+        __syncthreads();
+        // inclusive suffix sum: scan[b] = sum_{b' >= b} hist[b']
+        int v = hist[tid];
+        scan[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int add = (tid + off < 256) ? scan[tid + off] : 0;
+            __syncthreads();
+            v += add;
+            scan[tid] = v;
+            __syncthreads();
+        }
+        const int above = (tid == 255) ? 0 : scan[tid + 1];
+        if (v >= remaining && above < remaining) {
+            ctrl[0] = tid;
+            ctrl[1] = remaining - above;
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint64_t)ctrl[0];
+        remaining = ctrl[1];
+        __syncthreads();
+    }
+    const uint64_t T = prefix;  // the k-th largest key (keys are unique)
+
+    if (tid == 0) {
+        ctrl[2] = 0;
+        ctrl[3] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < k; i += 256) {
+        const bool hole = (i >= nr) || (run[i] < T);
+        if (hole) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;
+    }
+    for (int i = tid; i < nc; i += 256) {
+        if (cand[i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)i;
+    }
+    __syncthreads();
+    const int nf = ctrl[3] < ctrl[2] ? ctrl[3] : ctrl[2];  // equal by construction
+    for (int j = tid; j < nf; j += 256) run[hole_pos[j]] = cand[filler_idx[j]];
+    if (tid == 0) {
+        run_count[q] = k;
+        cand_count[q] = 0;
+        tau[q] = sr_key_score(T);
+    }
+}
+
+// ------------------------------------------------------------------- sort ---
+// Bitonic sort (descending) of the running top-k in LDS; P = next pow2 >= k.
+__global__ __launch_bounds__(256) void topk_sort_kernel(const uint64_t* __restrict__ run_keys, const int* __restrict__ run_count,
+                                                        int k, int P, float pad_score, float* __restrict__ out_scores,
+                                                        int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int cnt = run_count[q];
+    const uint64_t* run = run_keys + (int64_t)q * k;
+    for (int i = tid; i < P; i += 256) keys[i] = i < cnt ? run[i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool desc = (i & size) == 0;
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    if (desc ? (a < b) : (a > b)) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        const int64_t o = (int64_t)q * k + i;
+        if (i < cnt) {
+            out_scores[o] = sr_key_score(keys[i]);
+            out_ids[o] = (int64_t)sr_key_gid(keys[i]);
+        } else {
+            out_scores[o] = pad_score;
+            out_ids[o] = -1;
+        }
+    }
+    if (out_counts && tid == 0) out_counts[q] = cnt;
+}
+
+// ------------------------------------------------------------ list packing ---
+__global__ void topk_pack_lists_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids, int n_lists,
+                                       int64_t nq, int k, uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
+                                       int64_t cand_cap) {
+    // one workgroup per query; keeps only valid (id >= 0) entries
+    const int64_t q = blockIdx.x;
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int total = n_lists * k;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int l = i / k, j = i - l * k;
+        const int64_t src = ((int64_t)l * nq + q) * k + j;
+        const int64_t id = ids[src];
+        if (id >= 0) {
+            const int pos = atomicAdd(&cnt, 1);
+            cand_keys[q * cand_cap + pos] = sr_make_key(scores[src], (uint32_t)id);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cand_count[q] = cnt;
+}
+
+// ------------------------------------------------------------------- host ---
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int TopkWS::ensure(int64_t nq, int kk, int64_t cc) {
+    if (nq <= nq_cap && kk <= k && cc <= cand_cap) return SR_OK;
+    release();
+    nq_cap = nq;
+    k = kk;
+    cand_cap = cc;
+    SR_CHECK_HIP(hipMalloc(&run_keys, sizeof(uint64_t) * (size_t)nq * (size_t)kk));
+    SR_CHECK_HIP(hipMalloc(&run_count, sizeof(int) * (size_t)nq));
+    SR_CHECK_HIP(hipMalloc(&tau, sizeof(float) * (size_t)nq));
+    SR_CHECK_HIP(hipMalloc(&cand_keys, sizeof(uint64_t) * (size_t)nq * (size_t)cc));
+    SR_CHECK_HIP(hipMalloc(&cand_count, sizeof(int) * (size_t)nq));
+    return SR_OK;
+}
+
+void TopkWS::release() {
+    if (run_keys) (void)hipFree(run_keys);
+    if (run_count) (void)hipFree(run_count);
+    if (tau) (void)hipFree(tau);
+    if (cand_keys) (void)hipFree(cand_keys);
+    if (cand_count) (void)hipFree(cand_count);
+    run_keys = cand_keys = nullptr;
+    run_count = cand_count = nullptr;
+    tau = nullptr;
+    nq_cap = 0;
+    k = 0;
+    cand_cap = 0;
+}
+
+int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    hipLaunchKernelGGL(topk_reset_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, ws.run_count,
+                       ws.cand_count, ws.tau, nq);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+// NOTE: kernels index run_keys with stride ws.k and cand_keys with stride ws.cand_cap
+// (the ALLOCATED sizes); `k` below is the logical k of this search and must equal ws.k.
+int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
+    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
+                       ws.cand_keys, ws.cand_count, k, ws.cand_cap);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_scores, int64_t* d_out_ids,
+                  int32_t* d_out_counts, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    const int P = next_pow2(k < 2 ? 2 : k);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3((unsigned)nq), dim3(256), sizeof(uint64_t) * (size_t)P, s, ws.run_keys,
+                       ws.run_count, k, P, pad_score, d_out_scores, d_out_ids, d_out_counts);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+static std::mutex g_merge_mu;
+static TopkWS g_merge_ws;
+
+extern "C" int sr_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int64_t nq, int k,
+                             float pad_score, float* d_out_scores, int64_t* d_out_ids, sr_stream stream) {
+    SR_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1 && k <= SR_MAX_TOPK, "sr_topk_merge: bad sizes (n_lists=%d nq=%lld k=%d)",
+               n_lists, (long long)nq, k);
+    SR_REQUIRE(d_scores && d_ids && d_out_scores && d_out_ids, "sr_topk_merge: null pointer");
+    if (nq == 0) return SR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_merge_mu);
+    // exact-size workspace: strides must equal the logical sizes
+    if (g_merge_ws.k != k || g_merge_ws.cand_cap != (int64_t)n_lists * k || g_merge_ws.nq_cap < nq) {
+        g_merge_ws.release();
+        SR_TRY(g_merge_ws.ensure(nq, k, (int64_t)n_lists * k));
+    }
+    SR_TRY(topk_reset(g_merge_ws, nq, s));
+    hipLaunchKernelGGL(topk_pack_lists_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_scores, d_ids, n_lists, nq, k,
+                       g_merge_ws.cand_keys, g_merge_ws.cand_count, g_merge_ws.cand_cap);
+    SR_CHECK_LAUNCH();
+    SR_TRY(topk_compact(g_merge_ws, nq, k, s));
+    SR_TRY(topk_finalize(g_merge_ws, nq, k, pad_score, d_out_scores, d_out_ids, nullptr, s));
+    return SR_OK;
+}

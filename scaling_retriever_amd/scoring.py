@@ -1,0 +1,167 @@
+"""Thin torch-tensor front ends over the scoring entry points of libsr_hip.so.
+
+These hold device memory (torch tensors) and call the C ABI; all arithmetic is in
+the HIP kernels (csrc/dense_score.hip, csrc/sparse_score.hip, csrc/topk.hip).
+The reference-shaped classes in indexer.py are built on top of these.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DenseIndexHIP:
+    """Flat inner-product index resident in HBM (segments of fp32 [n, dim] rows)."""
+
+    def __init__(self, dim, device=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.dim = int(dim)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = ctypes.c_void_p()
+        _lib.check(self.lib.sr_dense_index_create(ctypes.byref(self._h), self.dim), "sr_dense_index_create")
+        self._segments = []  # keeps the device tensors alive (the C side holds non-owning views)
+
+    def add_device_rows(self, rows, id_base=None, id_stride=1):
+        """rows: fp32 cuda tensor [n, dim] (kept alive by this object, not copied)."""
+        if rows.dtype != torch.float32 or rows.dim() != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [n, {self.dim}] rows, got {rows.dtype} {tuple(rows.shape)}")
+        if not rows.is_cuda:
+            raise ValueError("add_device_rows needs a cuda tensor")
+        rows = rows.contiguous()
+        if id_base is None:
+            id_base = self.ntotal
+        _lib.check(self.lib.sr_dense_index_add(self._h, _ptr(rows), rows.shape[0], int(id_base), int(id_stride)),
+                   "sr_dense_index_add")
+        self._segments.append(rows)
+
+    def add_host_rows(self, rows, buffer_size=50000, id_base=None, id_stride=1):
+        """rows: np.float32 [n, dim]; streamed to HBM in `buffer_size`-row pieces."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] rows, got {rows.shape}")
+        n = rows.shape[0]
+        dev = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        for i in range(0, n, buffer_size):
+            dev[i:i + buffer_size].copy_(torch.from_numpy(rows[i:i + buffer_size]), non_blocking=False)
+        self.add_device_rows(dev, id_base=id_base, id_stride=id_stride)
+
+    @property
+    def ntotal(self):
+        return int(self.lib.sr_dense_index_ntotal(self._h))
+
+    def set_workspace_limit(self, nbytes):
+        _lib.check(self.lib.sr_dense_index_set_workspace_limit(self._h, int(nbytes)))
+
+    def search(self, queries, k):
+        """queries: fp32 cuda tensor [nq, dim] -> (scores fp32 [nq,k], ids int64 [nq,k]) cuda tensors."""
+        if queries.dtype != torch.float32 or queries.dim() != 2 or queries.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [nq, {self.dim}] queries, got {queries.dtype} {tuple(queries.shape)}")
+        if not queries.is_cuda:
+            raise ValueError("queries must be a cuda tensor")
+        queries = queries.contiguous()
+        nq = queries.shape[0]
+        scores = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
+        _lib.check(self.lib.sr_dense_search(self._h, _ptr(queries), nq, int(k), _ptr(scores), _ptr(ids),
+                                            _lib.stream_ptr()), "sr_dense_search")
+        return scores, ids
+
+    def close(self):
+        if self._h:
+            self.lib.sr_dense_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        self._segments = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SparseIndexHIP:
+    """CSR-by-term inverted index resident in HBM.
+
+    indptr int64 [V+1], doc_ids int32 [nnz] (strictly ascending inside each term),
+    vals fp32 [nnz]; n_docs = IndexDictOfArray.nb_docs().
+    """
+
+    def __init__(self, indptr, doc_ids, vals, n_docs, device=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+        def to_dev(x, dt):
+            if isinstance(x, np.ndarray):
+                x = torch.from_numpy(np.ascontiguousarray(x))
+            return x.to(device=self.device, dtype=dt).contiguous()
+        self.indptr = to_dev(indptr, torch.int64)
+        self.doc_ids = to_dev(doc_ids, torch.int32)
+        self.vals = to_dev(vals, torch.float32)
+        if self.doc_ids.numel() == 0:  # keep valid pointers
+            self.doc_ids = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.vals = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.n_terms = self.indptr.numel() - 1
+        self.n_docs = int(n_docs)
+        self._h = ctypes.c_void_p()
+        _lib.check(self.lib.sr_sparse_index_create(ctypes.byref(self._h), _ptr(self.indptr), _ptr(self.doc_ids),
+                                                   _ptr(self.vals), self.n_terms, self.n_docs, _lib.stream_ptr()),
+                   "sr_sparse_index_create")
+
+    def set_workspace_limit(self, nbytes):
+        _lib.check(self.lib.sr_sparse_index_set_workspace_limit(self._h, int(nbytes)))
+
+    def search(self, q_indptr, q_cols, q_vals, k, threshold=0.0, id_base=0, id_stride=1):
+        """Queries as CSR tensors. Returns (scores [nq,k], ids [nq,k], counts [nq]) cuda tensors."""
+        def to_dev(x, dt):
+            if isinstance(x, np.ndarray):
+                x = torch.from_numpy(np.ascontiguousarray(x))
+            return x.to(device=self.device, dtype=dt).contiguous()
+        q_indptr = to_dev(q_indptr, torch.int64)
+        q_cols = to_dev(q_cols, torch.int32)
+        q_vals = to_dev(q_vals, torch.float32)
+        nq = q_indptr.numel() - 1
+        if q_cols.numel() == 0:
+            q_cols = torch.zeros(1, dtype=torch.int32, device=self.device)
+            q_vals = torch.zeros(1, dtype=torch.float32, device=self.device)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        counts = torch.empty((nq,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.sr_sparse_search(self._h, _ptr(q_indptr), _ptr(q_cols), _ptr(q_vals), nq, int(k),
+                                             float(threshold), int(id_base), int(id_stride), _ptr(scores), _ptr(ids),
+                                             _ptr(counts), _lib.stream_ptr()), "sr_sparse_search")
+        return scores, ids, counts
+
+    def close(self):
+        if self._h:
+            self.lib.sr_sparse_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def topk_merge(scores, ids, pad_score=-3.402823466e38):
+    """Merge per-shard top-k lists: scores fp32 [W, nq, k], ids int64 [W, nq, k] (cuda) -> ([nq,k], [nq,k])."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    if scores.dim() != 3 or ids.shape != scores.shape:
+        raise ValueError("expected scores/ids of shape [n_lists, nq, k]")
+    scores = scores.contiguous().float()
+    ids = ids.contiguous().to(torch.int64)
+    W, nq, k = scores.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    _lib.check(lib.sr_topk_merge(_ptr(scores), _ptr(ids), W, nq, k, float(pad_score), _ptr(out_s), _ptr(out_i),
+                                 _lib.stream_ptr()), "sr_topk_merge")
+    return out_s, out_i

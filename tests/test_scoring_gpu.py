@@ -1,0 +1,263 @@
+"""GPU parity: HIP scoring kernels (through the C ABI) vs the CPU oracle.
+
+Dense: reference = DenseFlatIndexer.search_knn over faiss IndexFlatIP
+(/root/reference/scaling_retriever/indexer.py:191-217) - exact fp32 IP, top-k desc.
+Sparse: reference = SparseRetrieval.numba_score_float + select_topk
+(/root/reference/scaling_retriever/indexer.py:315-344).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring as O
+
+pytestmark = pytest.mark.gpu
+
+FLT_MIN = np.float32(-3.402823466e38)
+
+
+def _dense_case(nq, n, h, k, seed, segments=1, scale=1.0):
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(seed)
+    Q = (rng.standard_normal((nq, h), dtype=np.float32) * scale).astype(np.float32)
+    D = (rng.standard_normal((n, h), dtype=np.float32) * scale).astype(np.float32)
+    idx = DenseIndexHIP(h)
+    bounds = np.linspace(0, n, segments + 1).astype(int)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        idx.add_host_rows(D[a:b], buffer_size=1000)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    torch.cuda.synchronize()
+    return Q, D, s.cpu().numpy(), i.cpu().numpy()
+
+
+def _check_dense_exact(Q, D, s, i, k):
+    """Bit-exact against the k-ordered fmaf chain oracle + (score desc, id asc) top-k."""
+    F = O.dense_scores_fma(Q, D, O.mfma_korder(Q.shape[1]))
+    es, ei = O.topk_rows(F, k)
+    assert np.array_equal(i, ei), f"id mismatch: {np.argwhere(i != ei)[:5]}"
+    assert np.array_equal(s, es)
+
+
+@pytest.mark.parametrize("nq,n,h,k", [
+    (1, 1000, 64, 10),          # single query (HBM-bound config)
+    (16, 5000, 128, 100),
+    (33, 3000, 64, 7),          # TN=64 config, ragged
+    (100, 2500, 256, 1000),     # TN=128 config, k close to n
+    (300, 4097, 64, 50),        # TN=256 config, ragged docs
+])
+def test_dense_search_bit_exact(nq, n, h, k):
+    Q, D, s, i = _dense_case(nq, n, h, k, seed=nq + n)
+    _check_dense_exact(Q, D, s, i, k)
+
+
+def test_dense_matches_sgemm_oracle():
+    """Against the faiss-style restatement (BLAS sgemm): same ids except near-ties, scores to 1e-5 rel."""
+    nq, n, h, k = 64, 20000, 256, 100
+    Q, D, s, i = _dense_case(nq, n, h, k, seed=5)
+    es, ei = O.flat_ip_search(Q, D, k)
+    np.testing.assert_allclose(s, es, rtol=2e-5, atol=2e-5)
+    mism = (i != ei)
+    if mism.any():  # only allowed where neighbouring scores are within rounding
+        r, c = np.nonzero(mism)
+        assert np.all(np.abs(es[r, c] - s[r, c]) <= 2e-5 * np.maximum(1, np.abs(es[r, c])))
+    assert mism.mean() < 0.01
+
+
+def test_dense_k_larger_than_n_pads_like_faiss():
+    Q, D, s, i = _dense_case(5, 40, 64, 64, seed=9)
+    F = O.dense_scores_fma(Q, D, O.mfma_korder(64))
+    es, ei = O.topk_rows(F, 64)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    assert (i[:, 40:] == -1).all() and (s[:, 40:] == FLT_MIN).all()
+
+
+def test_dense_ties_resolve_to_lowest_doc_index():
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    h, n = 64, 2000
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((10, h), dtype=np.float32)
+    D = base[rng.integers(0, 10, size=n)]          # heavy duplication -> many exact ties
+    Q = rng.standard_normal((7, h), dtype=np.float32)
+    idx = DenseIndexHIP(h)
+    idx.add_host_rows(D)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), 100)
+    _check_dense_exact(Q, D, s.cpu().numpy(), i.cpu().numpy(), 100)
+
+
+def test_dense_multi_segment_and_strided_ids():
+    """Segments with id_base/id_stride (doc-sharded layout g_row = row*W + rank, indexer.py:262)."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    h, n, W, k = 64, 3000, 3, 50
+    rng = np.random.default_rng(11)
+    D = rng.standard_normal((n, h), dtype=np.float32)
+    Q = rng.standard_normal((20, h), dtype=np.float32)
+    idx = DenseIndexHIP(h)
+    for r in range(W):
+        idx.add_device_rows(torch.from_numpy(D[r::W].copy()).cuda(), id_base=r, id_stride=W)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    _check_dense_exact(Q, D, s.cpu().numpy(), i.cpu().numpy(), k)
+
+
+def test_dense_small_workspace_forces_many_chunks():
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    h, n, k = 64, 6000, 30
+    rng = np.random.default_rng(12)
+    D = rng.standard_normal((n, h), dtype=np.float32)
+    D = D[np.argsort(D @ np.ones(h, np.float32))]     # ascending along one direction: adversarial for tau
+    Q = np.ones((3, h), np.float32) + 0.01 * rng.standard_normal((3, h), dtype=np.float32)
+    idx = DenseIndexHIP(h)
+    idx.add_host_rows(D)
+    idx.set_workspace_limit(1 << 20)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    _check_dense_exact(Q, D, s.cpu().numpy(), i.cpu().numpy(), k)
+
+
+def test_dense_linearity_property_large():
+    """Size-independent property at a larger size: scores are linear in the query, so
+    search(2q) returns the same ids with exactly doubled scores."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    h, n, k = 128, 300000, 100
+    g = torch.Generator(device="cuda").manual_seed(1)
+    D = torch.randn((n, h), device="cuda", generator=g)
+    Q = torch.randn((40, h), device="cuda", generator=g)
+    idx = DenseIndexHIP(h)
+    idx.add_device_rows(D)
+    s1, i1 = idx.search(Q, k)
+    s2, i2 = idx.search(2 * Q, k)
+    assert torch.equal(i1, i2) and torch.equal(2 * s1, s2)
+    assert (s1[:, :-1] >= s1[:, 1:]).all()           # sorted descending
+    ref = torch.topk(Q @ D.T, k, dim=1)
+    assert (ref.indices == i1).float().mean() > 0.999
+    torch.testing.assert_close(s1, ref.values, rtol=1e-4, atol=1e-4)
+
+
+def test_dense_rejects_bad_arguments():
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    with pytest.raises(ValueError):
+        DenseIndexHIP(30)
+    idx = DenseIndexHIP(64)
+    idx.add_host_rows(np.zeros((10, 64), np.float32))
+    with pytest.raises(ValueError):
+        idx.search(torch.zeros((2, 64), device="cuda"), 5000)
+    with pytest.raises(ValueError):
+        idx.search(torch.zeros((2, 32), device="cuda"), 5)
+
+
+# ---------------------------------------------------------------------- sparse
+def _random_index(rng, V, N, max_df, sort=True):
+    indptr, ids, vals = [0], [], []
+    for t in range(V):
+        df = int(rng.integers(0, max_df)) if t % 5 else 0
+        docs = rng.choice(N, size=min(df, N), replace=False).astype(np.int32)
+        if sort:
+            docs = np.sort(docs)
+        ids.append(docs)
+        vals.append(np.log1p(rng.uniform(0, 20, size=len(docs))).astype(np.float32))
+        indptr.append(indptr[-1] + len(docs))
+    return np.array(indptr, np.int64), np.concatenate(ids), np.concatenate(vals)
+
+
+def _random_queries(rng, V, nq, max_terms):
+    qi, qc, qv = [0], [], []
+    for _ in range(nq):
+        L0 = int(rng.integers(0, max_terms + 1))
+        cols = np.sort(rng.choice(V, size=L0, replace=False)).astype(np.int32)
+        qc.append(cols)
+        qv.append(np.log1p(rng.uniform(0, 20, size=L0)).astype(np.float32))
+        qi.append(qi[-1] + L0)
+    return np.array(qi, np.int64), np.concatenate(qc), np.concatenate(qv)
+
+
+def _check_sparse(indptr, ids, vals, N, qi, qc, qv, k, thr):
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    s, i, c = idx.search(qi, qc, qv, k, threshold=thr)
+    torch.cuda.synchronize()
+    s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
+    for q in range(len(qi) - 1):
+        cols, v = qc[qi[q]:qi[q + 1]], qv[qi[q]:qi[q + 1]]
+        fi, neg = O.numba_score_float(indptr, ids, vals, cols, v, thr, N)
+        ei, es = O.select_topk(fi, neg, k)
+        assert c[q] == len(ei), (q, c[q], len(ei))
+        assert np.array_equal(i[q, :c[q]], ei), q
+        assert np.array_equal(s[q, :c[q]], es), q     # bit-exact: term-serial unfused fp32 sums
+        assert (i[q, c[q]:] == -1).all()
+
+
+def test_sparse_golden_index(golden_dir):
+    """The golden index of tests/golden/sparse_score.npz (posting lists unsorted, as in a
+    merged multi-rank index): sort each list by doc id, then compare with the reference outputs."""
+    import os
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    z = np.load(os.path.join(golden_dir, "sparse_score.npz"))
+    indptr, ids, vals, N = z["indptr"], z["doc_ids"].copy(), z["vals"].copy(), int(z["N"])
+    for t in range(len(indptr) - 1):
+        b, e = indptr[t], indptr[t + 1]
+        o = np.argsort(ids[b:e], kind="stable")
+        ids[b:e], vals[b:e] = ids[b:e][o], vals[b:e][o]
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    for q in range(int(z["nq"])):
+        cols, v = z[f"q{q}:cols"], z[f"q{q}:vals"]
+        thr, k = float(z[f"q{q}:threshold"]), int(z[f"q{q}:k"])
+        s, i, c = idx.search(np.array([0, len(cols)], np.int64), cols, v, k, threshold=thr)
+        s, i, c = s.cpu().numpy()[0], i.cpu().numpy()[0], int(c.cpu().numpy()[0])
+        o = np.argsort(i[:c])
+        assert np.array_equal(i[:c][o], z[f"q{q}:topk_idx_sorted"]), q
+        assert np.array_equal(s[:c][o], z[f"q{q}:topk_score_sorted"]), q
+
+
+@pytest.mark.parametrize("V,N,max_df,nq,max_terms,k,thr", [
+    (50, 300, 80, 10, 8, 10, 0.0),
+    (200, 20000, 3000, 40, 30, 100, 0.0),       # 3 doc tiles
+    (300, 70000, 20000, 25, 300, 1000, 0.0),    # > 256 query terms: two term batches
+    (100, 9000, 2000, 12, 10, 50, 3.0),         # positive threshold
+    (100, 9000, 2000, 6, 10, 50, -1.0),         # negative threshold: untouched docs qualify too
+])
+def test_sparse_search_bit_exact(V, N, max_df, nq, max_terms, k, thr):
+    rng = np.random.default_rng(V + N)
+    indptr, ids, vals = _random_index(rng, V, N, max_df)
+    qi, qc, qv = _random_queries(rng, V, nq, min(max_terms, V))
+    _check_sparse(indptr, ids, vals, N, qi, qc, qv, k, thr)
+
+
+def test_sparse_rejects_unsorted_postings():
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    indptr = np.array([0, 3], np.int64)
+    with pytest.raises(ValueError):
+        SparseIndexHIP(indptr, np.array([5, 2, 9], np.int32), np.ones(3, np.float32), 10)
+    with pytest.raises(ValueError):
+        SparseIndexHIP(indptr, np.array([1, 2, 11], np.int32), np.ones(3, np.float32), 10)
+
+
+def test_sparse_many_queries_batches_and_small_workspace():
+    rng = np.random.default_rng(77)
+    V, N = 400, 50000
+    indptr, ids, vals = _random_index(rng, V, N, 5000)
+    qi, qc, qv = _random_queries(rng, V, 1500, 12)          # > 1024 queries: two query batches
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    idx.set_workspace_limit(64 << 20)
+    s, i, c = idx.search(qi, qc, qv, 20)
+    es_i, es_s, es_c = O.sparse_retrieve_c(indptr, ids, vals, qi, qc, qv, 20, 0.0, N, q_threads=4)
+    assert np.array_equal(c.cpu().numpy(), es_c)
+    assert np.array_equal(i.cpu().numpy(), es_i)
+    assert np.array_equal(s.cpu().numpy(), es_s)
+
+
+# ----------------------------------------------------------------------- merge
+def test_topk_merge_equals_global_topk():
+    from scaling_retriever_amd.scoring import topk_merge
+    rng = np.random.default_rng(3)
+    W, nq, k = 4, 9, 25
+    scores = rng.standard_normal((W, nq, k)).astype(np.float32)
+    scores[0, 0, :] = scores[1, 0, :]                       # exact ties across shards
+    ids = np.stack([np.stack([rng.choice(1000, size=k, replace=False) * W + w for _ in range(nq)]) for w in range(W)])
+    ids = ids.astype(np.int64)
+    ids[2, 3, 10:] = -1                                      # a short list
+    s, i = topk_merge(torch.from_numpy(scores).cuda(), torch.from_numpy(ids).cuda())
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    for q in range(nq):
+        cs, ci = scores[:, q].ravel(), ids[:, q].ravel()
+        keep = ci >= 0
+        o = np.lexsort((ci[keep], -cs[keep].astype(np.float64)))[:k]
+        assert np.array_equal(i[q], ci[keep][o]) and np.array_equal(s[q], cs[keep][o])
