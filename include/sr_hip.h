@@ -154,6 +154,23 @@ int sr_sparse_compact(const float* d_reps, int64_t B, int64_t V, int64_t* d_row_
                       int32_t* d_cols, float* d_vals, int64_t capacity, int64_t* h_nnz,
                       sr_stream stream);
 
+/* ----------------------------------------------------- building blocks ---
+ * The two MFMA kernels of the encoder, exported for per-kernel parity tests and
+ * profiling (they are what sr_encode_* launches per layer).
+ * sr_gemm_bf16: y = A[M,K] @ W[N,K]^T, bf16 inputs, fp32 accumulate.
+ *   epilogue 0: C bf16 [M,N];  1: C fp32 [M,N] += y;  2: SwiGLU, W rows interleaved
+ *   gate/up in 16-row blocks, C bf16 [M,N/2];  3: per-sequence max over token rows,
+ *   C fp32 [n_seq,N] (pre-zeroed), d_seq_of int32 [M];  4: C fp32 [M,N].
+ * sr_attention_varlen: bidirectional GQA attention over packed sequences with the
+ *   RoPE rotation fused; d_qkv bf16 [T,(nh+2nkv)*hd], d_out bf16 [T,nh*hd],
+ *   d_cu_seqlens int32 [B+1], d_pos int32 [T], d_key_valid uint8 [T],
+ *   d_rope_cos/sin fp32 [max_pos, hd/2].                                        */
+int sr_gemm_bf16(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                 void* d_C, const int32_t* d_seq_of, sr_stream stream);
+int sr_attention_varlen(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, const int32_t* d_pos,
+                        const uint8_t* d_key_valid, const float* d_rope_cos, const float* d_rope_sin,
+                        int32_t B, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, sr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

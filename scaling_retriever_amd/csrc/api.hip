@@ -1,5 +1,5 @@
 // Error plumbing + misc entry points of the C ABI (include/sr_hip.h).
-#include "common.h"
+#include "kernels.h"
 #include <string>
 
 static thread_local std::string g_last_error;
@@ -16,3 +16,25 @@ void sr_set_error(const char* fmt, ...) {
 extern "C" const char* sr_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sr_version(void) { return 1; }
 extern "C" int sr_max_topk(void) { return SR_MAX_TOPK; }
+
+extern "C" int sr_gemm_bf16(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* d_C,
+                            const int32_t* d_seq_of, sr_stream stream) {
+    SR_REQUIRE(d_A && d_W && d_C, "sr_gemm_bf16: null pointer");
+    SR_REQUIRE(epilogue >= 0 && epilogue <= 4, "sr_gemm_bf16: unknown epilogue %d", epilogue);
+    SR_REQUIRE(epilogue != EPI_SEGMAX || d_seq_of, "sr_gemm_bf16: epilogue 3 needs d_seq_of");
+    GemmArgs g{};
+    g.A = (const bf16_t*)d_A; g.W = (const bf16_t*)d_W; g.M = M; g.N = N; g.K = K; g.C = d_C; g.seq_of = d_seq_of; g.out_ld = N;
+    return launch_gemm_bf16((GemmEpilogue)epilogue, g, (hipStream_t)stream);
+}
+
+extern "C" int sr_attention_varlen(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, const int32_t* d_pos,
+                                   const uint8_t* d_key_valid, const float* d_rope_cos, const float* d_rope_sin, int32_t B,
+                                   int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, sr_stream stream) {
+    SR_REQUIRE(d_qkv && d_out && d_cu_seqlens && d_pos && d_key_valid && d_rope_cos && d_rope_sin, "sr_attention_varlen: null pointer");
+    SR_REQUIRE(B >= 0 && num_heads > 0 && num_kv_heads > 0, "sr_attention_varlen: bad sizes");
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)d_qkv; a.out = (bf16_t*)d_out; a.cu_seqlens = d_cu_seqlens; a.pos = d_pos; a.key_valid = d_key_valid;
+    a.rope_cos = d_rope_cos; a.rope_sin = d_rope_sin; a.B = B; a.nh = num_heads; a.nkv = num_kv_heads; a.hd = head_dim;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    return launch_attention(a, (hipStream_t)stream);
+}

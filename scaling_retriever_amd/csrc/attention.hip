@@ -1,0 +1,266 @@
+// Bidirectional GQA attention over packed var-len sequences, RoPE fused (gfx950).
+//
+// Replaces SDPA inside HF's LlamaAttention as driven by LlamaBiModel: full (NON-causal)
+// attention with only padded KEYS masked
+// (scaling_retriever/modeling/bidirectional_llama.py:138-161, is_causal=False :26-41).
+// Sequences are packed (no pad rows are computed unless the caller needs them), so the
+// key-padding mask is the per-token key_valid flag.
+//
+// One workgroup = (sequence, kv head); its 4 waves walk the (q head of the group, 32-row
+// q tile) items.  Keys/values of the sequence are staged through LDS in chunks of 256
+// keys: K row-major (16-B chunks XOR-swizzled) with RoPE applied while staging, V
+// TRANSPOSED ([d][key]) so that the P.V MFMA's B operand is two 8-byte reads.
+// Scores use the swapped product S^T = K.Q^T (v_mfma_f32_32x32x16_bf16): a lane owns
+// one q row, so the softmax statistics are lane-local (+ one cross-half shuffle), and the
+// S^T accumulator is fed straight back as the A operand of O += P^T-as-A . V (no LDS
+// round trip for P).  Two passes over the keys: pass 1 = row max and normaliser (online),
+// pass 2 = recompute scores, p = exp(s - m) / l, accumulate O.  Attention is ~1 % of the
+// encoder FLOPs at S <= 192, so the second QK^T is cheaper than rescaling O.
+#include "kernels.h"
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+
+#define AT_KC 256          // keys per LDS chunk
+#define AT_VT_LD (AT_KC + 4)  // padded row of the transposed V image (bf16 elements)
+
+union Frag8 {
+    mfma_bf16x8 v;
+    bf16_t u[8];
+    uint32_t w[4];
+    uint2 d2[2];
+    uint4 q;
+};
+
+__device__ inline uint32_t pack_bf16x2(float a, float b) {
+    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    constexpr int NCH = HD / 8;        // 16-B chunks per head row
+    constexpr int NKK = HD / 16;       // MFMA k-steps over the head dim
+    constexpr int NDB = HD / 32;       // 32-wide output blocks over the head dim
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                       // [AT_KC][HD], chunk-swizzled
+    bf16_t* Vt = Ks + AT_KC * HD;                                        // [HD][AT_VT_LD]
+    unsigned char* kval = reinterpret_cast<unsigned char*>(Vt + HD * AT_VT_LD);  // [AT_KC]
+
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = a.cu_seqlens[b];
+    const int S = a.cu_seqlens[b + 1] - t0;
+    if (S <= 0) return;
+    const int G = a.nh / a.nkv;
+    const int ldq = (a.nh + 2 * a.nkv) * HD;
+    const int koff = a.nh * HD + kvh * HD;
+    const int voff = (a.nh + a.nkv) * HD + kvh * HD;
+    const int n_qt = (S + 31) / 32;
+    const int n_items = G * n_qt;
+    const int n_chunks = (S + AT_KC - 1) / AT_KC;
+    const float sc_log2 = a.scale * 1.4426950408889634f;
+    const int r = lane & 31, h = lane >> 5;
+
+    // per-item state carried across key chunks: items are wave-strided, MAXI per wave per round
+    // (a round re-stages K/V; MS MARCO passages (S ~ 75, G = 4) need one round)
+    constexpr int MAXI = HD <= 64 ? 4 : 2;
+    for (int item_base = 0; item_base < n_items; item_base += 4 * MAXI) {
+        Frag8 qf[MAXI][NKK];
+        float m_run[MAXI], l_run[MAXI];
+        f32x16 o[MAXI][NDB];
+        // ---- load + rotate Q fragments (B operand: lane = q row r, elements d = 16kk + 8h + j)
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int item = item_base + it * 4 + wave;
+            m_run[it] = -INFINITY;
+            l_run[it] = 0.f;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) o[it][db][x] = 0.f;
+            if (item < n_items) {
+                const int qh = kvh * G + item / n_qt;
+                int qrow = (item % n_qt) * 32 + r;
+                qrow = qrow < S ? qrow : S - 1;
+                const bf16_t* qp = a.qkv + (int64_t)(t0 + qrow) * ldq + qh * HD;
+                const int p = a.pos[t0 + qrow];
+                const float* cs = a.rope_cos + (int64_t)p * (HD / 2);
+                const float* sn = a.rope_sin + (int64_t)p * (HD / 2);
+                Frag8 raw[NKK];
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) raw[kk].q = *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * h);
+#pragma unroll
+                for (int kk = 0; kk < NKK / 2; ++kk) {
+                    // d = 16kk + 8h + j (first half of the head), partner d + HD/2 lives in raw[kk + NKK/2]
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int d = 16 * kk + 8 * h + j;
+                        const float c = cs[d], s_ = sn[d];
+                        const float x1 = bf16_to_f32(raw[kk].u[j]), x2 = bf16_to_f32(raw[kk + NKK / 2].u[j]);
+                        qf[it][kk].u[j] = f32_to_bf16(x1 * c - x2 * s_);
+                        qf[it][kk + NKK / 2].u[j] = f32_to_bf16(x2 * c + x1 * s_);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) qf[it][kk].q = uint4{0, 0, 0, 0};
+            }
+        }
+
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const int key0 = ch * AT_KC;
+                const int nkeys = (S - key0) < AT_KC ? (S - key0) : AT_KC;
+                const int nkb = (nkeys + 31) / 32;
+                __syncthreads();  // previous chunk fully consumed
+                // ---- stage K (rope applied) : thread handles a chunk pair (c, c + NCH/2) of one key
+                for (int idx = tid; idx < nkb * 32 * (NCH / 2); idx += 256) {
+                    const int key = idx / (NCH / 2), c = idx % (NCH / 2);
+                    Frag8 lo, hi;
+                    if (key < nkeys) {
+                        const int tok = t0 + key0 + key;
+                        const bf16_t* kp = a.qkv + (int64_t)tok * ldq + koff;
+                        Frag8 x1, x2;
+                        x1.q = *reinterpret_cast<const uint4*>(kp + c * 8);
+                        x2.q = *reinterpret_cast<const uint4*>(kp + c * 8 + HD / 2);
+                        const int p = a.pos[tok];
+                        const float* cs = a.rope_cos + (int64_t)p * (HD / 2) + c * 8;
+                        const float* sn = a.rope_sin + (int64_t)p * (HD / 2) + c * 8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float v1 = bf16_to_f32(x1.u[j]), v2 = bf16_to_f32(x2.u[j]);
+                            lo.u[j] = f32_to_bf16(v1 * cs[j] - v2 * sn[j]);
+                            hi.u[j] = f32_to_bf16(v2 * cs[j] + v1 * sn[j]);
+                        }
+                    } else {
+                        lo.q = uint4{0, 0, 0, 0};
+                        hi.q = uint4{0, 0, 0, 0};
+                    }
+                    const int sw = key & 7;
+                    *reinterpret_cast<uint4*>(Ks + key * HD + ((c ^ sw) * 8)) = lo.q;
+                    *reinterpret_cast<uint4*>(Ks + key * HD + (((c + NCH / 2) ^ sw) * 8)) = hi.q;
+                }
+                for (int key = tid; key < nkb * 32; key += 256)
+                    kval[key] = (key < nkeys) ? a.key_valid[t0 + key0 + key] : 0;
+                // ---- stage V transposed (pass 2 only)
+                if (pass == 1) {
+                    for (int idx = tid; idx < nkb * 32 * NCH; idx += 256) {
+                        const int key = idx / NCH, c = idx % NCH;
+                        Frag8 x;
+                        if (key < nkeys)
+                            x.q = *reinterpret_cast<const uint4*>(a.qkv + (int64_t)(t0 + key0 + key) * ldq + voff + c * 8);
+                        else
+                            x.q = uint4{0, 0, 0, 0};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * AT_VT_LD + key] = x.u[j];
+                    }
+                }
+                __syncthreads();
+
+#pragma unroll
+                for (int it = 0; it < MAXI; ++it) {
+                    const int item = item_base + it * 4 + wave;
+                    if (item >= n_items) continue;  // wave-uniform
+                    for (int kb = 0; kb < nkb; ++kb) {
+                        // S^T block = K[32 keys] . Q^T : A = K rows (lane r = key), B = Q (lane r = q row)
+                        f32x16 st;
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) st[x] = 0.f;
+                        const int key = kb * 32 + r;
+#pragma unroll
+                        for (int kk = 0; kk < NKK; ++kk) {
+                            Frag8 kf;
+                            kf.q = *reinterpret_cast<const uint4*>(Ks + key * HD + (((2 * kk + h) ^ (key & 7)) * 8));
+                            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[it][kk].v, st, 0, 0, 0);
+                        }
+                        // lane holds q row r; register x = key kb*32 + (x&3) + 8*(x>>2) + 4h
+                        float sv[16];
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) {
+                            const int kl = kb * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                            sv[x] = kval[kl] ? st[x] * sc_log2 : -INFINITY;
+                        }
+                        if (pass == 0) {
+                            float bm = sv[0];
+#pragma unroll
+                            for (int x = 1; x < 16; ++x) bm = fmaxf(bm, sv[x]);
+                            bm = fmaxf(bm, __shfl_xor(bm, 32));
+                            const float mn = fmaxf(m_run[it], bm);
+                            if (mn > -INFINITY) {
+                                float ps = 0.f;
+#pragma unroll
+                                for (int x = 0; x < 16; ++x) ps += exp2f(sv[x] - mn);
+                                ps += __shfl_xor(ps, 32);
+                                l_run[it] = l_run[it] * exp2f(m_run[it] - mn) + ps;
+                                m_run[it] = mn;
+                            }
+                        } else {
+                            const float mf = m_run[it];
+                            const float inv_l = l_run[it] > 0.f ? 1.f / l_run[it] : 0.f;
+                            float pv[16];
+#pragma unroll
+                            for (int x = 0; x < 16; ++x) pv[x] = (mf > -INFINITY) ? exp2f(sv[x] - mf) * inv_l : 0.f;
+                            // P^T block as the A operand of O[q][d] += sum_key P[key][q] V[key][d]:
+                            // k-step s uses registers 8s..8s+7; element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                Frag8 pf;
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) pf.w[w] = pack_bf16x2(pv[8 * s2 + 2 * w], pv[8 * s2 + 2 * w + 1]);
+#pragma unroll
+                                for (int db = 0; db < NDB; ++db) {
+                                    Frag8 vf;  // B operand: lane r = column d, elements = the same key order
+                                    const bf16_t* vp = Vt + (db * 32 + r) * AT_VT_LD + kb * 32 + 16 * s2 + 4 * h;
+                                    vf.d2[0] = *reinterpret_cast<const uint2*>(vp);
+                                    vf.d2[1] = *reinterpret_cast<const uint2*>(vp + 8);
+                                    o[it][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.v, vf.v, o[it][db], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- write O: lane = column d (r), registers = q rows
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int item = item_base + it * 4 + wave;
+            if (item >= n_items) continue;
+            const int qh = kvh * G + item / n_qt;
+            const int q0 = (item % n_qt) * 32;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int qrow = q0 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                    if (qrow < S)
+                        a.out[(int64_t)(t0 + qrow) * (a.nh * HD) + qh * HD + db * 32 + r] = f32_to_bf16(o[it][db][x]);
+                }
+        }
+    }
+}
+
+template <int HD>
+static int launch_hd(const AttnArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)AT_KC * HD * 2 + (size_t)HD * AT_VT_LD * 2 + AT_KC;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<HD>), dim3((unsigned)a.B, (unsigned)a.nkv), dim3(256), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t s) {
+    SR_REQUIRE(a.nh % a.nkv == 0, "attention: num_heads %d not a multiple of num_kv_heads %d", a.nh, a.nkv);
+    if (a.B == 0) return SR_OK;
+    switch (a.hd) {
+        case 64: return launch_hd<64>(a, s);
+        case 128: return launch_hd<128>(a, s);
+    }
+    sr_set_error("attention: head_dim %d not supported (64 or 128)", a.hd);
+    return SR_ERR_UNSUPPORTED;
+}

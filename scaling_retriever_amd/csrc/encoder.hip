@@ -1,12 +1,650 @@
-// placeholder: encoder entry points (implemented next)
-#include "common.h"
-#define NOT_YET(name) do { sr_set_error(name ": not implemented in this build"); return SR_ERR_UNSUPPORTED; } while (0)
-extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) { NOT_YET("sr_model_create"); }
-extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols, sr_stream stream) { NOT_YET("sr_model_set_weight"); }
-extern "C" int sr_model_finalize(sr_model* m) { NOT_YET("sr_model_finalize"); }
-extern "C" int sr_encode_dense(sr_model* m, const int64_t* a, const int64_t* b, int32_t B, int32_t L, float* o, sr_stream s) { NOT_YET("sr_encode_dense"); }
-extern "C" int sr_encode_sparse(sr_model* m, const int64_t* a, const int64_t* b, int32_t B, int32_t L, float* o, sr_stream s) { NOT_YET("sr_encode_sparse"); }
-extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t cap, int64_t* n, sr_stream s) { NOT_YET("sr_model_last_hidden"); }
-extern "C" int sr_model_destroy(sr_model* m) { return SR_OK; }
-extern "C" int sr_lora_merge(float* W, const float* A, const float* B, int64_t o, int64_t i, int32_t r, float sc, sr_stream s) { NOT_YET("sr_lora_merge"); }
-extern "C" int sr_sparse_compact(const float* d, int64_t B, int64_t V, int64_t* rp, int32_t* c, float* v, int64_t cap, int64_t* n, sr_stream s) { NOT_YET("sr_sparse_compact"); }
+// LlamaBiDense / LlamaBiSparse encode on gfx950: model handle, packing plan, norms,
+// pooling heads and the layer loop.  GEMMs: gemm_bf16.hip; attention: attention.hip.
+//
+// Reference semantics reproduced (file:line into HansiZeng/scaling-retriever):
+//  * backbone   LlamaBiModel over HF LlamaModel.forward, bidirectional mask on padded
+//               KEYS only, position_ids = arange(L)     modeling/bidirectional_llama.py:67-188
+//  * dense head per-token L2 normalise, mean of the LAST `len` positions (literal
+//               `[-length:]` slice, so left padding is assumed)  modeling/llm_encoder.py:424-443
+//  * sparse head log(1 + relu(max_L(logits * H^-0.25 + (1-mask) * -1e6)))
+//                                                           modeling/llm_encoder.py:186-196
+//  * precision  bf16 GEMM inputs / fp32 accumulate, fp32 residual stream, norms, rope
+//               tables, softmax and heads - the torch.autocast(bf16) regime of
+//               indexer.py:46-52,255-256 (fp32 master weights are rounded to bf16 once).
+//
+// Packing: a row keeps the contiguous span of positions it needs - the keys (mask == 1)
+// and, for the dense head, the last `len` positions - so a left-padded batch (the
+// reference's eval setting) is computed with ZERO pad tokens, while right-padded or
+// holed masks stay literal (pad query rows are computed, masked as keys).
+#include "kernels.h"
+#include <math.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ============================================================== small kernels ===
+// ---- plan: per-row span ------------------------------------------------------
+// mode 0 (dense): span = [min(first1, L - len), L); pool_start = L - len (0 if len == 0)
+// mode 1 (sparse): span = [first1, last1 + 1)
+__global__ void plan_rows_kernel(const int64_t* __restrict__ mask, int B, int L, int mode, int* __restrict__ span_start,
+                                 int* __restrict__ span_len, int* __restrict__ pool_start, int* __restrict__ row_len) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;  // 64 threads
+    int len = 0, first = L, last = -1;
+    for (int p = lane; p < L; p += 64) {
+        if (mask[(int64_t)b * L + p] != 0) {
+            ++len;
+            first = p < first ? p : first;
+            last = p > last ? p : last;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        len += __shfl_xor(len, off);
+        const int f = __shfl_xor(first, off), l = __shfl_xor(last, off);
+        first = f < first ? f : first;
+        last = l > last ? l : last;
+    }
+    if (lane == 0) {
+        int st, ln, ps;
+        if (len == 0) {
+            st = 0; ln = 0; ps = 0;
+        } else if (mode == 0) {
+            ps = L - len;
+            st = first < ps ? first : ps;
+            ln = L - st;
+        } else {
+            ps = first;
+            st = first;
+            ln = last + 1 - first;
+        }
+        span_start[b] = st;
+        span_len[b] = ln;
+        pool_start[b] = ps;
+        row_len[b] = len;
+    }
+}
+
+// exclusive scan of span_len -> cu_seqlens[B+1] (single workgroup, B <= 65536)
+__global__ void plan_scan_kernel(const int* __restrict__ span_len, int B, int* __restrict__ cu) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int b0 = tid * per, b1 = (b0 + per) < B ? (b0 + per) : B;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += span_len[b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        cu[B] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int b = b0; b < b1; ++b) { cu[b] = run; run += span_len[b]; }
+}
+
+// per packed token: source position, token id, key flag, sequence id
+__global__ void plan_tokens_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int L,
+                                   const int* __restrict__ span_start, const int* __restrict__ cu, int* __restrict__ tok_id,
+                                   int* __restrict__ pos, unsigned char* __restrict__ key_valid, int* __restrict__ seq_of,
+                                   int vocab, int mode) {
+    const int b = blockIdx.x;
+    const int t0 = cu[b], n = cu[b + 1] - t0, st = span_start[b];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int p = st + j;
+        int64_t id = ids[(int64_t)b * L + p];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // clamp (HF would raise an index error)
+        tok_id[t0 + j] = (int)id;
+        pos[t0 + j] = p;
+        const bool valid = mask[(int64_t)b * L + p] != 0;
+        key_valid[t0 + j] = valid ? 1 : 0;
+        // sparse head: masked positions inside the span take no part in the max (-2 = skip row)
+        seq_of[t0 + j] = (mode == 1 && !valid) ? -2 : b;
+    }
+}
+
+// ---- RMSNorm (fp32 variance) : one wave per token, optional embedding gather -----
+// x[t] = embed[tok_id[t]] (if embed) ; xn[t] = bf16( x * rsqrt(mean(x^2) + eps) * w )
+__global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ embed,
+                                                      const int* __restrict__ tok_id, const float* __restrict__ w,
+                                                      bf16_t* __restrict__ xn, float* __restrict__ xn_f32, int T, int H,
+                                                      float eps) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float* xr = x + (int64_t)t * H;
+    const float* src = embed ? embed + (int64_t)tok_id[t] * H : xr;
+    float ss = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if (embed) *reinterpret_cast<f32x4*>(xr + i) = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+        f32x4 y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = (v[c] * rs) * g[c];
+        if (xn) {
+            bf16x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (short)f32_to_bf16(y[c]);
+            *reinterpret_cast<bf16x4*>(xn + (int64_t)t * H + i) = o;
+        }
+        if (xn_f32) *reinterpret_cast<f32x4*>(xn_f32 + (int64_t)t * H + i) = y;
+    }
+}
+
+// ---- dense head: final RMSNorm -> per-token L2 normalise -> mean over pooled tokens -----
+// one workgroup per sequence; LDS accumulates the H-vector.
+__global__ __launch_bounds__(256) void dense_head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const int* __restrict__ cu, const int* __restrict__ pos,
+                                                         const int* __restrict__ pool_start, float* __restrict__ out,
+                                                         int H, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float accv[];  // [H]
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = cu[b], n = cu[b + 1] - t0;
+    for (int i = tid; i < H; i += 256) accv[i] = 0.f;
+    int cnt = 0;
+    const int ps = pool_start[b];
+    for (int j = 0; j < n; ++j) {
+        const int t = t0 + j;
+        if (pos[t] < ps) continue;  // uniform
+        ++cnt;
+        const float* xr = x + (int64_t)t * H;
+        float ss = 0.f;
+        for (int i = tid; i < H; i += 256) { const float v = xr[i]; ss += v * v; }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        __syncthreads();
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        const float rs = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+        float s2 = 0.f;
+        for (int i = tid; i < H; i += 256) { const float y = (xr[i] * rs) * w[i]; s2 += y * y; }
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+        if (lane == 0) red[4 + wave] = s2;
+        __syncthreads();
+        const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+        for (int i = tid; i < H; i += 256) accv[i] += ((xr[i] * rs) * w[i]) * inv;
+    }
+    const float invc = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    for (int i = tid; i < H; i += 256) out[(int64_t)b * H + i] = accv[i] * invc;
+}
+
+// ---- sparse head finish: reps = log(1 + relu(bf16_round(max_logit) * H^-0.25)) ----
+__global__ void sparse_finish_kernel(float* __restrict__ out, int64_t n, float scale, int round_bf16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = out[i];  // max over tokens of positive logits, 0 if none
+    if (round_bf16) v = bf16_to_f32(f32_to_bf16(v));
+    v *= scale;
+    out[i] = logf(fmaxf(v, 0.f) + 1.0f);
+}
+
+// ---- weights: convert / permute rows into the internal bf16 layout --------------------
+// dst[row_map(r)][c] = bf16(src[r][c]);  row_map: dst_row = base + (interleave ? blk16(r) : r)
+__global__ void convert_rows_kernel(const void* __restrict__ src, int src_dtype, int64_t rows, int64_t cols,
+                                    bf16_t* __restrict__ dst_bf16, float* __restrict__ dst_f32, int64_t dst_row_base,
+                                    int interleave /*0 none, 1 gate, 2 up*/) {
+    const int64_t r = blockIdx.x;
+    int64_t dr = r;
+    if (interleave) dr = (r / 16) * 32 + (interleave == 2 ? 16 : 0) + (r % 16);
+    dr += dst_row_base;
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) {
+        float v;
+        if (src_dtype == SR_DTYPE_F32) v = reinterpret_cast<const float*>(src)[r * cols + c];
+        else v = bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[r * cols + c]);
+        if (dst_bf16) dst_bf16[dr * cols + c] = f32_to_bf16(v);
+        if (dst_f32) dst_f32[dr * cols + c] = v;
+    }
+}
+
+// ---- LoRA merge: W += scale * B @ A -----------------------------------------------------
+__global__ void lora_merge_kernel(float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
+                                  int64_t out_f, int64_t in_f, int r, float scale) {
+    const int64_t o = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in_f) return;
+    float acc = 0.f;
+    for (int k = 0; k < r; ++k) acc += Bm[o * r + k] * A[(int64_t)k * in_f + i];
+    W[o * in_f + i] += scale * acc;
+}
+
+// ---- sparse reps -> CSR (torch.nonzero order: row-major, cols ascending) ----------------
+__global__ __launch_bounds__(256) void nnz_count_kernel(const float* __restrict__ reps, int64_t V, int64_t* __restrict__ row_nnz) {
+    __shared__ int red[4];
+    const int64_t b = blockIdx.x;
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < V; i += 256) c += reps[b * V + i] != 0.f ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_nnz[b] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void nnz_scan_kernel(const int64_t* __restrict__ row_nnz, int64_t B, int64_t* __restrict__ row_ptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t b = 0; b < B; ++b) { row_ptr[b] = run; run += row_nnz[b]; }
+        row_ptr[B] = run;
+    }
+}
+__global__ __launch_bounds__(256) void nnz_fill_kernel(const float* __restrict__ reps, int64_t V, const int64_t* __restrict__ row_ptr,
+                                                       int32_t* __restrict__ cols, float* __restrict__ vals, int64_t capacity) {
+    __shared__ int wtot[4];
+    __shared__ int64_t base;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = row_ptr[b];
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < V; i0 += 256) {
+        const int64_t i = i0 + tid;
+        const float v = i < V ? reps[b * V + i] : 0.f;
+        const int nz = v != 0.f ? 1 : 0;
+        int incl = nz;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) wb += wtot[w]; tot += wtot[w]; }
+        const int64_t p = base + wb + incl - nz;
+        if (nz && p < capacity) { cols[p] = (int32_t)i; vals[p] = v; }
+        __syncthreads();
+        if (tid == 0) base += tot;
+        __syncthreads();
+    }
+}
+
+// ==================================================================== model ====
+struct LayerW {
+    bf16_t* wqkv = nullptr;   // [(nh + 2 nkv) hd, H]
+    bf16_t* wo = nullptr;     // [H, nh hd]
+    bf16_t* wgu = nullptr;    // [2 I, H], gate/up interleaved in 16-row blocks
+    bf16_t* wdown = nullptr;  // [H, I]
+    float* ln1 = nullptr;     // [H]
+    float* ln2 = nullptr;     // [H]
+    unsigned have = 0;        // bit per tensor: q k v o gate up down ln1 ln2
+};
+
+struct sr_model {
+    sr_model_config cfg;
+    int Tm = 0, Bm = 0;        // workspace capacity (tokens rounded up to 128, sequences)
+    int max_pos = 0;
+    float* embed = nullptr;    // fp32 [V, H]
+    bf16_t* lm_head = nullptr; // bf16 [V, H] (sparse head)
+    float* norm_w = nullptr;   // [H]
+    std::vector<LayerW> layers;
+    bool have_embed = false, have_norm = false, have_lm_head = false, finalized = false;
+    float* rope_cos = nullptr; // [max_pos, hd/2]
+    float* rope_sin = nullptr;
+    // workspace
+    float* x = nullptr;        // [Tm, H] fp32 residual stream
+    bf16_t* xn = nullptr;      // [Tm, H]
+    bf16_t* qkv = nullptr;     // [Tm, (nh + 2 nkv) hd]
+    bf16_t* attn = nullptr;    // [Tm, nh hd]
+    bf16_t* act = nullptr;     // [Tm, I]
+    int *span_start = nullptr, *span_len = nullptr, *pool_start = nullptr, *row_len = nullptr, *cu = nullptr;
+    int *tok_id = nullptr, *pos = nullptr, *seq_of = nullptr;
+    unsigned char* key_valid = nullptr;
+    int* h_cu = nullptr;       // pinned host copy of cu_seqlens
+    int last_T = 0;
+    std::mutex mu;
+};
+
+static void model_free(sr_model* m) {
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(m->embed); F(m->lm_head); F(m->norm_w); F(m->rope_cos); F(m->rope_sin);
+    for (auto& l : m->layers) { F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); }
+    F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act);
+    F(m->span_start); F(m->span_len); F(m->pool_start); F(m->row_len); F(m->cu);
+    F(m->tok_id); F(m->pos); F(m->seq_of); F(m->key_valid);
+    if (m->h_cu) (void)hipHostFree(m->h_cu);
+}
+
+#define SR_ALLOC(ptr, bytes)                                                                      \
+    do {                                                                                          \
+        if (hipMalloc((void**)&(ptr), (size_t)(bytes)) != hipSuccess) {                            \
+            sr_set_error("sr_model_create: hipMalloc of %zu bytes failed", (size_t)(bytes));      \
+            model_free(m);                                                                        \
+            delete m;                                                                             \
+            return SR_ERR_NOMEM;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+static void rope_tables(const sr_model_config& c, int max_pos, std::vector<float>& cosv, std::vector<float>& sinv) {
+    // HF ROPE_INIT_FUNCTIONS["default" | "llama3"]; inv_freq kept in fp32, angles = fp32(pos) * inv_freq
+    const int hd = c.head_dim, half = hd / 2;
+    std::vector<float> inv(half);
+    for (int i = 0; i < half; ++i) {
+        double f = 1.0 / pow((double)c.rope_theta, (double)(2 * i) / (double)hd);
+        if (c.rope_llama3) {
+            const double factor = c.rope_factor, lo = c.rope_low_freq_factor, hi = c.rope_high_freq_factor;
+            const double old = (double)c.rope_original_max_pos;
+            const double low_wl = old / lo, high_wl = old / hi;
+            const double wl = 2.0 * M_PI / f;
+            const double f_l = wl > low_wl ? f / factor : f;
+            if (!(wl < high_wl) && !(wl > low_wl)) {
+                const double smooth = (old / wl - lo) / (hi - lo);
+                f = (1.0 - smooth) * f_l / factor + smooth * f_l;
+            } else {
+                f = f_l;
+            }
+        }
+        inv[i] = (float)f;
+    }
+    cosv.resize((size_t)max_pos * half);
+    sinv.resize((size_t)max_pos * half);
+    for (int p = 0; p < max_pos; ++p)
+        for (int i = 0; i < half; ++i) {
+            const float ang = (float)p * inv[i];
+            cosv[(size_t)p * half + i] = (float)cos((double)ang);
+            sinv[(size_t)p * half + i] = (float)sin((double)ang);
+        }
+}
+
+extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
+    SR_REQUIRE(out && cfg, "sr_model_create: null argument");
+    const sr_model_config& c = *cfg;
+    SR_REQUIRE(c.vocab_size > 0 && c.hidden_size > 0 && c.intermediate_size > 0 && c.num_layers > 0,
+               "sr_model_create: bad dimensions");
+    SR_REQUIRE(c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
+               "sr_model_create: num_heads %d must be a multiple of num_kv_heads %d", c.num_heads, c.num_kv_heads);
+    SR_REQUIRE(c.head_dim == 64 || c.head_dim == 128, "sr_model_create: head_dim %d not supported (64 or 128)", c.head_dim);
+    SR_REQUIRE(c.hidden_size % 64 == 0 && c.intermediate_size % 64 == 0,
+               "sr_model_create: hidden_size and intermediate_size must be multiples of 64");
+    SR_REQUIRE(c.vocab_size % 16 == 0 || !c.has_lm_head, "sr_model_create: vocab_size must be a multiple of 16 for the sparse head");
+    SR_REQUIRE(c.max_batch_tokens > 0 && c.max_batch_seqs > 0 && c.max_batch_seqs <= 65536, "sr_model_create: bad workspace sizes");
+    sr_model* m = new sr_model();
+    m->cfg = c;
+    m->Tm = (int)(ceil_div64(c.max_batch_tokens, 128) * 128);
+    m->Bm = c.max_batch_seqs;
+    m->max_pos = 8192;
+    m->layers.resize(c.num_layers);
+    const int64_t H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+    const int64_t nq = (int64_t)c.num_heads * c.head_dim, nkv = (int64_t)c.num_kv_heads * c.head_dim;
+    SR_ALLOC(m->embed, V * H * 4);
+    if (c.has_lm_head) SR_ALLOC(m->lm_head, V * H * 2);
+    SR_ALLOC(m->norm_w, H * 4);
+    for (auto& l : m->layers) {
+        SR_ALLOC(l.wqkv, (nq + 2 * nkv) * H * 2);
+        SR_ALLOC(l.wo, H * nq * 2);
+        SR_ALLOC(l.wgu, 2 * I * H * 2);
+        SR_ALLOC(l.wdown, H * I * 2);
+        SR_ALLOC(l.ln1, H * 4);
+        SR_ALLOC(l.ln2, H * 4);
+    }
+    SR_ALLOC(m->rope_cos, (int64_t)m->max_pos * (c.head_dim / 2) * 4);
+    SR_ALLOC(m->rope_sin, (int64_t)m->max_pos * (c.head_dim / 2) * 4);
+    const int64_t Tm = m->Tm;
+    SR_ALLOC(m->x, Tm * H * 4);
+    SR_ALLOC(m->xn, Tm * H * 2);
+    SR_ALLOC(m->qkv, Tm * (nq + 2 * nkv) * 2);
+    SR_ALLOC(m->attn, Tm * nq * 2);
+    SR_ALLOC(m->act, Tm * I * 2);
+    SR_ALLOC(m->span_start, m->Bm * 4);
+    SR_ALLOC(m->span_len, m->Bm * 4);
+    SR_ALLOC(m->pool_start, m->Bm * 4);
+    SR_ALLOC(m->row_len, m->Bm * 4);
+    SR_ALLOC(m->cu, (m->Bm + 1) * 4);
+    SR_ALLOC(m->tok_id, Tm * 4);
+    SR_ALLOC(m->pos, Tm * 4);
+    SR_ALLOC(m->seq_of, Tm * 4);
+    SR_ALLOC(m->key_valid, Tm);
+    if (hipHostMalloc((void**)&m->h_cu, (size_t)(2 * m->Bm + 2) * 4) != hipSuccess) {
+        sr_set_error("sr_model_create: hipHostMalloc failed");
+        model_free(m);
+        delete m;
+        return SR_ERR_NOMEM;
+    }
+    // activations that feed GEMMs are read up to the tile edge: keep them finite
+    (void)hipMemset(m->xn, 0, (size_t)(Tm * H * 2));
+    (void)hipMemset(m->attn, 0, (size_t)(Tm * nq * 2));
+    (void)hipMemset(m->act, 0, (size_t)(Tm * I * 2));
+    std::vector<float> cs, sn;
+    rope_tables(c, m->max_pos, cs, sn);
+    if (hipMemcpy(m->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        sr_set_error("sr_model_create: rope table upload failed");
+        model_free(m);
+        delete m;
+        return SR_ERR_HIP;
+    }
+    *out = m;
+    return SR_OK;
+}
+
+extern "C" int sr_model_destroy(sr_model* m) {
+    if (!m) return SR_OK;
+    model_free(m);
+    delete m;
+    return SR_OK;
+}
+
+static int convert_rows(const void* src, int dtype, int64_t rows, int64_t cols, bf16_t* dbf, float* df32, int64_t base,
+                        int interleave, hipStream_t s) {
+    hipLaunchKernelGGL(convert_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dbf, df32, base,
+                       interleave);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols,
+                                   sr_stream stream) {
+    SR_REQUIRE(m && name && d_ptr, "sr_model_set_weight: null argument");
+    SR_REQUIRE(dtype == SR_DTYPE_F32 || dtype == SR_DTYPE_BF16, "sr_model_set_weight: dtype %d not supported", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(m->mu);
+    const sr_model_config& c = m->cfg;
+    const int64_t H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+    const int64_t nq = (int64_t)c.num_heads * c.head_dim, nkv = (int64_t)c.num_kv_heads * c.head_dim;
+    std::string n(name);
+    auto shape_is = [&](int64_t r, int64_t cc) { return rows == r && cols == cc; };
+#define SHAPE_REQ(r, cc) SR_REQUIRE(shape_is((r), (cc)), "sr_model_set_weight: %s has shape [%lld, %lld], expected [%lld, %lld]", name, (long long)rows, (long long)cols, (long long)(r), (long long)(cc))
+    if (n == "model.embed_tokens.weight") {
+        SHAPE_REQ(V, H);
+        SR_TRY(convert_rows(d_ptr, dtype, V, H, (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head : nullptr, m->embed, 0, 0, s));
+        m->have_embed = true;
+        if (c.has_lm_head && c.tie_word_embeddings) m->have_lm_head = true;
+        return SR_OK;
+    }
+    if (n == "lm_head.weight") {
+        SR_REQUIRE(c.has_lm_head, "sr_model_set_weight: model was created without an lm_head");
+        SHAPE_REQ(V, H);
+        SR_TRY(convert_rows(d_ptr, dtype, V, H, m->lm_head, nullptr, 0, 0, s));
+        m->have_lm_head = true;
+        return SR_OK;
+    }
+    if (n == "model.norm.weight") {
+        SHAPE_REQ(H, 1);
+        SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, m->norm_w, 0, 0, s));
+        m->have_norm = true;
+        return SR_OK;
+    }
+    int li = -1;
+    char rest[128] = {0};
+    if (sscanf(name, "model.layers.%d.%127s", &li, rest) == 2 && li >= 0 && li < c.num_layers) {
+        LayerW& l = m->layers[li];
+        std::string r(rest);
+        if (r == "self_attn.q_proj.weight") { SHAPE_REQ(nq, H); SR_TRY(convert_rows(d_ptr, dtype, nq, H, l.wqkv, nullptr, 0, 0, s)); l.have |= 1; return SR_OK; }
+        if (r == "self_attn.k_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq, 0, s)); l.have |= 2; return SR_OK; }
+        if (r == "self_attn.v_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq + nkv, 0, s)); l.have |= 4; return SR_OK; }
+        if (r == "self_attn.o_proj.weight") { SHAPE_REQ(H, nq); SR_TRY(convert_rows(d_ptr, dtype, H, nq, l.wo, nullptr, 0, 0, s)); l.have |= 8; return SR_OK; }
+        if (r == "mlp.gate_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 1, s)); l.have |= 16; return SR_OK; }
+        if (r == "mlp.up_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 2, s)); l.have |= 32; return SR_OK; }
+        if (r == "mlp.down_proj.weight") { SHAPE_REQ(H, I); SR_TRY(convert_rows(d_ptr, dtype, H, I, l.wdown, nullptr, 0, 0, s)); l.have |= 64; return SR_OK; }
+        if (r == "input_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln1, 0, 0, s)); l.have |= 128; return SR_OK; }
+        if (r == "post_attention_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln2, 0, 0, s)); l.have |= 256; return SR_OK; }
+    }
+    sr_set_error("sr_model_set_weight: unknown tensor name '%s'", name);
+    return SR_ERR_INVALID;
+}
+
+extern "C" int sr_model_finalize(sr_model* m) {
+    SR_REQUIRE(m, "sr_model_finalize: null model");
+    SR_REQUIRE(m->have_embed, "sr_model_finalize: model.embed_tokens.weight missing");
+    SR_REQUIRE(m->have_norm, "sr_model_finalize: model.norm.weight missing");
+    SR_REQUIRE(!m->cfg.has_lm_head || m->have_lm_head, "sr_model_finalize: lm_head.weight missing");
+    for (int i = 0; i < m->cfg.num_layers; ++i)
+        SR_REQUIRE(m->layers[i].have == 511, "sr_model_finalize: layer %d is missing tensors (mask 0x%x)", i, m->layers[i].have);
+    SR_CHECK_HIP(hipDeviceSynchronize());
+    m->finalized = true;
+    return SR_OK;
+}
+
+// --------------------------------------------------------------- forward ------
+static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mask, int B, int L, int mode, hipStream_t s,
+                         int* T_out) {
+    const sr_model_config& c = m->cfg;
+    SR_REQUIRE(m->finalized, "encode: sr_model_finalize was not called");
+    SR_REQUIRE(B >= 1 && L >= 1, "encode: bad batch shape [%d, %d]", B, L);
+    SR_REQUIRE(B <= m->Bm, "encode: batch of %d sequences exceeds max_batch_seqs %d", B, m->Bm);
+    SR_REQUIRE(L <= m->max_pos, "encode: sequence length %d exceeds %d", L, m->max_pos);
+    SR_REQUIRE(d_ids && d_mask, "encode: null input");
+    const int H = c.hidden_size, I = c.intermediate_size;
+    const int nq = c.num_heads * c.head_dim, nkv = c.num_kv_heads * c.head_dim;
+
+    hipLaunchKernelGGL(plan_rows_kernel, dim3(B), dim3(64), 0, s, d_mask, B, L, mode, m->span_start, m->span_len,
+                       m->pool_start, m->row_len);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(256), 0, s, m->span_len, B, m->cu);
+    SR_CHECK_LAUNCH();
+    SR_CHECK_HIP(hipMemcpyAsync(m->h_cu, m->cu, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipMemcpyAsync(m->h_cu + m->Bm + 1, m->row_len, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    const int T = m->h_cu[B];
+    for (int b = 0; b < B; ++b)
+        SR_REQUIRE(m->h_cu[m->Bm + 1 + b] > 0, "encode: row %d has an all-zero attention_mask (empty sequence)", b);
+    SR_REQUIRE(T <= m->Tm, "encode: batch packs to %d tokens, workspace holds %d (raise max_batch_tokens or split the batch)", T, m->Tm);
+    *T_out = T;
+    m->last_T = T;
+    hipLaunchKernelGGL(plan_tokens_kernel, dim3(B), dim3(128), 0, s, d_ids, d_mask, L, m->span_start, m->cu, m->tok_id,
+                       m->pos, m->key_valid, m->seq_of, c.vocab_size, mode);
+    SR_CHECK_LAUNCH();
+
+    const unsigned nblk = (unsigned)ceil_div64(T, 4);
+    // embedding gather fused with the first input_layernorm
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, m->embed, m->tok_id, m->layers[0].ln1, m->xn,
+                       (float*)nullptr, T, H, c.rms_norm_eps);
+    SR_CHECK_LAUNCH();
+    for (int li = 0; li < c.num_layers; ++li) {
+        LayerW& l = m->layers[li];
+        if (li > 0) {
+            hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
+                               l.ln1, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
+            SR_CHECK_LAUNCH();
+        }
+        GemmArgs g{};
+        g.A = m->xn; g.W = l.wqkv; g.M = T; g.N = nq + 2 * nkv; g.K = H; g.C = m->qkv;
+        SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));
+        AttnArgs a{};
+        a.qkv = m->qkv; a.out = m->attn; a.cu_seqlens = m->cu; a.pos = m->pos; a.key_valid = m->key_valid;
+        a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.B = B; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+        a.hd = c.head_dim; a.scale = 1.0f / sqrtf((float)c.head_dim);
+        SR_TRY(launch_attention(a, s));
+        g = GemmArgs{};
+        g.A = m->attn; g.W = l.wo; g.M = T; g.N = H; g.K = nq; g.C = m->x;
+        SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
+        hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr, l.ln2,
+                           m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
+        SR_CHECK_LAUNCH();
+        g = GemmArgs{};
+        g.A = m->xn; g.W = l.wgu; g.M = T; g.N = 2 * I; g.K = H; g.C = m->act;
+        SR_TRY(launch_gemm_bf16(EPI_SWIGLU, g, s));
+        g = GemmArgs{};
+        g.A = m->act; g.W = l.wdown; g.M = T; g.N = H; g.K = I; g.C = m->x;
+        SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                               float* d_out, sr_stream stream) {
+    SR_REQUIRE(m && d_out, "sr_encode_dense: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(m->mu);
+    int T = 0;
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, s, &T));
+    hipLaunchKernelGGL(dense_head_kernel, dim3(B), dim3(256), (size_t)m->cfg.hidden_size * 4, s, m->x, m->norm_w, m->cu, m->pos,
+                       m->pool_start, d_out, m->cfg.hidden_size, m->cfg.rms_norm_eps);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                                float* d_out, sr_stream stream) {
+    SR_REQUIRE(m && d_out, "sr_encode_sparse: null argument");
+    SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_sparse: model was created without an lm_head (LlamaBiModel)");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(m->mu);
+    int T = 0;
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, s, &T));
+    const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
+    // final norm -> bf16 GEMM input
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
+                       (const int*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps);
+    SR_CHECK_LAUNCH();
+    SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
+    GemmArgs g{};
+    g.A = m->xn; g.W = m->lm_head; g.M = T; g.N = V; g.K = H; g.C = d_out; g.seq_of = m->seq_of; g.out_ld = V;
+    // rows with seq_of == -2 (mask == 0 inside the span) are skipped by the segmented max
+    SR_TRY(launch_gemm_bf16(EPI_SEGMAX, g, s));
+    const int64_t n = (int64_t)B * V;
+    hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, d_out, n,
+                       powf((float)H, -0.25f), 1);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_rows, int64_t* n_tokens, sr_stream stream) {
+    SR_REQUIRE(m && d_out && n_tokens, "sr_model_last_hidden: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(m->mu);
+    const int T = m->last_T;
+    *n_tokens = T;
+    SR_REQUIRE(capacity_rows >= T, "sr_model_last_hidden: capacity %lld < %d tokens", (long long)capacity_rows, T);
+    if (T == 0) return SR_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
+                       (const int*)nullptr, m->norm_w, (bf16_t*)nullptr, d_out, T, m->cfg.hidden_size, m->cfg.rms_norm_eps);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_lora_merge(float* d_W, const float* d_A, const float* d_B, int64_t out_features, int64_t in_features,
+                             int32_t r, float scale, sr_stream stream) {
+    SR_REQUIRE(d_W && d_A && d_B && out_features > 0 && in_features > 0 && r > 0, "sr_lora_merge: bad argument");
+    SR_REQUIRE(out_features < 65536 * 32, "sr_lora_merge: out_features too large");
+    hipLaunchKernelGGL(lora_merge_kernel, dim3((unsigned)ceil_div64(in_features, 256), (unsigned)out_features), dim3(256), 0,
+                       (hipStream_t)stream, d_W, d_A, d_B, out_features, in_features, r, scale);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_compact(const float* d_reps, int64_t B, int64_t V, int64_t* d_row_ptr, int32_t* d_cols, float* d_vals,
+                                 int64_t capacity, int64_t* h_nnz, sr_stream stream) {
+    SR_REQUIRE(d_reps && d_row_ptr && h_nnz && B >= 0 && V > 0, "sr_sparse_compact: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) { *h_nnz = 0; return SR_OK; }
+    int64_t* d_cnt = nullptr;
+    SR_CHECK_HIP(hipMalloc((void**)&d_cnt, (size_t)B * 8));
+    hipLaunchKernelGGL(nnz_count_kernel, dim3((unsigned)B), dim3(256), 0, s, d_reps, V, d_cnt);
+    hipLaunchKernelGGL(nnz_scan_kernel, dim3(1), dim3(64), 0, s, d_cnt, B, d_row_ptr);
+    int64_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, d_row_ptr + B, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_cnt);
+    SR_CHECK_HIP(e);
+    *h_nnz = total;
+    if (total > capacity || (total > 0 && (!d_cols || !d_vals))) {
+        sr_set_error("sr_sparse_compact: %lld non-zeros, capacity %lld", (long long)total, (long long)capacity);
+        return SR_ERR_NOMEM;
+    }
+    if (total > 0) {
+        hipLaunchKernelGGL(nnz_fill_kernel, dim3((unsigned)B), dim3(256), 0, s, d_reps, V, d_row_ptr, d_cols, d_vals, capacity);
+        SR_CHECK_LAUNCH();
+    }
+    return SR_OK;
+}

@@ -1,0 +1,40 @@
+// Internal launch interface of the encoder kernels (gfx950).
+#pragma once
+#include "common.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+enum GemmEpilogue {
+    EPI_STORE_BF16 = 0,  // C[M,N] bf16 = acc
+    EPI_RESID_F32 = 1,   // X[M,N] fp32 += acc            (o_proj / down_proj + residual)
+    EPI_SWIGLU = 2,      // C[M,N/2] bf16 = silu(gate) * up, W rows interleaved gate/up in 16-row blocks
+    EPI_SEGMAX = 3,      // out[seq_of[m], n] = max(out, acc) over the tokens of each sequence (sparse head)
+    EPI_STORE_F32 = 4,   // C[M,N] fp32 = acc (tests)
+};
+
+struct GemmArgs {
+    const bf16_t* A;   // activations [M, K] row-major
+    const bf16_t* W;   // weights [N, K] row-major (nn.Linear layout)
+    int M, N, K;
+    void* C;           // output (bf16 or fp32 by epilogue); ldc = N (or N/2 for SWIGLU)
+    const int* seq_of; // EPI_SEGMAX: sequence id of each token row
+    int64_t out_ld;    // EPI_SEGMAX: leading dimension of out (= N)
+};
+
+// y = A @ W^T with fused epilogue. Requirements: K % 64 == 0, N % 16 == 0 (N % 32 for SWIGLU),
+// A/W/C 16-byte aligned.
+int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s);
+
+struct AttnArgs {
+    const bf16_t* qkv;      // [T, (nh + 2*nkv) * hd] packed tokens, q heads then k heads then v heads
+    bf16_t* out;            // [T, nh * hd]
+    const int* cu_seqlens;  // [B + 1]
+    const int* pos;         // [T] rope position of each token
+    const unsigned char* key_valid;  // [T] 1 = attend to this token as a key
+    const float* rope_cos;  // [max_pos, hd/2]
+    const float* rope_sin;
+    int B, nh, nkv, hd;
+    float scale;            // 1/sqrt(hd)
+};
+// Bidirectional (non-causal) GQA attention over packed var-len sequences, RoPE fused into the loads.
+int launch_attention(const AttnArgs& a, hipStream_t s);

@@ -105,8 +105,9 @@ def _make_batch(rng, V, L, lengths, side, pad_id):
 
 ENC_CASES = {
     # name: (config kwargs, L, lengths)
-    "enc_tiny_a": (dict(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-                        num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+    # head_dim 64, MHA (2 q heads : 2 kv heads), llama3 rope scaling, tied lm_head
+    "enc_tiny_a": (dict(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=256,
                         rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=True,
                         rope_scaling={"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
                                       "high_freq_factor": 4.0, "original_max_position_embeddings": 64}),
@@ -122,8 +123,8 @@ ENC_CASES = {
                        rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=False),
                   70, [70, 3, 64, 65, 31]),
     # README toy shape (config 1): queries lens {9,8}, passages lens {9,10}
-    "enc_toy_q": (dict(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-                       num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+    "enc_toy_q": (dict(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
                        rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=True,
                        rope_scaling={"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
                                      "high_freq_factor": 4.0, "original_max_position_embeddings": 64}),
