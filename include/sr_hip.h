@@ -61,6 +61,13 @@ int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int
 /* Workspace ceiling in bytes for candidate buffers (default 4 GiB). */
 int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes);
 int sr_dense_index_destroy(sr_dense_index* idx);
+/* Measurement hook: while enabled, every launch of the score kernel is bracketed by HIP
+ * events on the search stream.  _read synchronises those events and returns the number
+ * of launches, their summed duration (ms) and the algorithmic work they covered
+ * (2*nq*rows*dim FLOP, rows*dim*4 bytes of D), then clears the log.              */
+int sr_dense_index_profile(sr_dense_index* idx, int enable);
+int sr_dense_index_profile_read(sr_dense_index* idx, int64_t* n_launches, double* total_ms,
+                                double* total_flop, double* total_d_bytes);
 
 /* ----------------------------------------------------------------- sparse ---
  * Replaces SparseRetrieval.numba_score_float + select_topk
@@ -88,6 +95,11 @@ int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int3
                      sr_stream stream);
 int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t bytes);
 int sr_sparse_index_destroy(sr_sparse_index* idx);
+/* Measurement hook as for the dense index; algorithmic bytes = 8 B per posting of the
+ * query terms that falls in the launched doc tiles (computed on the device).       */
+int sr_sparse_index_profile(sr_sparse_index* idx, int enable);
+int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_launches, double* total_ms,
+                                 double* total_posting_bytes);
 
 /* ------------------------------------------------------------ top-k merge ---
  * The one exchange step of doc-sharded retrieval: merge `n_lists` per-shard

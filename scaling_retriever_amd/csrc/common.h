@@ -87,3 +87,37 @@ int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_s
                   int64_t* d_out_ids, int32_t* d_out_counts, hipStream_t s);
 
 #define SR_MAX_TOPK 4096
+
+// ---- per-launch HIP event log (measurement hook of the search handles) ----
+#include <vector>
+struct LaunchProfile {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;   // pairs: start, stop
+    double flop = 0, bytes = 0;
+    void begin(hipStream_t s) {
+        if (!enabled) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        ev.push_back(a); ev.push_back(b);
+        (void)hipEventRecord(a, s);
+    }
+    void end(hipStream_t s, double f, double by) {
+        if (!enabled || ev.empty()) return;
+        (void)hipEventRecord(ev.back(), s);
+        flop += f; bytes += by;
+    }
+    // returns launches; synchronises
+    int64_t read(double* total_ms) {
+        double ms = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t = 0;
+            (void)hipEventSynchronize(ev[i + 1]);
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms += t;
+            (void)hipEventDestroy(ev[i]); (void)hipEventDestroy(ev[i + 1]);
+        }
+        const int64_t n = (int64_t)(ev.size() / 2);
+        ev.clear();
+        *total_ms = ms;
+        return n;
+    }
+};

@@ -165,6 +165,7 @@ struct sr_dense_index {
     int64_t ntotal = 0;
     int64_t ws_limit = 4ll << 30;
     TopkWS ws;
+    LaunchProfile prof;
     std::mutex mu;
 };
 
@@ -267,15 +268,35 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
             a.cand_cap = idx->ws.cand_cap;
             a.id_base = (uint32_t)seg.id_base;
             a.id_stride = (uint32_t)seg.id_stride;
+            idx->prof.begin(s);
             switch (cfg) {
                 case 0: SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s))); break;
                 case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
                 case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
                 default: SR_TRY((launch_dense<4, 1, 2, 1>(a, r1 - r0, s))); break;
             }
+            idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
             SR_TRY(topk_compact(idx->ws, nq, k, s));
         }
     }
     SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_profile(sr_dense_index* idx, int enable) {
+    SR_REQUIRE(idx, "sr_dense_index_profile: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->prof.enabled = enable != 0;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_profile_read(sr_dense_index* idx, int64_t* n_launches, double* total_ms, double* total_flop,
+                                           double* total_d_bytes) {
+    SR_REQUIRE(idx && n_launches && total_ms && total_flop && total_d_bytes, "sr_dense_index_profile_read: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *total_flop = idx->prof.flop;
+    *total_d_bytes = idx->prof.bytes;
+    *n_launches = idx->prof.read(total_ms);
+    idx->prof.flop = idx->prof.bytes = 0;
     return SR_OK;
 }

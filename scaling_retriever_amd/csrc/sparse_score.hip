@@ -163,8 +163,24 @@ struct sr_sparse_index {
     int32_t* skip = nullptr;
     int64_t ws_limit = 4ll << 30;
     TopkWS ws;
+    LaunchProfile prof;
+    unsigned long long* d_postings = nullptr;  // device counter of postings touched (profiling only)
     std::mutex mu;
 };
+
+// postings of the batch's query terms inside tiles [tile_begin, tile_begin + n_t): one thread per query term
+__global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, int n_tiles, const int64_t* __restrict__ q_indptr,
+                                             const int32_t* __restrict__ q_cols, int64_t q_begin, int64_t q_end, int tile_begin,
+                                             int n_t, unsigned long long* __restrict__ total) {
+    const int64_t t = q_indptr[q_begin] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n = 0;
+    if (t < q_indptr[q_end]) {
+        const int32_t* sk = skip + (int64_t)q_cols[t] * (n_tiles + 1);
+        n = (unsigned long long)(sk[tile_begin + n_t] - sk[tile_begin]);
+    }
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+}
 
 extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_indptr, const int32_t* d_doc_ids,
                                       const float* d_vals, int64_t n_terms, int64_t n_docs, sr_stream stream) {
@@ -229,7 +245,33 @@ extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
     if (idx->skip) (void)hipFree(idx->skip);
+    if (idx->d_postings) (void)hipFree(idx->d_postings);
     delete idx;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_index_profile(sr_sparse_index* idx, int enable) {
+    SR_REQUIRE(idx, "sr_sparse_index_profile: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (enable && !idx->d_postings) {
+        SR_CHECK_HIP(hipMalloc((void**)&idx->d_postings, 8));
+        SR_CHECK_HIP(hipMemset(idx->d_postings, 0, 8));
+    }
+    idx->prof.enabled = enable != 0;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_launches, double* total_ms,
+                                            double* total_posting_bytes) {
+    SR_REQUIRE(idx && n_launches && total_ms && total_posting_bytes, "sr_sparse_index_profile_read: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *n_launches = idx->prof.read(total_ms);
+    unsigned long long n = 0;
+    if (idx->d_postings) {
+        SR_CHECK_HIP(hipMemcpy(&n, idx->d_postings, 8, hipMemcpyDeviceToHost));
+        SR_CHECK_HIP(hipMemset(idx->d_postings, 0, 8));
+    }
+    *total_posting_bytes = 8.0 * (double)n;
     return SR_OK;
 }
 
@@ -281,8 +323,21 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             a.cand_cap = idx->ws.cand_cap;
             a.id_base = (uint32_t)id_base;
             a.id_stride = (uint32_t)id_stride;
+            idx->prof.begin(s);
             hipLaunchKernelGGL(sparse_score_kernel, dim3((unsigned)nqb, (unsigned)nt), dim3(256), 0, s, a);
             SR_CHECK_LAUNCH();
+            idx->prof.end(s, 0, 0);
+            if (idx->prof.enabled && idx->d_postings) {
+                int64_t h[2];
+                SR_CHECK_HIP(hipMemcpyAsync(h, d_q_indptr + qb, 8, hipMemcpyDeviceToHost, s));
+                SR_CHECK_HIP(hipMemcpyAsync(h + 1, d_q_indptr + qb + nqb, 8, hipMemcpyDeviceToHost, s));
+                SR_CHECK_HIP(hipStreamSynchronize(s));
+                const int64_t nterms = h[1] - h[0];
+                if (nterms > 0)
+                    hipLaunchKernelGGL(sparse_count_postings_kernel, dim3((unsigned)ceil_div64(nterms, 256)), dim3(256), 0, s,
+                                       idx->skip, idx->n_tiles, d_q_indptr, d_q_cols, qb, qb + nqb, (int)t0, (int)nt,
+                                       idx->d_postings);
+            }
             SR_TRY(topk_compact(idx->ws, nqb, k, s));
             t0 += nt;
             step *= 2;

@@ -1,0 +1,80 @@
+"""Doc-sharded retrieval across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference shards the corpus by document for ENCODING only - DistributedSampler(shuffle=False):
+rank r takes dataset rows r, r+W, ... (/root/reference/eval_dense.py:178, eval_sparse.py:96), the
+global row of local row i being g_row = i*W + rank (/root/reference/scaling_retriever/indexer.py:262)
+- and then scores on ONE process (eval_dense.py:191, eval_sparse.py:114).  Here each GPU also keeps
+and scores the documents it encoded; the only exchange is ONE gather of the per-shard top-k to rank 0
+(6980 x 1000 x 8 B = 55.8 MB per rank), followed by sr_topk_merge.
+
+Unlike the sampler, shards are NOT padded by wrap-around: no duplicate documents exist, so the merged
+result equals the single-GPU result bit for bit (same keys, same tie rule).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_total, rank, world_size):
+    """Dataset rows of this rank: rank, rank + W, ... (no wrap-around padding)."""
+    return range(rank, n_total, world_size)
+
+
+def shard_size(n_total, rank, world_size):
+    return len(shard_rows(n_total, rank, world_size))
+
+
+def pack_topk(scores, ids):
+    """(fp32 [nq,k], int64 [nq,k]) -> one int64 [nq,k] tensor: id in the high 32 bits (-1 -> 0xffffffff),
+    score bits in the low 32, so that the shard result travels in ONE collective."""
+    bits = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return ((ids.to(torch.int64) & 0xFFFFFFFF) << 32) | bits
+
+
+def unpack_topk(packed):
+    lo = packed & 0xFFFFFFFF
+    lo = torch.where(lo >= 2 ** 31, lo - 2 ** 32, lo).to(torch.int32)   # back to the original bit pattern
+    scores = lo.view(torch.float32)
+    ids = (packed >> 32) & 0xFFFFFFFF
+    ids = torch.where(ids == 0xFFFFFFFF, torch.full_like(ids, -1), ids)
+    return scores, ids
+
+
+def gather_topk(scores, ids, dst=0, group=None):
+    """The single collective of doc-sharded retrieval.  Every rank passes its local (scores, global ids)
+    [nq, k]; rank `dst` gets (scores [W,nq,k], ids [W,nq,k]), the others (None, None)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return scores.unsqueeze(0), ids.unsqueeze(0)
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    packed = pack_topk(scores, ids)
+    bufs = [torch.empty_like(packed) for _ in range(W)] if rank == dst else None
+    dist.gather(packed, gather_list=bufs, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    s, i = zip(*[unpack_topk(b) for b in bufs])
+    return torch.stack(s), torch.stack(i)
+
+
+class ShardedDenseRetriever:
+    """Each rank holds rows rank, rank+W, ... of the corpus in its own HBM (DenseIndexHIP with
+    id_base = rank, id_stride = W) and scores the replicated query matrix against them."""
+
+    def __init__(self, hidden_dim, rank=None, world_size=None):
+        from .scoring import DenseIndexHIP
+        self.rank = dist.get_rank() if rank is None and dist.is_initialized() else (rank or 0)
+        self.world_size = dist.get_world_size() if world_size is None and dist.is_initialized() else (world_size or 1)
+        self.index = DenseIndexHIP(hidden_dim)
+
+    def add_local_rows(self, rows):
+        """rows: fp32 cuda tensor [n_local, H] = the embeddings of dataset rows rank, rank+W, ..."""
+        self.index.add_device_rows(rows, id_base=self.rank, id_stride=self.world_size)
+
+    def search(self, queries, k, dst=0):
+        """queries replicated on every rank.  Returns (scores, global ids) on rank dst, (None, None) elsewhere."""
+        from .scoring import topk_merge
+        s, i = self.index.search(queries, k)
+        gs, gi = gather_topk(s, i, dst=dst)
+        if gs is None:
+            return None, None
+        if gs.shape[0] == 1:
+            return gs[0], gi[0]
+        return topk_merge(gs, gi)
