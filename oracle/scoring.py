@@ -168,6 +168,21 @@ def mfma_korder(H):
     return np.array(o, np.int32)
 
 
+def mfma_korder16(H):
+    """k visiting order of the streaming small-batch kernel (csrc/dense_stream.hip, v_mfma_f32_16x16x4_f32):
+    per 16-wide k group s, for jj = 0..3, k = 16s + 4g + jj for lane group g = 0..3."""
+    o = []
+    for s in range(H // 16):
+        for jj in range(4):
+            o += [16 * s + 4 * g + jj for g in range(4)]
+    return np.array(o, np.int32)
+
+
+def dense_korder(nq, H):
+    """Which accumulation order sr_dense_search uses: the streaming kernel serves nq <= 64 when H % 256 == 0."""
+    return mfma_korder16(H) if (nq <= 64 and H % 256 == 0) else mfma_korder(H)
+
+
 def dense_scores_fma(Q, D, korder=None):
     L = clib()
     Q = np.ascontiguousarray(Q, np.float32)

@@ -13,7 +13,9 @@
 // (score >= tau[q]) are appended as 64-bit keys to the per-query candidate buffer
 // (topk.hip).  A doc chunk = one launch; tau is raised between chunks.
 #include "common.h"
+#include "dense_stream.h"
 #include <mutex>
+#include <stdlib.h>
 #include <vector>
 
 struct DenseArgs {
@@ -30,13 +32,16 @@ struct DenseArgs {
     uint32_t id_base, id_stride;
 };
 
-// Tile = (32*WM*WAVES_M docs) x (32*WN*WAVES_N queries), 4 waves, BK = 16.
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N, BK = 16, LDK = BK + 4;
+// Tile = (32*WM*WAVES_M docs) x (32*WN*WAVES_N queries), 4 or 8 waves, BK = 16.
+// 8 waves = 2 per SIMD: while one wave sits at the k-step barrier or waits for its LDS fragments,
+// its SIMD partner keeps the (64-cycle) fp32 MFMA pipe busy.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) void dense_score_kernel(DenseArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per workgroup");
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N, LDK = BK + 4, KC = BK / 4;
     constexpr int A_CHUNKS = TM * (BK / 4), B_CHUNKS = TN * (BK / 4);
-    constexpr int A_PER_T = (A_CHUNKS + 255) / 256, B_PER_T = (B_CHUNKS + 255) / 256;
+    constexpr int A_PER_T = (A_CHUNKS + NT - 1) / NT, B_PER_T = (B_CHUNKS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][TM][LDK]
     float* Bs = smem + 2 * TM * LDK;   // [2][TN][LDK]
@@ -51,8 +56,8 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
-            const int c = tid + i * 256;
-            const int r = c >> 2, kc = c & 3;
+            const int c = tid + i * NT;
+            const int r = c / KC, kc = c % KC;
             const int64_t row = row0 + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c < A_CHUNKS && row < a.row_end) v = *reinterpret_cast<const f32x4*>(a.D + row * H + k0 + kc * 4);
@@ -60,8 +65,8 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
-            const int c = tid + i * 256;
-            const int r = c >> 2, kc = c & 3;
+            const int c = tid + i * NT;
+            const int r = c / KC, kc = c % KC;
             const int q = q0 + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (c < B_CHUNKS && q < a.nq) v = *reinterpret_cast<const f32x4*>(a.Q + (int64_t)q * H + k0 + kc * 4);
@@ -71,13 +76,13 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
-            const int c = tid + i * 256;
-            if (c < A_CHUNKS) *reinterpret_cast<f32x4*>(&As[(buf * TM + (c >> 2)) * LDK + (c & 3) * 4]) = ra[i];
+            const int c = tid + i * NT;
+            if (c < A_CHUNKS) *reinterpret_cast<f32x4*>(&As[(buf * TM + (c / KC)) * LDK + (c % KC) * 4]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
-            const int c = tid + i * 256;
-            if (c < B_CHUNKS) *reinterpret_cast<f32x4*>(&Bs[(buf * TN + (c >> 2)) * LDK + (c & 3) * 4]) = rb[i];
+            const int c = tid + i * NT;
+            if (c < B_CHUNKS) *reinterpret_cast<f32x4*>(&Bs[(buf * TN + (c / KC)) * LDK + (c % KC) * 4]) = rb[i];
         }
     };
 
@@ -122,6 +127,10 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
 
     // ---- epilogue: lane-local tau filter, append survivors -------------------
     const int half = lane >> 5;
+    const int64_t left = a.row_end - row0;
+    const int rows_valid = left < TM ? (int)left : TM;            // doc rows of this tile that exist
+    const int lr0 = wm * WM * 32 + 4 * half;                      // local row of register 0 in block m = 0
+    const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int q = q0 + wn * WN * 32 + n * 32 + (lane & 31);
@@ -132,8 +141,8 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
         for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm * WM * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                cnt += (row < a.row_end && acc[m][n][r] >= tq) ? 1 : 0;
+                const int lr = lr0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                cnt += (lr < rows_valid && acc[m][n][r] >= tq) ? 1 : 0;
             }
         if (cnt == 0) continue;
         int pos = atomicAdd(&a.cand_count[q], cnt);
@@ -142,10 +151,10 @@ __global__ __launch_bounds__(256, 1) void dense_score_kernel(DenseArgs a) {
         for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm * WM * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lr = lr0 + m * 32 + (r & 3) + 8 * (r >> 2);
                 const float sc = acc[m][n][r];
-                if (row < a.row_end && sc >= tq) {
-                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, a.id_base + (uint32_t)row * a.id_stride);
+                if (lr < rows_valid && sc >= tq) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
                     ++pos;
                 }
             }
@@ -169,18 +178,18 @@ struct sr_dense_index {
     std::mutex mu;
 };
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
 static int launch_dense(const DenseArgs& a, int64_t rows, hipStream_t s) {
     constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
-    constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * 20;
+    constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div64(rows, TM), (unsigned)ceil_div64(a.nq, TN));
-    hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -242,13 +251,46 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     else { cfg = 3; TN = 32; }
     const int TM = 256;
     const int64_t qtiles = ceil_div64(nq, TN);
-    // enough workgroups per launch to fill 256 CUs several times over
-    int64_t chunk = TM * ceil_div64(2048, qtiles);
-    if (chunk < 16384) chunk = 16384;
+    // Workgroups per launch = doc tiles x query tiles: a multiple of the 256 CUs (one workgroup per CU:
+    // no partially filled last round), at least 2048.
+    int64_t g = 256, t = qtiles;
+    while (t) { const int64_t r = g % t; g = t; t = r; }     // g = gcd(256, qtiles)
+    const int64_t unit = 256 / g;
+    int64_t chunk = TM * unit * ceil_div64(2048, unit * qtiles);
+    static const char* env_variant = getenv("SR_DENSE_VARIANT");   // development A/B switch
+    const int variant = env_variant ? atoi(env_variant) : 1;
     int64_t max_cap = idx->ws_limit / (8 * nq);
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
+    const bool use_stream = variant != 9 && dense_stream_supports((int)nq, idx->dim);
+    if (use_stream) {
+        // HBM-bound regime: D straight to registers, chunks grow geometrically (64 Ki docs, x2 per launch)
+        int64_t cap = idx->ws_limit / (8 * nq);
+        if (cap > (1ll << 22)) cap = 1ll << 22;
+        cap = (cap / 128) * 128;
+        if (cap < 128) cap = 128;
+        SR_TRY(idx->ws.ensure(nq, k, cap));
+        SR_TRY(topk_reset(idx->ws, nq, s));
+        int64_t step = 65536 < cap ? 65536 : cap;
+        for (const DenseSegment& seg : idx->segs) {
+            for (int64_t r0 = 0; r0 < seg.n;) {
+                const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
+                DenseStreamArgs a;
+                a.D = seg.rows; a.Q = d_queries; a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
+                a.tau = idx->ws.tau; a.cand_keys = idx->ws.cand_keys; a.cand_count = idx->ws.cand_count;
+                a.cand_cap = idx->ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
+                idx->prof.begin(s);
+                SR_TRY(launch_dense_stream(a, s));
+                idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
+                SR_TRY(topk_compact(idx->ws, nq, k, s));
+                r0 = r1;
+                step = step * 2 < cap ? step * 2 : cap;
+            }
+        }
+        SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+        return SR_OK;
+    }
     SR_TRY(idx->ws.ensure(nq, k, chunk));
     SR_TRY(topk_reset(idx->ws, nq, s));
 
@@ -270,7 +312,11 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
             a.id_stride = (uint32_t)seg.id_stride;
             idx->prof.begin(s);
             switch (cfg) {
-                case 0: SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s))); break;
+                case 0:
+                    if (variant == 0) SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s)));
+                    else if (variant == 1) SR_TRY((launch_dense<2, 4, 4, 2>(a, r1 - r0, s)));
+                    else SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
+                    break;
                 case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
                 case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
                 default: SR_TRY((launch_dense<4, 1, 2, 1>(a, r1 - r0, s))); break;

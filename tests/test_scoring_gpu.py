@@ -32,7 +32,7 @@ def _dense_case(nq, n, h, k, seed, segments=1, scale=1.0):
 
 def _check_dense_exact(Q, D, s, i, k):
     """Bit-exact against the k-ordered fmaf chain oracle + (score desc, id asc) top-k."""
-    F = O.dense_scores_fma(Q, D, O.mfma_korder(Q.shape[1]))
+    F = O.dense_scores_fma(Q, D, O.dense_korder(Q.shape[0], Q.shape[1]))
     es, ei = O.topk_rows(F, k)
     assert np.array_equal(i, ei), f"id mismatch: {np.argwhere(i != ei)[:5]}"
     assert np.array_equal(s, es)
@@ -44,6 +44,13 @@ def _check_dense_exact(Q, D, s, i, k):
     (33, 3000, 64, 7),          # TN=64 config, ragged
     (100, 2500, 256, 1000),     # TN=128 config, k close to n
     (300, 4097, 64, 50),        # TN=256 config, ragged docs
+    (1, 70001, 256, 10),        # streaming kernel (nq <= 32, H % 256 == 0), ragged docs
+    (16, 9000, 512, 100),       # streaming, one 16-query block
+    (17, 3000, 256, 1000),      # streaming, two query blocks
+    (32, 200000, 256, 64),      # streaming, several geometric chunks
+    (33, 3000, 256, 20),        # streaming, three query blocks
+    (64, 5000, 512, 50),        # streaming, four query blocks
+    (65, 3000, 256, 20),        # just above the streaming range
 ])
 def test_dense_search_bit_exact(nq, n, h, k):
     Q, D, s, i = _dense_case(nq, n, h, k, seed=nq + n)

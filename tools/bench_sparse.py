@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: Lion-SP-1B sparse - inverted-index scoring on MSMARCO-Dev shape, 1 MI355X
+vs the host cores (synthetic index, the reference publishes no L0 statistics).
+
+  V = 128 256 terms, N = 8 841 823 docs, mean L0_d postings per doc, document frequencies Zipf(1.0)
+  (df_r ~ 1/r, capped at N); queries: L0_q distinct terms drawn from the same Zipf, values log1p(U(0,20)).
+
+Prints one JSON line: queries/s of sr_sparse_search (index resident in HBM), the HBM roofline of
+sparse_score_kernel (algorithmic bytes = 8 B per posting of the query terms, counted on the device),
+and the CPU baseline (oracle C port of numba_score_float with the reference's threading shape).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def zipf_df(V, N, total):
+    """df_r = min(N, C / r) with sum = total (water-filling on the cap)."""
+    r = np.arange(1, V + 1, dtype=np.float64)
+    lo, hi = 0.0, float(total) * V
+    for _ in range(100):
+        C = 0.5 * (lo + hi)
+        s = np.minimum(N, C / r).sum()
+        lo, hi = (C, hi) if s < total else (lo, C)
+    return np.maximum(1, np.floor(np.minimum(N, C / r))).astype(np.int64)
+
+
+def build_index(V, N, L0_d, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    df = zipf_df(V, N, N * L0_d)
+    heavy = int((df > N // 8).sum())          # Bernoulli masks for the heaviest lists, sampling for the rest
+    ids_parts, counts = [], np.zeros(V, dtype=np.int64)
+    for t in range(heavy):
+        m = torch.rand(N, device=device, generator=g) < (df[t] / N)
+        d = torch.nonzero(m)[:, 0].to(torch.int32)
+        ids_parts.append(d)
+        counts[t] = d.numel()
+    light_df = torch.from_numpy(df[heavy:]).to(device)
+    term = torch.repeat_interleave(torch.arange(heavy, V, device=device), light_df)
+    doc = torch.randint(0, N, (int(light_df.sum().item()),), device=device, generator=g)
+    key = torch.unique(term * N + doc)        # sorted by (term, doc), duplicates dropped
+    del term, doc
+    t_of = torch.div(key, N, rounding_mode="floor")
+    ids_parts.append((key - t_of * N).to(torch.int32))
+    counts[heavy:] = torch.bincount(t_of - heavy, minlength=V - heavy).cpu().numpy()
+    del key, t_of
+    doc_ids = torch.cat(ids_parts)
+    del ids_parts
+    vals = torch.log1p(torch.rand(doc_ids.numel(), device=device, generator=g) * 20.0)
+    indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(device)
+    return indptr, doc_ids, vals, df
+
+
+def build_queries(V, nq, L0_q, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    w = 1.0 / torch.arange(1, V + 1, device=device, dtype=torch.float32)
+    cols = torch.multinomial(w.expand(nq, V), L0_q, replacement=False, generator=g)
+    cols = torch.sort(cols, dim=1).values.to(torch.int32).reshape(-1).contiguous()
+    vals = torch.log1p(torch.rand(nq * L0_q, device=device, generator=g) * 20.0)
+    indptr = torch.arange(0, nq * L0_q + 1, L0_q, device=device, dtype=torch.int64)
+    return indptr, cols, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--V", type=int, default=128256)
+    ap.add_argument("--N", type=int, default=8_841_823)
+    ap.add_argument("--L0-d", type=int, default=128)
+    ap.add_argument("--L0-q", type=int, default=32)
+    ap.add_argument("--nq", type=int, default=6980)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--cpu-queries", type=int, default=32)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check", type=int, default=4, help="queries verified bit-exact against the C oracle")
+    a = ap.parse_args()
+    from scaling_retriever_amd import _lib
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    t0 = time.time()
+    indptr, doc_ids, vals, df = build_index(a.V, a.N, a.L0_d, dev, 3)
+    q_indptr, q_cols, q_vals = build_queries(a.V, a.nq, a.L0_q, dev, 4)
+    torch.cuda.synchronize()
+    nnz = doc_ids.numel()
+    t1 = time.time()
+    idx = SparseIndexHIP(indptr, doc_ids, vals, a.N)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    print(f"index: {nnz} postings ({nnz * 8 / 1e9:.2f} GB), built in {t1 - t0:.1f}s; skip table + validation {t2 - t1:.2f}s",
+          file=sys.stderr, flush=True)
+    lens = (indptr[1:] - indptr[:-1])
+    touched = lens[q_cols.long()].reshape(a.nq, a.L0_q).sum(1).double()
+    idx.search(q_indptr, q_cols, q_vals, a.k)          # warm-up
+    torch.cuda.synchronize()
+    _lib.check(lib.sr_sparse_index_profile(idx._h, 1))
+    ts = time.perf_counter()
+    for _ in range(a.steps):
+        s, i, c = idx.search(q_indptr, q_cols, q_vals, a.k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - ts) / a.steps
+    n_l, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    _lib.check(lib.sr_sparse_index_profile_read(idx._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by)))
+    _lib.check(lib.sr_sparse_index_profile(idx._h, 0))
+    gbps = by.value / (ms.value * 1e-3) / 1e9 if ms.value else 0.0
+    out = {"metric": "sparse inverted-index queries/s (index resident in HBM, top-%d)" % a.k, "value": round(a.nq / dt, 1),
+           "unit": "queries/s", "n_gpus": 1, "ms_per_pass": round(dt * 1e3, 1), "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "Lion-SP-1B sparse scoring, synthetic Zipf(1.0) index", "V": a.V, "N": a.N, "L0_d": a.L0_d,
+                      "L0_q": a.L0_q, "nq": a.nq, "k": a.k, "postings": nnz,
+                      "mean_postings_touched_per_query": float(touched.mean().item())},
+           "roofline": {"kernel": "sparse_score_kernel", "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None, "launches": int(n_l.value),
+                        "kernel_ms_per_pass": round(ms.value / a.steps, 1),
+                        "algorithmic_bytes_per_query": round(by.value / a.steps / a.nq, 1)}}
+    if not a.no_cpu or a.check:
+        from oracle import scoring as SC
+        h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
+        nqc = max(a.cpu_queries, a.check)
+        hq_indptr = q_indptr[:nqc + 1].cpu().numpy()
+        hq_cols, hq_vals = q_cols[:nqc * a.L0_q].cpu().numpy(), q_vals[:nqc * a.L0_q].cpu().numpy()
+        cores = os.cpu_count()
+        best = None
+        for qt, it in ((4, max(1, cores // 4)), (min(cores, nqc), 1)):
+            tc = time.perf_counter()
+            oi, os_, oc = SC.sparse_retrieve_c(h_indptr, h_ids, h_vals, hq_indptr, hq_cols, hq_vals, a.k, 0.0, a.N,
+                                               q_threads=qt, inner_threads=it)
+            tc = time.perf_counter() - tc
+            rec = {"q_threads": qt, "inner_threads": it, "qps": nqc / tc, "seconds": tc}
+            print("cpu:", rec, file=sys.stderr, flush=True)
+            if best is None or rec["qps"] > best["qps"]:
+                best = rec
+        if a.check:
+            gi, gs, gc = i[:a.check].cpu().numpy(), s[:a.check].cpu().numpy(), c[:a.check].cpu().numpy()
+            for q in range(a.check):
+                assert gc[q] == oc[q], (q, gc[q], oc[q])
+                assert np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), q
+            out["parity"] = f"{a.check} queries bit-exact (ids and fp32 scores) vs oracle C port at full size"
+        out["cpu_baseline"] = {"value": round(best["qps"], 3), "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{nqc} queries on the full index, oracle_sparse_retrieve (C/OpenMP port of numba_score_float + "
+                                         f"select_topk); best of the reference's shape (4 query threads x {max(1, cores // 4)} posting threads) "
+                                         f"and {min(cores, nqc)} query threads x 1: q_threads={best['q_threads']}, {best['seconds']:.1f}s"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
