@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--n-docs", type=int, default=8_841_823)
     ap.add_argument("--n-queries", type=int, default=6980)
     ap.add_argument("--topk", type=int, default=1000)
-    ap.add_argument("--query-batch", type=int, default=128)
+    ap.add_argument("--query-batch", type=int, default=512, help="queries per query_encode call (eval_batch_size; the reference script uses 128)")
     ap.add_argument("--encode-batches", type=int, default=16, help="passage batches (x128) for the encode figure")
     ap.add_argument("--layers", type=int, default=None, help="override num layers (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +120,7 @@ def main():
         cfg["num_hidden_layers"] = args.layers
     H = cfg["hidden_size"]
     t_setup = time.time()
-    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=32768).to(device).eval()
+    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=2048).to(device).eval()
     q_batches, q_lens = synth_batches(args.n_queries, args.query_batch, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device)
     n_local = shard_size(args.n_docs, rank, world)
     D = torch.empty((n_local, H), dtype=torch.float32, device=device)
@@ -165,27 +165,43 @@ def main():
     n_l, ms, fl, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
     _lib.check(lib.sr_dense_index_profile_read(index._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
     achieved_tf = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-    roofline = {"kernel": "dense_score_kernel<2,2,4,4> (fp32 MFMA 32x32x2, 256 docs x 256 queries per workgroup)",
+    # HBM/fabric traffic per launch of the dominant kernel comes from the committed PMC passes (rocprofv3
+    # cannot run inside this process); used only when it was measured on the same launch shape.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pmc = json.load(f)
+        shape = pmc["dense_score_launch"]
+        docs_per_launch = fl.value / max(1, n_l.value) / (2.0 * args.n_queries * H)
+        if shape["nq"] == args.n_queries and shape["dim"] == H and abs(docs_per_launch / shape["docs_per_launch"] - 1) < 0.02:
+            traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("dense_score_kernel")][0]
+    except Exception:
+        traffic = None
+    roofline = {"kernel": "dense_score_kernel<2,4,4,2> (fp32 MFMA 32x32x2, 256 docs x 256 queries per workgroup, 8 waves)",
                 "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                 "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4),
                 "flop_per_launch": fl.value / max(1, n_l.value), "kernel_share_of_step": round(ms.value * 1e-3 / dt, 3)}
 
     # ---- secondary figure: passages/s of doc_encode (same engine, doc-length batches) ----
-    d_batches, d_lens = synth_batches(args.encode_batches * 128, 128, 4.25, 0.35, 8, 192, cfg["vocab_size"], 3, device)
-    model.doc_encode(input_ids=d_batches[0][0], attention_mask=d_batches[0][1])
-    torch.cuda.synchronize()
-    te = time.perf_counter()
-    for i_, m_ in d_batches:
-        model.doc_encode(input_ids=i_, attention_mask=m_)
-    torch.cuda.synchronize()
-    te = time.perf_counter() - te
-    tokens = int(d_lens.sum())
-    enc_tf = tokens * (FLOP_PER_TOKEN_1B * cfg["num_hidden_layers"] / 16 + 4 * float((d_lens ** 2).sum()) / max(1, tokens) * H * cfg["num_hidden_layers"]) / te / 1e12
-    encode = {"passages_per_s_per_gpu": round(len(d_lens) / te, 1), "tokens_per_s_per_gpu": round(tokens / te, 1),
-              "mean_tokens_per_passage": round(float(d_lens.mean()), 1), "achieved_TFLOPs": round(enc_tf, 1),
-              "frac_of_bf16_mfma_peak": round(enc_tf / PEAK_BF16_MFMA_TF, 4), "sample_passages": int(len(d_lens)),
-              "batch": 128, "dtype": "bf16 GEMM / fp32 accumulate"}
+    def encode_rate(batch):
+        d_batches, d_lens = synth_batches(args.encode_batches * 128, batch, 4.25, 0.35, 8, 192, cfg["vocab_size"], 3, device)
+        model.doc_encode(input_ids=d_batches[0][0], attention_mask=d_batches[0][1])
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for i_, m_ in d_batches:
+            model.doc_encode(input_ids=i_, attention_mask=m_)
+        torch.cuda.synchronize()
+        te = time.perf_counter() - te
+        tokens = int(d_lens.sum())
+        L = cfg["num_hidden_layers"]
+        flop = tokens * FLOP_PER_TOKEN_1B * L / 16 + 4.0 * float((d_lens.astype(np.float64) ** 2).sum()) * H * L
+        return {"batch": batch, "passages_per_s_per_gpu": round(len(d_lens) / te, 1), "tokens_per_s_per_gpu": round(tokens / te, 1),
+                "achieved_TFLOPs": round(flop / te / 1e12, 1), "frac_of_bf16_mfma_peak": round(flop / te / 1e12 / PEAK_BF16_MFMA_TF, 4),
+                "mean_tokens_per_passage": round(float(d_lens.mean()), 1), "sample_passages": int(len(d_lens))}
+    e128, e512 = encode_rate(128), encode_rate(512)
+    encode = {"passages_per_s_per_gpu": e512["passages_per_s_per_gpu"], "dtype": "bf16 GEMM / fp32 accumulate",
+              "reference_batch_128": e128, "batch_512": e512}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
