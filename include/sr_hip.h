@@ -176,9 +176,16 @@ int sr_sparse_compact(const float* d_reps, int64_t B, int64_t V, int64_t* d_row_
  * sr_attention_varlen: bidirectional GQA attention over packed sequences with the
  *   RoPE rotation fused; d_qkv bf16 [T,(nh+2nkv)*hd], d_out bf16 [T,nh*hd],
  *   d_cu_seqlens int32 [B+1], d_pos int32 [T], d_key_valid uint8 [T],
- *   d_rope_cos/sin fp32 [max_pos, hd/2].                                        */
+ *   d_rope_cos/sin fp32 [max_pos, hd/2]; pass NULL for both when d_qkv is already
+ *   rotated (sr_gemm_qkv_rope output) - that is the form sr_encode_* uses.      */
 int sr_gemm_bf16(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                  void* d_C, const int32_t* d_seq_of, sr_stream stream);
+/* QKV projection with the RoPE rotation fused into the epilogue (fp32, HF rotate_half layout):
+ * C bf16 [M,N]; features [0, n_rope) = q heads then k heads are rotated with the angle of
+ * d_pos[m], features [n_rope, N) (v heads) are stored as is.                      */
+int sr_gemm_qkv_rope(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, void* d_C,
+                     const int32_t* d_pos, const float* d_rope_cos, const float* d_rope_sin,
+                     int32_t n_rope, int32_t head_dim, sr_stream stream);
 int sr_attention_varlen(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, const int32_t* d_pos,
                         const uint8_t* d_key_valid, const float* d_rope_cos, const float* d_rope_sin,
                         int32_t B, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, sr_stream stream);

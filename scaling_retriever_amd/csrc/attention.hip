@@ -35,7 +35,7 @@ __device__ inline uint32_t pack_bf16x2(float a, float b) {
     return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
 }
 
-template <int HD>
+template <int HD, bool ROPE>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     constexpr int NCH = HD / 8;        // 16-B chunks per head row
     constexpr int NKK = HD / 16;       // MFMA k-steps over the head dim
@@ -82,12 +82,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                 int qrow = (item % n_qt) * 32 + r;
                 qrow = qrow < S ? qrow : S - 1;
                 const bf16_t* qp = a.qkv + (int64_t)(t0 + qrow) * ldq + qh * HD;
-                const int p = a.pos[t0 + qrow];
-                const float* cs = a.rope_cos + (int64_t)p * (HD / 2);
-                const float* sn = a.rope_sin + (int64_t)p * (HD / 2);
                 Frag8 raw[NKK];
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) raw[kk].q = *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * h);
+                if constexpr (!ROPE) {
+#pragma unroll
+                    for (int kk = 0; kk < NKK; ++kk) qf[it][kk].q = raw[kk].q;
+                } else {
+                const int p = a.pos[t0 + qrow];
+                const float* cs = a.rope_cos + (int64_t)p * (HD / 2);
+                const float* sn = a.rope_sin + (int64_t)p * (HD / 2);
 #pragma unroll
                 for (int kk = 0; kk < NKK / 2; ++kk) {
                     // d = 16kk + 8h + j (first half of the head), partner d + HD/2 lives in raw[kk + NKK/2]
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                         qf[it][kk].u[j] = f32_to_bf16(x1 * c - x2 * s_);
                         qf[it][kk + NKK / 2].u[j] = f32_to_bf16(x2 * c + x1 * s_);
                     }
+                }
                 }
             } else {
 #pragma unroll
@@ -122,6 +127,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                         Frag8 x1, x2;
                         x1.q = *reinterpret_cast<const uint4*>(kp + c * 8);
                         x2.q = *reinterpret_cast<const uint4*>(kp + c * 8 + HD / 2);
+                        if constexpr (!ROPE) {
+                            lo.q = x1.q;
+                            hi.q = x2.q;
+                        } else {
                         const int p = a.pos[tok];
                         const float* cs = a.rope_cos + (int64_t)p * (HD / 2) + c * 8;
                         const float* sn = a.rope_sin + (int64_t)p * (HD / 2) + c * 8;
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                             const float v1 = bf16_to_f32(x1.u[j]), v2 = bf16_to_f32(x2.u[j]);
                             lo.u[j] = f32_to_bf16(v1 * cs[j] - v2 * sn[j]);
                             hi.u[j] = f32_to_bf16(v2 * cs[j] + v1 * sn[j]);
+                        }
                         }
                     } else {
                         lo.q = uint4{0, 0, 0, 0};
@@ -240,16 +250,152 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast path for sequences of at most 256 tokens (every MS MARCO batch: doc_max_length 192,
+// query_max_length 64) with q/k already rotated by the QKV GEMM epilogue: K and V^T are staged
+// once, every wave walks its (q head, 32-row q tile) items with ALL score blocks of the row held in
+// registers - one QK^T pass, exact softmax, no rescaling, no restaging.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attention_small_kernel(AttnArgs a) {
+    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = AT_KC / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vt = Ks + AT_KC * HD;
+    unsigned char* kval = reinterpret_cast<unsigned char*>(Vt + HD * AT_VT_LD);
+
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = a.cu_seqlens[b];
+    const int S = a.cu_seqlens[b + 1] - t0;
+    if (S <= 0) return;
+    const int G = a.nh / a.nkv;
+    const int ldq = (a.nh + 2 * a.nkv) * HD;
+    const int koff = a.nh * HD + kvh * HD;
+    const int voff = (a.nh + a.nkv) * HD + kvh * HD;
+    const int n_qt = (S + 31) / 32, n_items = G * n_qt, nkb = n_qt;
+    const float sc_log2 = a.scale * 1.4426950408889634f;
+    const int r = lane & 31, h = lane >> 5;
+
+    for (int idx = tid; idx < nkb * 32 * NCH; idx += 256) {
+        const int key = idx / NCH, c = idx % NCH;
+        uint4 kx = uint4{0, 0, 0, 0};
+        Frag8 vx;
+        vx.q = uint4{0, 0, 0, 0};
+        if (key < S) {
+            const bf16_t* base = a.qkv + (int64_t)(t0 + key) * ldq;
+            kx = *reinterpret_cast<const uint4*>(base + koff + c * 8);
+            vx.q = *reinterpret_cast<const uint4*>(base + voff + c * 8);
+        }
+        *reinterpret_cast<uint4*>(Ks + key * HD + ((c ^ (key & 7)) * 8)) = kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * AT_VT_LD + key] = vx.u[j];
+    }
+    for (int key = tid; key < nkb * 32; key += 256) kval[key] = (key < S) ? a.key_valid[t0 + key] : 0;
+    __syncthreads();
+
+    for (int item = wave; item < n_items; item += 4) {
+        const int qh = kvh * G + item / n_qt;
+        const int q0 = (item % n_qt) * 32;
+        int qrow = q0 + r;
+        qrow = qrow < S ? qrow : S - 1;
+        const bf16_t* qp = a.qkv + (int64_t)(t0 + qrow) * ldq + qh * HD;
+        Frag8 qf[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk].q = *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * h);
+
+        f32x16 st[MAXKB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+                f32x16 acc;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                const int key = kb * 32 + r;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    Frag8 kf;
+                    kf.q = *reinterpret_cast<const uint4*>(Ks + key * HD + (((2 * kk + h) ^ (key & 7)) * 8));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[kk].v, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int kl = kb * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                    const float v = kval[kl] ? acc[x] * sc_log2 : -INFINITY;
+                    acc[x] = v;
+                    mx = fmaxf(mx, v);
+                }
+                st[kb] = acc;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const float p = (mx > -INFINITY) ? __builtin_amdgcn_exp2f(st[kb][x] - mx) : 0.f;
+                    st[kb][x] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv_l = sum > 0.f ? 1.f / sum : 0.f;
+
+        f32x16 o[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) o[db][x] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Frag8 pf;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        pf.w[w] = pack_bf16x2(st[kb][8 * s2 + 2 * w] * inv_l, st[kb][8 * s2 + 2 * w + 1] * inv_l);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        Frag8 vf;
+                        const bf16_t* vp = Vt + (db * 32 + r) * AT_VT_LD + kb * 32 + 16 * s2 + 4 * h;
+                        vf.d2[0] = *reinterpret_cast<const uint2*>(vp);
+                        vf.d2[1] = *reinterpret_cast<const uint2*>(vp + 8);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.v, vf.v, o[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int qr = q0 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                if (qr < S) a.out[(int64_t)(t0 + qr) * (a.nh * HD) + qh * HD + db * 32 + r] = f32_to_bf16(o[db][x]);
+            }
+    }
+}
+
 template <int HD>
 static int launch_hd(const AttnArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)AT_KC * HD * 2 + (size_t)HD * AT_VT_LD * 2 + AT_KC;
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<HD>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<HD>), dim3((unsigned)a.B, (unsigned)a.nkv), dim3(256), lds, s, a);
+    const dim3 grid((unsigned)a.B, (unsigned)a.nkv);
+    if (a.apply_rope) hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), lds, s, a);
+    else if (a.max_seqlen > 0 && a.max_seqlen <= AT_KC) hipLaunchKernelGGL((attention_small_kernel<HD>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -140,41 +140,50 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
 }
 
 // ---- dense head: final RMSNorm -> per-token L2 normalise -> mean over pooled tokens -----
-// one workgroup per sequence; LDS accumulates the H-vector.
-__global__ __launch_bounds__(256) void dense_head_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const int* __restrict__ cu, const int* __restrict__ pos,
-                                                         const int* __restrict__ pool_start, float* __restrict__ out,
-                                                         int H, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float accv[];  // [H]
-    __shared__ float red[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = cu[b], n = cu[b + 1] - t0;
-    for (int i = tid; i < H; i += 256) accv[i] = 0.f;
+// (1) one wave per token: the two row statistics  rs = rsqrt(mean(x^2) + eps),  inv = 1 / max(||x rs w||, 1e-12)
+__global__ __launch_bounds__(256) void dense_head_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float2* __restrict__ stats, int T, int H, float eps) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const float* xr = x + (int64_t)t * H;
+    float ss = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+    float s2 = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float y = (v[c] * rs) * g[c]; s2 += y * y; }
+    }
+    for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+    if (lane == 0) stats[t] = make_float2(rs, 1.0f / fmaxf(sqrtf(s2), 1e-12f));
+}
+// (2) workgroup = (sequence, 256-column slab): out[b][c] = mean over pooled tokens of x[t][c] rs_t w[c] inv_t,
+//     accumulated in token order (fp32), coalesced row reads.
+__global__ __launch_bounds__(256) void dense_head_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float2* __restrict__ stats, const int* __restrict__ cu,
+                                                              const int* __restrict__ pos, const int* __restrict__ pool_start,
+                                                              float* __restrict__ out, int H) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= H) return;
+    const int t0 = cu[b], n = cu[b + 1] - t0, ps = pool_start[b];
+    const float wc = w[c];
+    float acc = 0.f;
     int cnt = 0;
-    const int ps = pool_start[b];
     for (int j = 0; j < n; ++j) {
         const int t = t0 + j;
-        if (pos[t] < ps) continue;  // uniform
+        if (pos[t] < ps) continue;
+        const float2 st = stats[t];
+        acc += ((x[(int64_t)t * H + c] * st.x) * wc) * st.y;
         ++cnt;
-        const float* xr = x + (int64_t)t * H;
-        float ss = 0.f;
-        for (int i = tid; i < H; i += 256) { const float v = xr[i]; ss += v * v; }
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-        __syncthreads();
-        if (lane == 0) red[wave] = ss;
-        __syncthreads();
-        const float rs = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
-        float s2 = 0.f;
-        for (int i = tid; i < H; i += 256) { const float y = (xr[i] * rs) * w[i]; s2 += y * y; }
-        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
-        if (lane == 0) red[4 + wave] = s2;
-        __syncthreads();
-        const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
-        const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-        for (int i = tid; i < H; i += 256) accv[i] += ((xr[i] * rs) * w[i]) * inv;
     }
-    const float invc = cnt > 0 ? 1.0f / (float)cnt : 0.f;
-    for (int i = tid; i < H; i += 256) out[(int64_t)b * H + i] = accv[i] * invc;
+    out[(int64_t)b * H + c] = cnt > 0 ? acc / (float)cnt : 0.f;
 }
 
 // ---- sparse head finish: reps = log(1 + relu(bf16_round(max_logit) * H^-0.25)) ----
@@ -516,6 +525,8 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     SR_CHECK_HIP(hipMemcpyAsync(m->h_cu + m->Bm + 1, m->row_len, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     SR_CHECK_HIP(hipStreamSynchronize(s));
     const int T = m->h_cu[B];
+    int max_len = 0;
+    for (int b = 0; b < B; ++b) max_len = (m->h_cu[b + 1] - m->h_cu[b]) > max_len ? (m->h_cu[b + 1] - m->h_cu[b]) : max_len;
     for (int b = 0; b < B; ++b)
         SR_REQUIRE(m->h_cu[m->Bm + 1 + b] > 0, "encode: row %d has an all-zero attention_mask (empty sequence)", b);
     SR_REQUIRE(T <= m->Tm, "encode: batch packs to %d tokens, workspace holds %d (raise max_batch_tokens or split the batch)", T, m->Tm);
@@ -539,11 +550,13 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         }
         GemmArgs g{};
         g.A = m->xn; g.W = l.wqkv; g.M = T; g.N = nq + 2 * nkv; g.K = H; g.C = m->qkv;
-        SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));
+        g.pos = m->pos; g.rope_cos = m->rope_cos; g.rope_sin = m->rope_sin; g.n_rope = nq + nkv; g.head_dim = c.head_dim;
+        SR_TRY(launch_gemm_bf16(EPI_QKV_ROPE, g, s));
         AttnArgs a{};
         a.qkv = m->qkv; a.out = m->attn; a.cu_seqlens = m->cu; a.pos = m->pos; a.key_valid = m->key_valid;
         a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.B = B; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
         a.hd = c.head_dim; a.scale = 1.0f / sqrtf((float)c.head_dim);
+        a.apply_rope = 0; a.max_seqlen = max_len;
         SR_TRY(launch_attention(a, s));
         g = GemmArgs{};
         g.A = m->attn; g.W = l.wo; g.M = T; g.N = H; g.K = nq; g.C = m->x;
@@ -568,8 +581,12 @@ extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const in
     std::lock_guard<std::mutex> lock(m->mu);
     int T = 0;
     SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, s, &T));
-    hipLaunchKernelGGL(dense_head_kernel, dim3(B), dim3(256), (size_t)m->cfg.hidden_size * 4, s, m->x, m->norm_w, m->cu, m->pos,
-                       m->pool_start, d_out, m->cfg.hidden_size, m->cfg.rms_norm_eps);
+    const int H = m->cfg.hidden_size;
+    float2* stats = reinterpret_cast<float2*>(m->xn);   // xn (bf16 [Tm, H]) is free after the last layer: reuse as [T] float2
+    hipLaunchKernelGGL(dense_head_stats_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, m->norm_w, stats, T, H,
+                       m->cfg.rms_norm_eps);
+    hipLaunchKernelGGL(dense_head_pool_kernel, dim3((unsigned)B, (unsigned)ceil_div64(H, 256)), dim3(256), 0, s, m->x, m->norm_w,
+                       stats, m->cu, m->pos, m->pool_start, d_out, H);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -3,65 +3,79 @@
 // y[M,N] = A[M,K] @ W[N,K]^T  (nn.Linear).  Replaces the cuBLAS GEMMs HF's
 // LlamaModel issues under torch.autocast(bf16) (scaling_retriever/indexer.py:46-52).
 //
-// Tile 128(n) x 128(m) x 64(k), 4 waves (2 x 2), each wave 64 x 64 as 4 x 4 blocks of
-// v_mfma_f32_16x16x32_bf16.  The WEIGHT tile is the MFMA A operand and the activation
-// tile the B operand, so an accumulator lane owns one token row m (lane & 15) and 4
-// consecutive output features n in its 4 registers: epilogue stores are 8 B (bf16x4) or
-// 16 B (fp32x4) per lane, gate/up and RoPE partners sit in the same lane.
-// Staging: global_load_lds 16 B (LDS-DMA), two LDS stages, one barrier per k-step; the
-// XOR swizzle (16-B chunk ^ (row & 7)) is applied on the global SOURCE address and on the
-// ds_read_b128 address (LDS image is lane-linear).  Grid is n-tile-fastest so that, with
-// round-robin XCD placement, an XCD keeps touching the same 1/8 of W (L2-resident).
+// Two tile configurations of one kernel template (BK = 64, v_mfma_f32_16x16x32_bf16):
+//   128(n) x 128(m), 4 waves (2 x 2), wave tile 64 x 64, 64 KB LDS, 2 workgroups per CU
+//   256(n) x 256(m), 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS, 1 workgroup per CU:
+//       half the L2->LDS bytes per FLOP and a full k-step (2048 MFMA cycles per SIMD) of
+//       prefetch lead, used when the problem fills the 256 CUs with 256^2 tiles.
+// The WEIGHT tile is the MFMA A operand and the activation tile the B operand, so an
+// accumulator lane owns one token row m (lane & 15) and 4 consecutive output features n in
+// its 4 registers: epilogue stores are 8 B (bf16x4) or 16 B (fp32x4) per lane, gate/up
+// partners sit in the same lane.
+// Staging: global_load_lds 16 B (LDS-DMA), two LDS stages, one barrier per k-step; the XOR
+// swizzle (16-B chunk ^ (row & 7)) is applied on the global SOURCE address and on the
+// ds_read_b128 address (the LDS image is lane-linear).  Grid is n-tile-fastest so that, with
+// round-robin XCD placement, an XCD keeps touching the same 1/8 of W.
 #include "kernels.h"
+#include <math.h>
+#include <stdlib.h>
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 
-#define G_BM 128
-#define G_BN 128
 #define G_BK 64
-#define G_STAGE_BYTES (2 * 128 * 64 * 2)  // W tile + A tile, bf16
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
+// WAVES_N x WAVES_M waves; each wave owns (16 * NB) features x (16 * MB) tokens.
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
+void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int NW = WAVES_N * WAVES_M, NT = 64 * NW;
+    constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
+    constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE_BYTES = W_BYTES + A_BYTES;
+    constexpr int W_INSTR = BN / 8 / NW, A_INSTR = BM / 8 / NW;   // 8-row (1 KB) LDS-DMA pieces per wave
+    static_assert(BN % (8 * NW) == 0 && BM % (8 * NW) == 0, "tile rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
-    const int tiles_n = (g.N + G_BN - 1) / G_BN;
+    const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+    const int tiles_n = (g.N + BN - 1) / BN;
     const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-    const int n0 = tile_n * G_BN, m0 = tile_m * G_BM;
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
     const int K = g.K;
 
-    // ---- staging addresses: wave w moves rows [32w, 32w+32) of each tile, 8 rows per instruction
+    // ---- staging addresses: wave w moves rows [w*R, (w+1)*R) of each tile, 8 rows per instruction
     const int srow = lane >> 3;                       // row inside an 8-row piece
     const int schunk = (lane & 7) ^ (srow & 7);       // source 16-B chunk (swizzle on the source)
-    const bf16_t* wsrc[4];
-    const bf16_t* asrc[4];
+    const bf16_t* wsrc[W_INSTR];
+    const bf16_t* asrc[A_INSTR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int rn = n0 + wave * 32 + i * 8 + srow;
+    for (int i = 0; i < W_INSTR; ++i) {
+        int rn = n0 + (wave * W_INSTR + i) * 8 + srow;
         rn = rn < g.N ? rn : g.N - 1;
-        int rm = m0 + wave * 32 + i * 8 + srow;
-        rm = rm < g.M ? rm : g.M - 1;
         wsrc[i] = g.W + (int64_t)rn * K + schunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        int rm = m0 + (wave * A_INSTR + i) * 8 + srow;
+        rm = rm < g.M ? rm : g.M - 1;
         asrc[i] = g.A + (int64_t)rm * K + schunk * 8;
     }
     auto stage = [&](int st, int k0) {
-        unsigned char* wbase = smem + st * G_STAGE_BYTES + (wave * 32) * 128;
-        unsigned char* abase = wbase + 128 * 128;
+        unsigned char* wbase = smem + st * STAGE_BYTES + (wave * W_INSTR) * 1024;
+        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * A_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < W_INSTR; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void_ptr)(wsrc[i] + k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void_ptr)(asrc[i] + k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
-        }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NB][MB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
     const int nk = K / G_BK;
@@ -70,22 +84,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * G_BK);
-        const unsigned char* wt = smem + cur * G_STAGE_BYTES;
-        const unsigned char* at = wt + 128 * 128;
+        const unsigned char* wt = smem + cur * STAGE_BYTES;
+        const unsigned char* at = wt + W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
-            mfma_bf16x8 wf[4], af[4];
+            mfma_bf16x8 wf[NB], af[MB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * 64 + i * 16 + frow) * 128 + pos);
+            for (int i = 0; i < NB; ++i)
+                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + i * 16 + frow) * 128 + pos);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * 64 + j * 16 + frow) * 128 + pos);
+            for (int j = 0; j < MB; ++j)
+                af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < MB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -94,12 +108,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
     if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + frow;
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
                 if (n >= g.N) continue;
                 const f32x4 v = acc[i][j];
                 if constexpr (EPI == EPI_STORE_BF16) {
@@ -119,15 +133,55 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
                 }
             }
         }
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        // q/k heads: out[d] = x[d] cos - x[d + hd/2] sin, out[d + hd/2] = x[d + hd/2] cos + x[d] sin (HF rotate_half),
+        // in fp32 on the accumulators; both halves of a head live in this lane (blocks i and i + hd/32).
+        // A wave's feature range (16 * NB) covers whole heads: NB * 16 % head_dim == 0 is checked at launch.
+        const int hd = g.head_dim, hb = hd / 32;   // hb = block distance between rotation partners
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            if (m >= g.M) continue;
+            const int p = g.pos[m];
+            bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.N;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+                if (n >= g.N) continue;
+                bf16x4 o;
+                if (n < g.n_rope) {
+                    const int d = n % hd;
+                    if (d >= hd / 2) continue;                 // written together with its first-half partner
+                    // partner block index is a compile-time offset only when unrolled over i: handle both head sizes
+                    f32x4 x1 = acc[i][j], x2;
+                    if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
+                    bf16x4 o2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = (short)f32_to_bf16(x1[r] * c[r] - x2[r] * s[r]);
+                        o2[r] = (short)f32_to_bf16(x2[r] * c[r] + x1[r] * s[r]);
+                    }
+                    *reinterpret_cast<bf16x4*>(crow + n) = o;
+                    *reinterpret_cast<bf16x4*>(crow + n + hd / 2) = o2;
+                } else {
+                    const f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(v[r]);
+                    *reinterpret_cast<bf16x4*>(crow + n) = o;
+                }
+            }
+        }
     } else if constexpr (EPI == EPI_SWIGLU) {
         const int half_n = g.N >> 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + frow;
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const int n = (n0 >> 1) + wn * 32 + (i >> 1) * 16 + fg * 4;
+            for (int i = 0; i < NB; i += 2) {
+                const int n = (n0 >> 1) + wn * NB * 8 + (i >> 1) * 16 + fg * 4;
                 if (n >= half_n) continue;
                 const f32x4 gt = acc[i][j], up = acc[i + 1][j];
                 bf16x4 o;
@@ -139,16 +193,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * half_n + n) = o;
             }
         }
-    } else {  // EPI_SEGMAX: tile of logits -> LDS, per-column segmented max over token rows, atomicMax
+    } else {  // EPI_SEGMAX (128 x 128 tile only): logits tile -> LDS, per-column segmented max over token rows
+        static_assert(EPI != EPI_SEGMAX || (BN == 128 && BM == 128), "segmented max uses the 128^2 tile");
         float* L = reinterpret_cast<float*>(smem);            // [128 m][128 n], column index XOR-swizzled by row
-        int* seq_s = reinterpret_cast<int*>(smem + 2 * G_STAGE_BYTES);  // [128]
+        int* seq_s = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);  // [128]
         if (tid < 128) seq_s[tid] = (m0 + tid < g.M) ? g.seq_of[m0 + tid] : -1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ml = wm * 64 + j * 16 + frow;
+        for (int j = 0; j < MB; ++j) {
+            const int ml = wm * MB * 16 + j * 16 + frow;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nl = wn * 64 + i * 16 + fg * 4;
+            for (int i = 0; i < NB; ++i) {
+                const int nl = wn * NB * 16 + i * 16 + fg * 4;
                 *reinterpret_cast<f32x4*>(L + ml * 128 + (nl ^ ((ml & 15) << 2))) = acc[i][j];
             }
         }
@@ -178,19 +233,50 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int EPI>
-static int launch_one(const GemmArgs& g, hipStream_t s) {
-    constexpr size_t lds = 2 * G_STAGE_BYTES + (EPI == EPI_SEGMAX ? 512 : 0);
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
+static int launch_cfg(const GemmArgs& g, hipStream_t s) {
+    constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
+    constexpr size_t lds = 2 * (size_t)(BN + BM) * 128 + (EPI == EPI_SEGMAX ? 512 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int64_t tiles = ceil_div64(g.N, G_BN) * ceil_div64(g.M, G_BM);
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3((unsigned)tiles), dim3(256), lds, s, g);
+    const int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
+                       s, g);
     SR_CHECK_LAUNCH();
     return SR_OK;
+}
+
+// 256^2 tiles when they fill the chip about as well as 128^2 tiles would (one 256^2 workgroup per CU,
+// two 128^2 workgroups per CU): compare the two tilings' round quantisation.
+static bool prefer_big_tile(const GemmArgs& g) {
+    const char* env = getenv("SR_GEMM_TILE");   // test / A-B switch: 128 | 256 (read per call)
+    if (env && *env) return atoi(env) == 256;
+    const double t256 = (double)(ceil_div64(g.N, 256) * ceil_div64(g.M, 256));
+    const double t128 = (double)(ceil_div64(g.N, 128) * ceil_div64(g.M, 128));
+    const double eff256 = t256 / (ceil(t256 / 256.0) * 256.0);
+    const double eff128 = t128 / (ceil(t128 / 512.0) * 512.0);
+    return eff256 >= 0.9 * eff128 && t256 >= 128;
+}
+
+template <int EPI>
+static int launch_one(const GemmArgs& g, hipStream_t s) {
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
+        SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
+                   "gemm(qkv+rope): bad rope arguments");
+        if (prefer_big_tile(g)) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);       // wave covers 128 features
+        if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
+        return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+    } else {
+        if constexpr (EPI != EPI_SEGMAX) {
+            if (prefer_big_tile(g)) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);
+        }
+        return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+    }
 }
 
 int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
@@ -204,6 +290,7 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
         case EPI_SWIGLU: return launch_one<EPI_SWIGLU>(g, s);
         case EPI_SEGMAX: return launch_one<EPI_SEGMAX>(g, s);
         case EPI_STORE_F32: return launch_one<EPI_STORE_F32>(g, s);
+        case EPI_QKV_ROPE: return launch_one<EPI_QKV_ROPE>(g, s);
     }
     sr_set_error("gemm: unknown epilogue %d", (int)epi);
     return SR_ERR_INVALID;

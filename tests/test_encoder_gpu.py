@@ -387,3 +387,30 @@ def test_sparse_compact_matches_torch_nonzero():
     rc = lib.sr_sparse_compact(reps.data_ptr(), 7, 1000, row_ptr.data_ptr(), cols.data_ptr(), vals.data_ptr(), 3,
                                ctypes.byref(n), L.stream_ptr())
     assert rc == L.SR_ERR_NOMEM and n.value == len(r)
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+def test_gemm_both_tile_configs_all_epilogues(tile, monkeypatch):
+    """The 256 x 256 (8-wave) and 128 x 128 (4-wave) configurations of the GEMM template, forced through
+    the SR_GEMM_TILE switch, on ragged shapes."""
+    monkeypatch.setenv("SR_GEMM_TILE", tile)
+    g = torch.Generator(device="cuda").manual_seed(int(tile))
+    M, N, K = 700, 800, 256
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    ref = A.float() @ W.float().T
+    torch.testing.assert_close(_gemm(A, W, 4), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(_gemm(A, W, 0).float(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    X = torch.randn((M, N), device="cuda", generator=g)
+    want = X + ref
+    _gemm(A, W, 1, C=X)
+    torch.testing.assert_close(X, want, rtol=1e-4, atol=1e-4)
+    I = N // 2
+    Wg, Wu = W[:I].contiguous(), W[I:].contiguous()
+    Wgu = torch.stack([Wg.reshape(I // 16, 16, K), Wu.reshape(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    out = _gemm(A, Wgu, 2)
+    sw = torch.nn.functional.silu(A.float() @ Wg.float().T) * (A.float() @ Wu.float().T)
+    torch.testing.assert_close(out.float(), sw, rtol=2e-2, atol=2e-2)
+    eye = torch.eye(K, device="cuda").bfloat16()
+    Wa = (torch.arange(512 * K, device="cuda").reshape(512, K) % 251).float().bfloat16()
+    assert torch.equal(_gemm(eye, Wa, 4), Wa.float().T.contiguous())
