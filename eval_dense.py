@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Dense eval driver on MI355X: same tasks, flags and artefacts as /root/reference/eval_dense.py
+(DenseRetrievalArguments :35-74; tasks write_doc_embeds :158-189, retrieval :190-241,
+evaluate_msmarco :138-145,242-243), running the HIP encoder + HIP flat index.
+
+  torchrun --nproc_per_node=8 eval_dense.py --task_name write_doc_embeds --model_name_or_path <lora dir> \
+           --corpus_path <tsv> --doc_embed_dir <dir> --eval_batch_size 128 --doc_max_length 192
+  python   eval_dense.py --task_name retrieval --model_name_or_path <lora dir> --query_path <tsv> \
+           --doc_embed_dir <dir> --out_dir <dir> --top_k 1000
+  torchrun --nproc_per_node=8 eval_dense.py --task_name retrieval ...      (doc-sharded: the reference asserts
+           world_size == 1, eval_dense.py:191; here each rank scores the shard files it loads, one RCCL gather)
+  python   eval_dense.py --task_name evaluate_msmarco --eval_qrel_path q.json --eval_run_path run.json \
+           --eval_metric '["mrr_10","recall"]' --out_dir <dir>
+"""
+import argparse
+import ast
+import json
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+CORPUS_DATASOURCE = {"./data/msmarco-full/full_collection/raw.tsv": "msmarco"}   # constants.py:10-13
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    for name in ["model_name_or_path", "ckpt_path", "model_type", "corpus_path", "doc_embed_dir", "index_dir", "out_dir",
+                 "query_path", "eval_run_path", "eval_qrel_path", "eval_metric", "beir_dataset", "beir_dataset_dir",
+                 "access_token"]:
+        ap.add_argument("--" + name, type=str, default=None)
+    ap.add_argument("--task_name", type=str, default="")
+    ap.add_argument("--data_source", type=str, default=None, help="msmarco | wiki (default: looked up from corpus_path, else msmarco)")
+    ap.add_argument("--is_beir", action="store_true")
+    ap.add_argument("--eval_batch_size", type=int, default=128)
+    ap.add_argument("--doc_max_length", type=int, default=192)
+    ap.add_argument("--query_max_length", type=int, default=64)
+    ap.add_argument("--hidden_dim", type=int, default=768)
+    ap.add_argument("--top_k", type=int, default=1000)
+    ap.add_argument("--local_rank", type=int, default=-1)
+    ap.add_argument("--world_size", type=int, default=1)
+    ap.add_argument("--chunk_size", type=int, default=2_000_000)
+    args = ap.parse_args(argv)
+    if args.eval_metric:
+        args.eval_metric = ast.literal_eval(args.eval_metric)     # the reference uses eval() (eval_dense.py:70)
+    return args
+
+
+def ddp_setup(args):
+    """eval_dense.py:29-32.  Works without torchrun too (single process, no process group)."""
+    if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        args.local_rank = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(args.local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", args.local_rank))
+        args.world_size = dist.get_world_size()
+    else:
+        args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(args.local_rank)
+        args.world_size = 1
+
+
+def _tokenizer(path, access_token=None):
+    from transformers import AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(path, token=access_token) if access_token else AutoTokenizer.from_pretrained(path)
+    tok.padding_side = "left"                                     # eval_dense.py:185,206
+    if tok.pad_token is None:
+        tok.pad_token = tok.eos_token
+    assert tok.pad_token == tok.eos_token                         # eval_dense.py:186,208
+    return tok
+
+
+def write_doc_embeds(args):
+    from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
+    from scaling_retriever_amd.dataset.dataset import CollectionDataset
+    from scaling_retriever_amd.indexer import store_embs
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    from scaling_retriever_amd.utils.utils import is_first_worker
+    if is_first_worker():
+        os.makedirs(args.doc_embed_dir, exist_ok=True)
+    tokenizer = _tokenizer(args.model_name_or_path, args.access_token)
+    source = args.data_source or CORPUS_DATASOURCE.get(args.corpus_path, "msmarco")
+    dataset = CollectionDataset(corpus_path=args.corpus_path, data_source=source)
+    sampler = DistributedSampler(dataset, shuffle=False) if args.world_size > 1 else None
+    loader = DataLoader(dataset, batch_size=args.eval_batch_size, shuffle=False, num_workers=1, sampler=sampler,
+                        collate_fn=LlamaDenseCollectionCollator(tokenizer=tokenizer, max_length=args.doc_max_length))
+    model = LlamaBiDense.load_from_lora(args.model_name_or_path, access_token=args.access_token)
+    model.to(args.local_rank)
+    model.eval()
+    store_embs(model=model, collection_loader=loader, local_rank=args.local_rank, index_dir=args.doc_embed_dir,
+               device=args.local_rank, chunk_size=args.chunk_size)
+    if args.world_size > 1:
+        dist.barrier()
+
+
+def generate_query_vecs(model, dataloader, device):
+    """DenseRetriever.generate_query_vecs (eval_dense.py:94-106)."""
+    reps, qids = [], []
+    for batch in dataloader:
+        inputs = {k: v.to(device) for k, v in batch.items() if k != "ids"}
+        with torch.no_grad():
+            reps.append(model.query_encode(**inputs))
+        qids.extend(batch["ids"])
+    return torch.cat(reps), qids
+
+
+def retrieval(args):
+    from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
+    from scaling_retriever_amd.dataset.dataset import MSMARCOQueryDataset
+    from scaling_retriever_amd.distributed import gather_topk
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    from scaling_retriever_amd.scoring import DenseIndexHIP, topk_merge
+    from scaling_retriever_amd.utils.utils import obtain_doc_vec_dir_files
+    rank, world = (dist.get_rank(), dist.get_world_size()) if args.world_size > 1 else (0, 1)
+    device = torch.device("cuda", args.local_rank)
+    if rank == 0:
+        os.makedirs(args.out_dir, exist_ok=True)
+    model = LlamaBiDense.load_from_lora(args.model_name_or_path, access_token=args.access_token)
+    model.to(device)
+    model.eval()
+    tokenizer = _tokenizer(args.model_name_or_path, args.access_token)
+    q_loader = DataLoader(MSMARCOQueryDataset(args.query_path), batch_size=args.eval_batch_size, shuffle=False, num_workers=0,
+                          collate_fn=LlamaDenseCollectionCollator(tokenizer=tokenizer, max_length=args.query_max_length))
+    vec_files, id_files = obtain_doc_vec_dir_files(args.doc_embed_dir)
+    # files in plan order (rank-major) get consecutive positions, exactly the order the reference concatenates them in
+    # (eval_dense.py:113-121); every retrieval rank takes a round-robin subset of the FILES as HBM segments.
+    sizes = [int(np.load(f, mmap_mode="r").shape[0]) for f in id_files]
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    index = DenseIndexHIP(model.hidden_size, device=device)
+    for fi in range(rank, len(vec_files), world):
+        index.add_host_rows(np.load(vec_files[fi]), id_base=int(offsets[fi]))
+    q_reps, qids = generate_query_vecs(model, q_loader, device)
+    scores, idx = index.search(q_reps, args.top_k)
+    if world > 1:
+        gs, gi = gather_topk(scores, idx, dst=0)
+        if gs is not None:
+            scores, idx = topk_merge(gs, gi)
+    if rank == 0:
+        doc_ids = np.concatenate([np.load(f) for f in id_files])
+        scores, idx = scores.cpu().numpy(), idx.cpu().numpy()
+        run = {}
+        for qid, row_i, row_s in zip(qids, idx, scores):
+            keep = row_i >= 0
+            run[str(qid)] = {str(doc_ids[j]): float(s) for j, s in zip(row_i[keep], row_s[keep])}
+        with open(os.path.join(args.out_dir, "run.json"), "w") as fout:
+            json.dump(run, fout)
+    if world > 1:
+        dist.barrier()
+
+
+def evaluate_msmarco(args):
+    from scaling_retriever_amd.utils.metrics import load_and_evaluate
+    res = {metric: load_and_evaluate(args.eval_qrel_path, args.eval_run_path, metric) for metric in args.eval_metric}
+    os.makedirs(args.out_dir, exist_ok=True)
+    with open(os.path.join(args.out_dir, "perf.json"), "w") as fout:
+        json.dump(res, fout, indent=4)
+    return res
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.task_name not in ["evaluate_msmarco", "evaluate_beir"]:
+        ddp_setup(args)
+        print("world_size = {}, local_rank = {}".format(args.world_size, args.local_rank))
+    if args.task_name == "write_doc_embeds":
+        write_doc_embeds(args)
+    elif args.task_name == "retrieval":
+        retrieval(args)
+    elif args.task_name == "evaluate_msmarco":
+        evaluate_msmarco(args)
+    else:
+        raise NotImplementedError(args.task_name)
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

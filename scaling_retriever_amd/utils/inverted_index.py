@@ -216,3 +216,13 @@ def merge_indexes(model_name_or_path, filename="array_index.h5py", index_name="i
         json.dump(index_dist, f)
     with open(os.path.join(out_dir, "index_stats.json"), "w") as f:
         json.dump(index_stats, f)
+
+
+if __name__ == "__main__":  # scripts/eval_sparse.sh:19 `python -m utils.inverted_index --model_name_or_path ...`
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--model_name_or_path", type=str, required=True)
+    parser.add_argument("--index_name", default="index", type=str)
+    parser.add_argument("--index_dir", default=None, type=str)
+    a = parser.parse_args()
+    merge_indexes(a.model_name_or_path, index_name=a.index_name, index_dir=a.index_dir)

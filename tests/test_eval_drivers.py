@@ -1,0 +1,168 @@
+"""Eval drivers (eval_dense.py / eval_sparse.py at the repo root) end to end on a tiny checkpoint, plus the
+dataset/collator contract on CPU.  Callers mirrored: /root/reference/eval_dense.py:148-251,
+/root/reference/eval_sparse.py:75-195, scripts/eval_dense.sh, scripts/eval_sparse.sh."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from golden_weights import make_weights
+from oracle import llama_bi as LB
+from oracle import scoring as SC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORDS = [f"w{i}" for i in range(200)]
+
+
+def _make_tokenizer(path):
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<s>": 0, "</s>": 1, "<unk>": 2, **{w: i + 3 for i, w in enumerate(WORDS)}}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 0)])   # BOS only
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="</s>")
+    fast.save_pretrained(path)
+    return fast
+
+
+def _texts(rng, n, lo, hi):
+    return [" ".join(rng.choice(WORDS, size=int(rng.integers(lo, hi + 1)))) for _ in range(n)]
+
+
+def test_dataset_and_collator_contract(tmp_path):
+    """(pid, text) records, string ids, BOS prepended / nothing appended, truncation, pad-to-longest, left padding."""
+    from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
+    from scaling_retriever_amd.dataset.dataset import CollectionDataset, MSMARCOQueryDataset
+    rng = np.random.default_rng(0)
+    docs = _texts(rng, 5, 2, 9)
+    with open(tmp_path / "corpus.tsv", "w") as f:
+        for i, t in enumerate(docs):
+            f.write(f"{100 + i}\t{t}\n")
+    ds = CollectionDataset(str(tmp_path / "corpus.tsv"), data_source="msmarco")
+    assert len(ds) == 5 and ds[2] == ("102", docs[2])
+    assert MSMARCOQueryDataset(str(tmp_path / "corpus.tsv"))[0] == ("100", docs[0])
+    with pytest.raises(NotImplementedError):
+        CollectionDataset(str(tmp_path / "corpus.tsv"), data_source="nope")
+    tok = _make_tokenizer(str(tmp_path / "tok"))
+    tok.padding_side = "left"
+    batch = LlamaDenseCollectionCollator(tok, max_length=6)([ds[i] for i in range(5)])
+    assert batch["ids"] == ["100", "101", "102", "103", "104"]
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    assert ids.dtype == torch.int64 and ids.shape == mask.shape and ids.shape[1] <= 6
+    for r, t in enumerate(docs):
+        n = min(len(t.split()) + 1, 6)
+        assert int(mask[r].sum()) == n and bool(mask[r, -n:].all())                 # left padded
+        assert int(ids[r, -n]) == 0 and (ids[r, :ids.shape[1] - n] == 1).all()      # BOS first, pad = eos
+
+
+def _write_model(tmp, cfg, w, rng):
+    """Bare LlamaBiModel base checkpoint + dense adapter, and MNTP base + sparse adapter, each with a tokenizer."""
+    from safetensors.numpy import save_file
+    out = {}
+    for kind, bare, prefix, base_cls in [("dense", True, "base_model.model.", "LlamaBiModel"),
+                                         ("sparse", False, "base_model.model.model.", "LlamaBiForMNTP")]:
+        base, lora = os.path.join(tmp, f"base_{kind}"), os.path.join(tmp, f"lora_{kind}")
+        os.makedirs(base), os.makedirs(lora)
+        sd = {(k[len("model."):] if bare else k): v for k, v in w.items() if not (bare and k.startswith("lm_head"))}
+        save_file(sd, os.path.join(base, "model.safetensors"))
+        json.dump(dict(cfg, model_type="llama"), open(os.path.join(base, "config.json"), "w"))
+        json.dump(dict(cfg, model_type="llama"), open(os.path.join(lora, "config.json"), "w"))
+        H, I, nh, nkv = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        hd = H // nh
+        shapes = {"self_attn.q_proj": (nh * hd, H), "self_attn.k_proj": (nkv * hd, H), "self_attn.v_proj": (nkv * hd, H),
+                  "self_attn.o_proj": (H, nh * hd), "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}
+        ad, merged = {}, dict(w)
+        for i in range(cfg["num_hidden_layers"]):
+            for mod, (o, inn) in shapes.items():
+                A = (rng.standard_normal((4, inn)) / inn ** 0.5).astype(np.float32)
+                B = (rng.standard_normal((o, 4)) * 0.2).astype(np.float32)
+                ad[f"{prefix}layers.{i}.{mod}.lora_A.weight"], ad[f"{prefix}layers.{i}.{mod}.lora_B.weight"] = A, B
+                name = f"model.layers.{i}.{mod}.weight"
+                merged[name] = LB.lora_merge(w[name], A, B, lora_alpha=8, r=4)
+        save_file(ad, os.path.join(lora, "adapter_model.safetensors"))
+        json.dump({"base_model_name_or_path": base, "r": 4, "lora_alpha": 8, "peft_type": "LORA",
+                   "auto_mapping": {"base_model_class": base_cls}}, open(os.path.join(lora, "adapter_config.json"), "w"))
+        _make_tokenizer(lora)
+        out[kind] = (lora, merged)
+    return out
+
+
+def _encode_oracle(fn, w, cfg, tok, texts, max_len):
+    reps = []
+    for t in texts:
+        ids = tok(t, max_length=max_len, truncation=True)["input_ids"]
+        reps.append(fn(w, cfg, np.asarray(ids)[None], np.ones((1, len(ids)), np.int64))[0])
+    return np.stack(reps)
+
+
+@pytest.mark.gpu
+def test_eval_dense_and_sparse_drivers_end_to_end(golden_dir, tmp_path):
+    sys.path.insert(0, ROOT)
+    import eval_dense
+    import eval_sparse
+    z = np.load(os.path.join(golden_dir, "enc_tiny_a.npz"))
+    cfg = json.loads(str(z["config_json"]))
+    w = make_weights(cfg, int(z["weight_seed"]))
+    rng = np.random.default_rng(3)
+    models = _write_model(str(tmp_path), cfg, w, rng)
+    docs, queries = _texts(rng, 60, 3, 20), _texts(rng, 6, 2, 6)
+    with open(tmp_path / "corpus.tsv", "w") as f:
+        for i, t in enumerate(docs):
+            f.write(f"d{i}\t{t}\n")
+    with open(tmp_path / "queries.tsv", "w") as f:
+        for i, t in enumerate(queries):
+            f.write(f"q{i}\t{t}\n")
+    from transformers import AutoTokenizer
+
+    # ---------------- dense: write_doc_embeds -> retrieval -> evaluate_msmarco
+    lora, merged = models["dense"]
+    emb_dir, out_dir = str(tmp_path / "embs"), str(tmp_path / "out_dense")
+    eval_dense.main(["--task_name", "write_doc_embeds", "--model_name_or_path", lora, "--corpus_path", str(tmp_path / "corpus.tsv"),
+                     "--doc_embed_dir", emb_dir, "--eval_batch_size", "16", "--doc_max_length", "16", "--chunk_size", "32"])
+    assert json.load(open(os.path.join(emb_dir, "plan.json")))["num_chunks"] == 2
+    eval_dense.main(["--task_name", "retrieval", "--model_name_or_path", lora, "--query_path", str(tmp_path / "queries.tsv"),
+                     "--doc_embed_dir", emb_dir, "--out_dir", out_dir, "--top_k", "10", "--query_max_length", "8"])
+    run = json.load(open(os.path.join(out_dir, "run.json")))
+    tok = AutoTokenizer.from_pretrained(lora)
+    d_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, docs, 16)
+    q_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, queries, 8)
+    ref_scores = q_ref @ d_ref.T
+    for qi in range(len(queries)):
+        got = run[f"q{qi}"]
+        assert len(got) == 10
+        top_ref = set(np.argsort(-ref_scores[qi])[:10])
+        top_got = {int(k[1:]) for k in got}
+        # bf16 encoder vs fp32 oracle: the sets agree except for near-ties at the cut
+        assert len(top_ref & top_got) >= 8
+        for k, v in got.items():
+            assert abs(v - ref_scores[qi, int(k[1:])]) < 2e-2
+    qrel = {f"q{qi}": {f"d{int(np.argmax(ref_scores[qi]))}": 1} for qi in range(len(queries))}
+    json.dump(qrel, open(tmp_path / "qrel.json", "w"))
+    res = eval_dense.main(["--task_name", "evaluate_msmarco", "--eval_qrel_path", str(tmp_path / "qrel.json"), "--eval_run_path",
+                           os.path.join(out_dir, "run.json"), "--eval_metric", '["mrr_10","recall"]', "--out_dir", out_dir])
+    perf = json.load(open(os.path.join(out_dir, "perf.json")))
+    assert perf["mrr_10"]["mrr_10"] > 0.8 and "recall_10" in perf["recall"]
+
+    # ---------------- sparse: indexing -> retrieval
+    lora_s, merged_s = models["sparse"]
+    index_dir, out_s = str(tmp_path / "sp_index"), str(tmp_path / "out_sparse")
+    eval_sparse.main(["--task_name", "indexing", "--model_name_or_path", lora_s, "--corpus_path", str(tmp_path / "corpus.tsv"),
+                      "--index_dir", index_dir, "--eval_batch_size", "8", "--doc_max_length", "16"])
+    assert os.path.exists(os.path.join(index_dir, "doc_ids.pkl")) and os.path.exists(os.path.join(index_dir, "index_stats.json"))
+    eval_sparse.main(["--task_name", "retrieval", "--model_name_or_path", lora_s, "--query_path", str(tmp_path / "queries.tsv"),
+                      "--index_dir", index_dir, "--out_dir", out_s, "--top_k", "10", "--query_max_length", "8"])
+    run_s = json.load(open(os.path.join(out_s, "run.json")))
+    d_sp = _encode_oracle(LB.sparse_encode, merged_s, cfg, tok, docs, 16)
+    q_sp = _encode_oracle(LB.sparse_encode, merged_s, cfg, tok, queries, 8)
+    ref_s = q_sp @ d_sp.T
+    for qi in range(len(queries)):
+        got = run_s[f"q{qi}"]
+        assert len(got) == 10
+        top_ref = set(np.argsort(-ref_s[qi])[:10])
+        assert len(top_ref & {int(k[1:]) for k in got}) >= 8
+        for k, v in got.items():
+            assert abs(v - ref_s[qi, int(k[1:])]) < 3e-2 * max(1.0, abs(ref_s[qi, int(k[1:])]))
