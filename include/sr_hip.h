@@ -58,6 +58,15 @@ int64_t sr_dense_index_ntotal(const sr_dense_index* idx);
  * d_out_ids int64 [nq, k] (global doc indices).                              */
 int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k,
                     float* d_out_scores, int64_t* d_out_ids, sr_stream stream);
+/* Arithmetic of the score kernel for query batches > 64:
+ *   SR_PRECISION_FP32   (default) exact fp32 MFMA, bit-for-bit a k-ordered fmaf chain;
+ *   SR_PRECISION_BF16X3 fp32 operands split into bf16 hi + lo, q.d ~= qh.dh + qh.dl + ql.dh on the
+ *                       bf16 MFMA pipe with fp32 accumulation: ~1e-7 relative to the fp32 result
+ *                       (the size of an fp32 summation-order change), ~3x faster.  Keeps a
+ *                       library-owned bf16 copy of every segment (same bytes as the fp32 rows). */
+#define SR_PRECISION_FP32 0
+#define SR_PRECISION_BF16X3 1
+int sr_dense_index_set_precision(sr_dense_index* idx, int mode);
 /* Workspace ceiling in bytes for candidate buffers (default 4 GiB). */
 int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes);
 int sr_dense_index_destroy(sr_dense_index* idx);

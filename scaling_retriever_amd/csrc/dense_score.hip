@@ -14,6 +14,7 @@
 // (topk.hip).  A doc chunk = one launch; tau is raised between chunks.
 #include "common.h"
 #include "dense_stream.h"
+#include "dense_split.h"
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
@@ -166,6 +167,8 @@ struct DenseSegment {
     const float* rows;
     int64_t n;
     int64_t id_base, id_stride;
+    unsigned short* hi = nullptr;   // library-owned bf16 planes (precision = bf16x3 only)
+    unsigned short* lo = nullptr;
 };
 
 struct sr_dense_index {
@@ -173,10 +176,28 @@ struct sr_dense_index {
     std::vector<DenseSegment> segs;
     int64_t ntotal = 0;
     int64_t ws_limit = 4ll << 30;
+    int precision = SR_PRECISION_FP32;
+    unsigned short* qhi = nullptr;   // query planes for the bf16x3 path
+    unsigned short* qlo = nullptr;
+    int64_t q_cap = 0;
     TopkWS ws;
     LaunchProfile prof;
     std::mutex mu;
 };
+
+static int split_segment(sr_dense_index* idx, DenseSegment& seg) {
+    if (seg.hi) return SR_OK;
+    const size_t bytes = (size_t)seg.n * (size_t)idx->dim * 2;
+    if (hipMalloc((void**)&seg.hi, bytes) != hipSuccess || hipMalloc((void**)&seg.lo, bytes) != hipSuccess) {
+        if (seg.hi) (void)hipFree(seg.hi);
+        seg.hi = seg.lo = nullptr;
+        sr_set_error("bf16x3 precision needs %zu more bytes of device memory for this segment", 2 * bytes);
+        return SR_ERR_NOMEM;
+    }
+    SR_TRY(launch_split_bf16(seg.rows, seg.hi, seg.lo, seg.n * (int64_t)idx->dim, nullptr));
+    SR_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return SR_OK;
+}
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
 static int launch_dense(const DenseArgs& a, int64_t rows, hipStream_t s) {
@@ -211,7 +232,10 @@ extern "C" int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int6
     SR_REQUIRE(((uintptr_t)d_rows & 15) == 0, "sr_dense_index_add: rows must be 16-byte aligned");
     SR_REQUIRE(id_base + (n_rows - 1) * id_stride < 0xffffffffll, "sr_dense_index_add: global doc index exceeds 32 bits");
     std::lock_guard<std::mutex> lock(idx->mu);
-    idx->segs.push_back({d_rows, n_rows, id_base, id_stride});
+    DenseSegment seg;
+    seg.rows = d_rows; seg.n = n_rows; seg.id_base = id_base; seg.id_stride = id_stride;
+    if (idx->precision == SR_PRECISION_BF16X3) SR_TRY(split_segment(idx, seg));
+    idx->segs.push_back(seg);
     idx->ntotal += n_rows;
     return SR_OK;
 }
@@ -227,7 +251,25 @@ extern "C" int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t b
 extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
+    for (DenseSegment& seg : idx->segs) {
+        if (seg.hi) (void)hipFree(seg.hi);
+        if (seg.lo) (void)hipFree(seg.lo);
+    }
+    if (idx->qhi) (void)hipFree(idx->qhi);
+    if (idx->qlo) (void)hipFree(idx->qlo);
     delete idx;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
+    SR_REQUIRE(idx, "sr_dense_index_set_precision: null index");
+    SR_REQUIRE(mode == SR_PRECISION_FP32 || mode == SR_PRECISION_BF16X3, "sr_dense_index_set_precision: unknown mode %d", mode);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (mode == SR_PRECISION_BF16X3) {
+        SR_REQUIRE(idx->dim % 64 == 0, "bf16x3 precision needs dim %% 64 == 0 (dim = %d)", idx->dim);
+        for (DenseSegment& seg : idx->segs) SR_TRY(split_segment(idx, seg));
+    }
+    idx->precision = mode;
     return SR_OK;
 }
 
@@ -263,6 +305,37 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
+    if (idx->precision == SR_PRECISION_BF16X3 && nq > 64) {
+        // fp32-equivalent scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
+        if (idx->q_cap < nq) {
+            if (idx->qhi) (void)hipFree(idx->qhi);
+            if (idx->qlo) (void)hipFree(idx->qlo);
+            idx->qhi = idx->qlo = nullptr;
+            idx->q_cap = 0;
+            SR_CHECK_HIP(hipMalloc((void**)&idx->qhi, (size_t)nq * idx->dim * 2));
+            SR_CHECK_HIP(hipMalloc((void**)&idx->qlo, (size_t)nq * idx->dim * 2));
+            idx->q_cap = nq;
+        }
+        SR_TRY(launch_split_bf16(d_queries, idx->qhi, idx->qlo, nq * (int64_t)idx->dim, s));
+        SR_TRY(idx->ws.ensure(nq, k, chunk));
+        SR_TRY(topk_reset(idx->ws, nq, s));
+        for (const DenseSegment& seg : idx->segs) {
+            for (int64_t r0 = 0; r0 < seg.n; r0 += chunk) {
+                const int64_t r1 = r0 + chunk < seg.n ? r0 + chunk : seg.n;
+                DenseSplitArgs a;
+                a.Dhi = seg.hi; a.Dlo = seg.lo; a.Qhi = idx->qhi; a.Qlo = idx->qlo;
+                a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
+                a.tau = idx->ws.tau; a.cand_keys = idx->ws.cand_keys; a.cand_count = idx->ws.cand_count;
+                a.cand_cap = idx->ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
+                idx->prof.begin(s);
+                SR_TRY(launch_dense_split(a, s));
+                idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
+                SR_TRY(topk_compact(idx->ws, nq, k, s));
+            }
+        }
+        SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+        return SR_OK;
+    }
     const bool use_stream = variant != 9 && dense_stream_supports((int)nq, idx->dim);
     if (use_stream) {
         // HBM-bound regime: D straight to registers, chunks grow geometrically (64 Ki docs, x2 per launch)

@@ -1,0 +1,169 @@
+// Dense scoring in "bf16x3" arithmetic: fp32-equivalent inner products on the bf16 MFMA pipe.
+//
+// Every fp32 operand is split x = hi + lo (+ O(2^-18 |x|)) into two bf16 numbers; then
+//     q . d  ~=  qh.dh + qh.dl + ql.dh           (the dropped ql.dl term is O(2^-18))
+// Products of bf16 pairs are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the
+// result differs from an fp32 dot product by ~1e-7 relative - the same size as the difference between
+// two fp32 summation orders (e.g. two BLAS libraries under faiss' IndexFlatIP, indexer.py:211) - while
+// running 3 bf16 MFMAs (2.5 PF peak) instead of 16x slower fp32 MFMAs (157 TF peak).
+//
+// Implementation: one GEMM with a 3x longer k loop.  k-tile kt in [0, 3 H/64): plane = kt / (H/64);
+// the doc operand streams (Dhi, Dlo, Dhi)[plane], the query operand (Qhi, Qhi, Qlo)[plane].  Tile
+// 256 docs x 256 queries, 8 waves, LDS-DMA staging with source-side swizzle (as csrc/gemm_bf16.hip).
+// Docs sit on the accumulator registers and queries on the lanes, so the tau filter is lane-local and
+// survivors are appended as 64-bit keys exactly as in dense_score.hip.
+#include "dense_split.h"
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
+
+// ---- fp32 -> (hi, lo) bf16 planes ---------------------------------------------------------------
+__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                  int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    bf16x4 h, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned short hb = f32_to_bf16(v[c]);
+        h[c] = (short)hb;
+        l[c] = (short)f32_to_bf16(v[c] - bf16_to_f32(hb));
+    }
+    reinterpret_cast<bf16x4*>(hi)[i] = h;
+    reinterpret_cast<bf16x4*>(lo)[i] = l;
+}
+
+int launch_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, int64_t n_elems, hipStream_t s) {
+    const int64_t n4 = n_elems / 4;
+    if (n4 == 0) return SR_OK;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, src, hi, lo, n4);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+// ---- scoring kernel ------------------------------------------------------------------------------
+#define SP_BN 256   // docs per workgroup
+#define SP_BM 256   // queries per workgroup
+__global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
+    constexpr int NB = 8, MB = 4, WAVES_M = 4;          // wave tile: 128 docs x 64 queries
+    constexpr int W_BYTES = SP_BN * 128, STAGE_BYTES = (SP_BN + SP_BM) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * SP_BN;
+    const int q0 = blockIdx.y * SP_BM;
+    const int H = a.H;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ (srow & 7);
+    int64_t doff[4], qoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t rn = row0 + (wave * 4 + i) * 8 + srow;
+        rn = rn < a.row_end ? rn : a.row_end - 1;
+        doff[i] = rn * H + schunk * 8;
+        int rq = q0 + (wave * 4 + i) * 8 + srow;
+        rq = rq < a.nq ? rq : a.nq - 1;
+        qoff[i] = (int64_t)rq * H + schunk * 8;
+    }
+    const int nk = H / 64;
+    auto stage = [&](int st, int kt) {
+        const int plane = kt / nk, k0 = (kt - plane * nk) * 64;
+        const unsigned short* dsrc = (plane == 1) ? a.Dlo : a.Dhi;
+        const unsigned short* qsrc = (plane == 2) ? a.Qlo : a.Qhi;
+        unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 4) * 1024;
+        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(dsrc + doff[i] + k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(qsrc + qoff[i] + k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4;
+    const int nkt = 3 * nk;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+        const unsigned char* wt = smem + cur * STAGE_BYTES;
+        const unsigned char* at = wt + W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+            mfma_bf16x8 wf[NB], af[MB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + i * 16 + frow) * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < MB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = query (frow + 16 j), registers = docs (16 i + 4 fg + r) --------------------
+    const int64_t left = a.row_end - row0;
+    const int rows_valid = left < SP_BN ? (int)left : SP_BN;
+    const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int q = q0 + wm * MB * 16 + j * 16 + frow;
+        if (q >= a.nq) continue;
+        const float tq = a.tau[q];
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
+                cnt += (lr < rows_valid && acc[i][j][r] >= tq) ? 1 : 0;
+            }
+        if (cnt == 0) continue;
+        int pos = atomicAdd(&a.cand_count[q], cnt);
+        uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
+                const float sc = acc[i][j][r];
+                if (lr < rows_valid && sc >= tq) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
+                    ++pos;
+                }
+            }
+    }
+}
+
+int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
+    const int64_t rows = a.row_end - a.row_begin;
+    if (rows <= 0) return SR_OK;
+    SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
+    constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)ceil_div64(rows, SP_BN), (unsigned)ceil_div64(a.nq, SP_BM));
+    hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}

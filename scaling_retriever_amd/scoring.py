@@ -59,6 +59,11 @@ class DenseIndexHIP:
     def set_workspace_limit(self, nbytes):
         _lib.check(self.lib.sr_dense_index_set_workspace_limit(self._h, int(nbytes)))
 
+    def set_precision(self, mode):
+        """"fp32" (default, exact) or "bf16x3" (fp32-equivalent on the bf16 MFMA pipe, query batches > 64)."""
+        code = {"fp32": 0, "bf16x3": 1}[mode]
+        _lib.check(self.lib.sr_dense_index_set_precision(self._h, code), "sr_dense_index_set_precision")
+
     def search(self, queries, k):
         """queries: fp32 cuda tensor [nq, dim] -> (scores fp32 [nq,k], ids int64 [nq,k]) cuda tensors."""
         if queries.dtype != torch.float32 or queries.dim() != 2 or queries.shape[1] != self.dim:
