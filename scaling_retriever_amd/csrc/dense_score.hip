@@ -38,7 +38,7 @@ struct DenseArgs {
 // its SIMD partner keeps the (64-cycle) fp32 MFMA pipe busy.
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) void dense_score_kernel(DenseArgs a) {
-    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per workgroup");
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 16, "4, 8 or 16 waves per workgroup");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N, LDK = BK + 4, KC = BK / 4;
     constexpr int A_CHUNKS = TM * (BK / 4), B_CHUNKS = TN * (BK / 4);
@@ -388,7 +388,8 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
                 case 0:
                     if (variant == 0) SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s)));
                     else if (variant == 1) SR_TRY((launch_dense<2, 4, 4, 2>(a, r1 - r0, s)));
-                    else SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
+                    else if (variant == 2) SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
+                    else SR_TRY((launch_dense<4, 4, 2, 2>(a, r1 - r0, s)));
                     break;
                 case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
                 case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
