@@ -53,6 +53,8 @@ def random_weights(cfg, device, seed):
     def lin(o, i):
         return (torch.randn((o, i), device=device, generator=g, dtype=torch.float32) * 0.02).bfloat16()
     w = {"model.embed_tokens.weight": lin(V, H), "model.norm.weight": torch.ones(H, device=device)}
+    if not cfg.get("tie_word_embeddings", False):
+        w["lm_head.weight"] = lin(V, H)
     for li in range(cfg["num_hidden_layers"]):
         p = f"model.layers.{li}."
         w[p + "self_attn.q_proj.weight"] = lin(nq, H)
@@ -93,7 +95,7 @@ def main():
     ap.add_argument("--n-docs", type=int, default=8_841_823)
     ap.add_argument("--n-queries", type=int, default=6980)
     ap.add_argument("--topk", type=int, default=1000)
-    ap.add_argument("--query-batch", type=int, default=512, help="queries per query_encode call (eval_batch_size; the reference script uses 128)")
+    ap.add_argument("--query-batch", type=int, default=2048, help="queries per query_encode call (eval_batch_size; the reference script uses 128)")
     ap.add_argument("--encode-batches", type=int, default=16, help="passage batches (x128) for the encode figure")
     ap.add_argument("--layers", type=int, default=None, help="override num layers (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,7 +123,7 @@ def main():
         cfg["num_hidden_layers"] = args.layers
     H = cfg["hidden_size"]
     t_setup = time.time()
-    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=2048).to(device).eval()
+    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=4096).to(device).eval()
     q_batches, q_lens = synth_batches(args.n_queries, args.query_batch, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device)
     n_local = shard_size(args.n_docs, rank, world)
     D = torch.empty((n_local, H), dtype=torch.float32, device=device)
@@ -183,6 +185,19 @@ def main():
                 "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                 "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4),
                 "flop_per_launch": fl.value / max(1, n_l.value), "kernel_share_of_step": round(ms.value * 1e-3 / dt, 3)}
+
+    # ---- where a step's time goes (one extra pass of each stage, synchronised; not part of the timed region) ----
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    reps_b = torch.cat([model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches])
+    torch.cuda.synchronize()
+    t_enc = time.perf_counter() - tb
+    tb = time.perf_counter()
+    index.search(reps_b, args.topk)
+    torch.cuda.synchronize()
+    t_search = time.perf_counter() - tb
+    breakdown = {"query_encode_ms": round(t_enc * 1e3, 1), "search_ms": round(t_search * 1e3, 1),
+                 "query_tokens": int(q_lens.sum()), "query_encode_calls": len(q_batches)}
 
     # ---- the same step with the score kernel in bf16x3 arithmetic (opt-in precision mode; fp32 operands split into
     #      bf16 hi + lo, three bf16 MFMA products, fp32 accumulate: within 2.5e-6 |q||d| of the fp32 scores) ----
@@ -264,7 +279,7 @@ def main():
                        "n_docs": args.n_docs, "n_queries": args.n_queries, "hidden": H, "topk": args.topk,
                        "query_batch": args.query_batch, "layers": cfg["num_hidden_layers"],
                        "parallelism": f"doc-shard x{world}" + (" + 1 RCCL gather of per-shard top-k" if world > 1 else "")},
-            "roofline": roofline, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
+            "roofline": roofline, "breakdown": breakdown, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

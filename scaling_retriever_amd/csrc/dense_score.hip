@@ -36,8 +36,8 @@ struct DenseArgs {
 // Tile = (32*WM*WAVES_M docs) x (32*WN*WAVES_N queries), 4 or 8 waves, BK = 16.
 // 8 waves = 2 per SIMD: while one wave sits at the k-step barrier or waits for its LDS fragments,
 // its SIMD partner keeps the (64-cycle) fp32 MFMA pipe busy.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) void dense_score_kernel(DenseArgs a) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16, int OCC = (WAVES_M * WAVES_N) / 4>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void dense_score_kernel(DenseArgs a) {
     static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 16, "4, 8 or 16 waves per workgroup");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N, LDK = BK + 4, KC = BK / 4;
@@ -199,18 +199,18 @@ static int split_segment(sr_dense_index* idx, DenseSegment& seg) {
     return SR_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16, int OCC = (WAVES_M * WAVES_N) / 4>
 static int launch_dense(const DenseArgs& a, int64_t rows, hipStream_t s) {
     constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
     constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK, OCC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div64(rows, TM), (unsigned)ceil_div64(a.nq, TN));
-    hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
+    hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK, OCC>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -287,7 +287,9 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
     int TN;
-    if (nq > 128) { cfg = 0; TN = 256; }
+    static const char* env_variant = getenv("SR_DENSE_VARIANT");   // development A/B switch
+    const int variant = env_variant ? atoi(env_variant) : 1;
+    if (nq > 128) { cfg = 0; TN = (variant == 4) ? 128 : 256; }
     else if (nq > 64) { cfg = 1; TN = 128; }
     else if (nq > 32) { cfg = 2; TN = 64; }
     else { cfg = 3; TN = 32; }
@@ -299,8 +301,6 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     while (t) { const int64_t r = g % t; g = t; t = r; }     // g = gcd(256, qtiles)
     const int64_t unit = 256 / g;
     int64_t chunk = TM * unit * ceil_div64(2048, unit * qtiles);
-    static const char* env_variant = getenv("SR_DENSE_VARIANT");   // development A/B switch
-    const int variant = env_variant ? atoi(env_variant) : 1;
     int64_t max_cap = idx->ws_limit / (8 * nq);
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
@@ -389,7 +389,8 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
                     if (variant == 0) SR_TRY((launch_dense<2, 2, 4, 4>(a, r1 - r0, s)));
                     else if (variant == 1) SR_TRY((launch_dense<2, 4, 4, 2>(a, r1 - r0, s)));
                     else if (variant == 2) SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
-                    else SR_TRY((launch_dense<4, 4, 2, 2>(a, r1 - r0, s)));
+                    else if (variant == 3) SR_TRY((launch_dense<4, 4, 2, 2>(a, r1 - r0, s)));
+                    else SR_TRY((launch_dense<4, 2, 2, 2, 16, 4>(a, r1 - r0, s)));   // 256 x 128 tile, 2 workgroups per CU
                     break;
                 case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
                 case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
