@@ -241,6 +241,9 @@ class SparseIndexer:
         doc_ids = {}
         stats = defaultdict(float)
         count = 0
+        # COO triples stay on the device; ONE stable sort by term at the end builds the CSR (the reference appends
+        # posting by posting in Python, inverted_index.py:74-76).  12 B per posting: 13.5 GB for MS MARCO at L0_d = 128.
+        dev_rows, dev_cols, dev_vals = [], [], []
         for t, batch in enumerate(tqdm(collection_loader, disable=not is_first_worker())):
             inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
             batch_documents = self.model.encode(**inputs)      # [bz, vocab_size] fp32 on device
@@ -249,7 +252,9 @@ class SparseIndexer:
             row_ptr, col, data = sparse_reps_to_csr(batch_documents)
             nnz_per_row = (row_ptr[1:] - row_ptr[:-1])
             row = torch.repeat_interleave(torch.arange(len(nnz_per_row), device=row_ptr.device), nnz_per_row) + count
-            g_row = row.cpu().numpy() * self.world_size + self.local_rank
+            dev_rows.append((row * self.world_size + self.local_rank).to(torch.int32))   # g_row = (row + count) * W + rank
+            dev_cols.append(col.clone())
+            dev_vals.append(data.clone())
             batch_ids = to_list(batch["ids"]) if isinstance(batch["ids"], torch.Tensor) else batch["ids"]
             assert isinstance(batch_ids, list)
             if id_dict:
@@ -259,8 +264,16 @@ class SparseIndexer:
             for _i, _idx in enumerate(all_idxes):            # docs without any posting get no entry (:271-283)
                 if has_posting[_i]:
                     doc_ids[int(_idx)] = batch_ids[_i]
-            self.sparse_index.add_batch_document(g_row, col.cpu().numpy(), data.cpu().numpy(), n_docs=len(batch_ids))
             count += len(batch_ids)
+        if dev_rows:
+            rows_t, cols_t, vals_t = torch.cat(dev_rows), torch.cat(dev_cols), torch.cat(dev_vals)
+            del dev_rows, dev_cols, dev_vals
+            order = torch.sort(cols_t.to(torch.int32), stable=True).indices      # insertion order kept inside a term
+            V = max(int(self.sparse_index.dim_voc or 0), int(cols_t.max().item()) + 1 if cols_t.numel() else 0)
+            counts = torch.bincount(cols_t.long(), minlength=V)
+            indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=counts.device), torch.cumsum(counts, 0)])
+            self.sparse_index.set_csr(indptr.cpu().numpy(), rows_t[order].cpu().numpy(), vals_t[order].cpu().numpy(),
+                                      self.sparse_index.nb_docs() + count)
 
         if self.compute_stats:
             stats = {key: value / len(collection_loader) for key, value in stats.items()}

@@ -115,6 +115,14 @@ class IndexDictOfArray:
         counts = np.bincount(cols, minlength=V).astype(np.int64)
         self.indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 
+    def set_csr(self, indptr, doc_ids, vals, n_docs):
+        """Adopt a finished CSR (built on the device by SparseIndexer): postings inside a term in insertion order."""
+        self._pending = []
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float32)
+        self.n = int(n_docs)
+
     def csr(self, dim_voc=None):
         """(indptr int64 [V+1], doc_ids int32, vals fp32) with V >= dim_voc."""
         self._finalize()
