@@ -104,27 +104,38 @@ __global__ void plan_tokens_kernel(const int64_t* __restrict__ ids, const int64_
     }
 }
 
-// ---- RMSNorm (fp32 variance) : one wave per token, optional embedding gather -----
-// x[t] = embed[tok_id[t]] (if embed) ; xn[t] = bf16( x * rsqrt(mean(x^2) + eps) * w )
+// ---- RMSNorm (fp32 variance) : one wave per token, optional embedding gather / pending residual -----
+// x[t] = embed[tok_id[t]]            (if embed)
+// x[t] += delta[t]                   (if delta: the bf16 output of the previous o_proj / down_proj GEMM - under the
+//                                     reference's autocast nn.Linear returns bf16, which is then added to the fp32
+//                                     residual stream; doing the add here keeps the GEMM epilogue at 2 B per element)
+// xn[t] = bf16( x * rsqrt(mean(x^2) + eps) * w )
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ embed,
-                                                      const int* __restrict__ tok_id, const float* __restrict__ w,
-                                                      bf16_t* __restrict__ xn, float* __restrict__ xn_f32, int T, int H,
-                                                      float eps) {
+                                                      const int* __restrict__ tok_id, const bf16_t* __restrict__ delta,
+                                                      const float* __restrict__ w, bf16_t* __restrict__ xn,
+                                                      float* __restrict__ xn_f32, int T, int H, float eps) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= T) return;
     float* xr = x + (int64_t)t * H;
     const float* src = embed ? embed + (int64_t)tok_id[t] * H : xr;
+    const bf16_t* dr = delta ? delta + (int64_t)t * H : nullptr;
     float ss = 0.f;
     for (int i = lane * 4; i < H; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        if (dr) {
+            const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += bf16_to_f32((unsigned short)d[c]);
+        }
         ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        if (embed) *reinterpret_cast<f32x4*>(xr + i) = v;
+        if (embed || dr) *reinterpret_cast<f32x4*>(xr + i) = v;
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+    if (!w) return;   // residual add only
     for (int i = lane * 4; i < H; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);   // this lane's own writes (or the unchanged row)
         const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
         f32x4 y;
 #pragma unroll
@@ -297,6 +308,7 @@ struct sr_model {
     bf16_t* qkv = nullptr;     // [Tm, (nh + 2 nkv) hd]
     bf16_t* attn = nullptr;    // [Tm, nh hd]
     bf16_t* act = nullptr;     // [Tm, I]
+    bf16_t* delta = nullptr;   // [Tm, H] bf16 output of o_proj / down_proj, added to x by the next norm kernel
     int *span_start = nullptr, *span_len = nullptr, *pool_start = nullptr, *row_len = nullptr, *cu = nullptr;
     int *tok_id = nullptr, *pos = nullptr, *seq_of = nullptr;
     unsigned char* key_valid = nullptr;
@@ -309,7 +321,7 @@ static void model_free(sr_model* m) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(m->embed); F(m->lm_head); F(m->norm_w); F(m->rope_cos); F(m->rope_sin);
     for (auto& l : m->layers) { F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); }
-    F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act);
+    F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act); F(m->delta);
     F(m->span_start); F(m->span_len); F(m->pool_start); F(m->row_len); F(m->cu);
     F(m->tok_id); F(m->pos); F(m->seq_of); F(m->key_valid);
     if (m->h_cu) (void)hipHostFree(m->h_cu);
@@ -395,6 +407,7 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
     SR_ALLOC(m->qkv, Tm * (nq + 2 * nkv) * 2);
     SR_ALLOC(m->attn, Tm * nq * 2);
     SR_ALLOC(m->act, Tm * I * 2);
+    SR_ALLOC(m->delta, Tm * H * 2);
     SR_ALLOC(m->span_start, m->Bm * 4);
     SR_ALLOC(m->span_len, m->Bm * 4);
     SR_ALLOC(m->pool_start, m->Bm * 4);
@@ -538,14 +551,15 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
 
     const unsigned nblk = (unsigned)ceil_div64(T, 4);
     // embedding gather fused with the first input_layernorm
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, m->embed, m->tok_id, m->layers[0].ln1, m->xn,
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, m->embed, m->tok_id, (const bf16_t*)nullptr, m->layers[0].ln1, m->xn,
                        (float*)nullptr, T, H, c.rms_norm_eps);
     SR_CHECK_LAUNCH();
     for (int li = 0; li < c.num_layers; ++li) {
         LayerW& l = m->layers[li];
         if (li > 0) {
+            // adds the previous layer's down_proj output, then input_layernorm
             hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
-                               l.ln1, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
+                               (const bf16_t*)m->delta, l.ln1, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
             SR_CHECK_LAUNCH();
         }
         GemmArgs g{};
@@ -559,18 +573,23 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         a.apply_rope = 0; a.max_seqlen = max_len;
         SR_TRY(launch_attention(a, s));
         g = GemmArgs{};
-        g.A = m->attn; g.W = l.wo; g.M = T; g.N = H; g.K = nq; g.C = m->x;
-        SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
-        hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr, l.ln2,
-                           m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
+        g.A = m->attn; g.W = l.wo; g.M = T; g.N = H; g.K = nq; g.C = m->delta;
+        SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));
+        // x += o_proj output, then post_attention_layernorm
+        hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
+                           (const bf16_t*)m->delta, l.ln2, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
         SR_CHECK_LAUNCH();
         g = GemmArgs{};
         g.A = m->xn; g.W = l.wgu; g.M = T; g.N = 2 * I; g.K = H; g.C = m->act;
         SR_TRY(launch_gemm_bf16(EPI_SWIGLU, g, s));
         g = GemmArgs{};
-        g.A = m->act; g.W = l.wdown; g.M = T; g.N = H; g.K = I; g.C = m->x;
-        SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
+        g.A = m->act; g.W = l.wdown; g.M = T; g.N = H; g.K = I; g.C = m->delta;
+        SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));   // added to x by the next norm kernel (or the head)
     }
+    // fold the last down_proj output into the residual stream so that the heads see the complete hidden state
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
+                       (const bf16_t*)m->delta, (const float*)nullptr, (bf16_t*)nullptr, (float*)nullptr, T, H, c.rms_norm_eps);
+    SR_CHECK_LAUNCH();
     return SR_OK;
 }
 
@@ -602,7 +621,7 @@ extern "C" int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const i
     const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
     // final norm -> bf16 GEMM input
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
-                       (const int*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps);
+                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps);
     SR_CHECK_LAUNCH();
     SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
     GemmArgs g{};
@@ -625,7 +644,7 @@ extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_
     SR_REQUIRE(capacity_rows >= T, "sr_model_last_hidden: capacity %lld < %d tokens", (long long)capacity_rows, T);
     if (T == 0) return SR_OK;
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
-                       (const int*)nullptr, m->norm_w, (bf16_t*)nullptr, d_out, T, m->cfg.hidden_size, m->cfg.rms_norm_eps);
+                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, (bf16_t*)nullptr, d_out, T, m->cfg.hidden_size, m->cfg.rms_norm_eps);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -30,7 +30,7 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
 void gemm_bf16_kernel(GemmArgs g) {
-    constexpr int NW = WAVES_N * WAVES_M, NT = 64 * NW;
+    constexpr int NW = WAVES_N * WAVES_M;
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE_BYTES = W_BYTES + A_BYTES;
     constexpr int W_INSTR = BN / 8 / NW, A_INSTR = BM / 8 / NW;   // 8-row (1 KB) LDS-DMA pieces per wave
@@ -38,28 +38,31 @@ void gemm_bf16_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-    const int n0 = tile_n * BN, m0 = tile_m * BM;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int n_tiles = tiles_n * tiles_m;
     const int K = g.K;
+    constexpr bool CROSS_PREFETCH = (EPI != EPI_SEGMAX);   // the segmented-max epilogue reuses the staging LDS
 
     // ---- staging addresses: wave w moves rows [w*R, (w+1)*R) of each tile, 8 rows per instruction
     const int srow = lane >> 3;                       // row inside an 8-row piece
     const int schunk = (lane & 7) ^ (srow & 7);       // source 16-B chunk (swizzle on the source)
     const bf16_t* wsrc[W_INSTR];
     const bf16_t* asrc[A_INSTR];
+    auto set_tile = [&](int tile) {
+        const int tn0 = (tile % tiles_n) * BN, tm0 = (tile / tiles_n) * BM;
 #pragma unroll
-    for (int i = 0; i < W_INSTR; ++i) {
-        int rn = n0 + (wave * W_INSTR + i) * 8 + srow;
-        rn = rn < g.N ? rn : g.N - 1;
-        wsrc[i] = g.W + (int64_t)rn * K + schunk * 8;
-    }
+        for (int i = 0; i < W_INSTR; ++i) {
+            int rn = tn0 + (wave * W_INSTR + i) * 8 + srow;
+            rn = rn < g.N ? rn : g.N - 1;
+            wsrc[i] = g.W + (int64_t)rn * K + schunk * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        int rm = m0 + (wave * A_INSTR + i) * 8 + srow;
-        rm = rm < g.M ? rm : g.M - 1;
-        asrc[i] = g.A + (int64_t)rm * K + schunk * 8;
-    }
+        for (int i = 0; i < A_INSTR; ++i) {
+            int rm = tm0 + (wave * A_INSTR + i) * 8 + srow;
+            rm = rm < g.M ? rm : g.M - 1;
+            asrc[i] = g.A + (int64_t)rm * K + schunk * 8;
+        }
+    };
     auto stage = [&](int st, int k0) {
         unsigned char* wbase = smem + st * STAGE_BYTES + (wave * W_INSTR) * 1024;
         unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * A_INSTR) * 1024;
@@ -72,19 +75,30 @@ void gemm_bf16_kernel(GemmArgs g) {
     };
 
     f32x4 acc[NB][MB];
+    const int frow = lane & 15, fg = lane >> 4;
+    const int nk = K / G_BK;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    set_tile(tile);
+    stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile of the NEXT output tile is
+    // prefetched during the last k-step of the current one, so only the epilogue's stores stay exposed between tiles.
+    for (; tile < n_tiles; tile += gridDim.x) {
+    const int n0 = (tile % tiles_n) * BN, m0 = (tile / tiles_n) * BM;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fg = lane >> 4;
-    const int nk = K / G_BK;
-    stage(0, 0);
-    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * G_BK);
-        const unsigned char* wt = smem + cur * STAGE_BYTES;
+        if (kt + 1 < nk) {
+            stage(buf ^ 1, (kt + 1) * G_BK);
+        } else if (CROSS_PREFETCH && tile + (int)gridDim.x < n_tiles) {
+            set_tile(tile + gridDim.x);
+            stage(buf ^ 1, 0);
+        }
+        const unsigned char* wt = smem + buf * STAGE_BYTES;
         const unsigned char* at = wt + W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -103,6 +117,7 @@ void gemm_bf16_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
+        buf ^= 1;
     }
 
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
@@ -187,7 +202,7 @@ void gemm_bf16_kernel(GemmArgs g) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float sg = gt[r] / (1.f + __expf(-gt[r]));
+                    const float sg = gt[r] * __builtin_amdgcn_rcpf(1.f + __expf(-gt[r]));   // silu; rcp is ~1 ulp, output is bf16
                     o[r] = (short)f32_to_bf16(sg * up[r]);
                 }
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * half_n + n) = o;
@@ -230,7 +245,15 @@ void gemm_bf16_kernel(GemmArgs g) {
             if (cur_seq >= 0 && cur_max > 0.f)
                 atomicMax(reinterpret_cast<int*>(out + (int64_t)cur_seq * g.out_ld + n), __float_as_int(cur_max));
         }
+        if (tile + (int)gridDim.x < n_tiles) {   // no cross-tile prefetch here: restage after the LDS epilogue
+            __syncthreads();
+            set_tile(tile + gridDim.x);
+            stage(0, 0);
+            __syncthreads();
+            buf = 0;
+        }
     }
+    }  // tile loop
 }
 
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
@@ -243,7 +266,10 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
+    int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
+    const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
+    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? 2 : 1);   // resident workgroups on 256 CUs
+    if (!(env && *env == '0') && tiles > slots) tiles = slots;
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
     SR_CHECK_LAUNCH();

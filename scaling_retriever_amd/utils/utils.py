@@ -1,27 +1,30 @@
-"""Small helpers of the eval path: mirror of /root/reference/scaling_retriever/utils/utils.py
-(is_first_worker :20, to_list :23, obtain_doc_vec_dir_files :26-43, supports_bfloat16 :69-75)."""
+"""Process-group and artefact helpers of the eval path.
+
+Same call surface as the reference's `scaling_retriever/utils/utils.py` for the names the hot path uses
+(is_first_worker :20, to_list :23, obtain_doc_vec_dir_files :26-43, supports_bfloat16 :69-75); everything
+else in that module (QA helpers, training-time reductions) is out of scope.
+"""
 import json
 import os
 
 import torch
-import torch.distributed
+import torch.distributed as dist
 
 
-def is_first_worker():
-    return (not torch.distributed.is_available() or not torch.distributed.is_initialized()
-            or torch.distributed.get_rank() == 0)
-
-
-def get_world_size():
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return torch.distributed.get_world_size()
-    return 1
+def _dist_ready():
+    return dist.is_available() and dist.is_initialized()
 
 
 def get_rank():
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return torch.distributed.get_rank()
-    return 0
+    return dist.get_rank() if _dist_ready() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if _dist_ready() else 1
+
+
+def is_first_worker():
+    return get_rank() == 0
 
 
 def to_list(tensor):
@@ -29,31 +32,27 @@ def to_list(tensor):
 
 
 def obtain_doc_vec_dir_files(doc_embed_dir):
-    """plan.json {nranks, num_chunks, index_path} -> embs_{rank}_{chunk}.npy / ids_{rank}_{chunk}.npy
-    lists in rank-major order."""
+    """Shard manifest -> ordered file lists.
+
+    `plan.json` = {"nranks", "num_chunks", "index_path"} (written by store_embs); the embedding and id files of
+    encode rank r, chunk c are `embs_{r}_{c}.npy` / `ids_{r}_{c}.npy`, listed rank-major.  Missing files are an error.
+    """
     with open(os.path.join(doc_embed_dir, "plan.json")) as fin:
         plan = json.load(fin)
-    doc_vec_files, doc_id_files = [], []
-    for i in range(plan["nranks"]):
-        for j in range(plan["num_chunks"]):
-            vec_file = os.path.join(doc_embed_dir, f"embs_{i}_{j}.npy")
-            doc_id_file = os.path.join(doc_embed_dir, f"ids_{i}_{j}.npy")
-            assert os.path.exists(vec_file) and os.path.exists(doc_id_file)
-            doc_vec_files.append(vec_file)
-            doc_id_files.append(doc_id_file)
-    return doc_vec_files, doc_id_files
+    pairs = [(r, c) for r in range(int(plan["nranks"])) for c in range(int(plan["num_chunks"]))]
+    vec_files = [os.path.join(doc_embed_dir, "embs_%d_%d.npy" % rc) for rc in pairs]
+    id_files = [os.path.join(doc_embed_dir, "ids_%d_%d.npy" % rc) for rc in pairs]
+    missing = [f for f in vec_files + id_files if not os.path.exists(f)]
+    assert not missing, f"plan.json lists shard files that do not exist: {missing[:3]}"
+    return vec_files, id_files
 
 
 def supports_bfloat16():
-    """The reference tests compute capability >= 8; on ROCm `major` is the gfx major (9 on gfx950).
-    The HIP encoder always computes its GEMMs in bf16 with fp32 accumulation."""
-    if torch.cuda.is_available():
-        return torch.cuda.get_device_properties(torch.cuda.current_device()).major >= 8
-    return False
+    """True on MI355X.  The reference gates autocast on CUDA compute capability >= 8; on ROCm `major` is the gfx
+    major (9 for gfx950).  The HIP encoder always uses bf16 GEMM inputs with fp32 accumulation, so this only
+    exists for callers that branch on it."""
+    return torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).major >= 8
 
 
 def batch_to_device(batch, device):
-    for k, v in batch.items():
-        if isinstance(v, torch.Tensor):
-            batch[k] = v.to(device)
-    return batch
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}

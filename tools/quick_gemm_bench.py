@@ -1,4 +1,4 @@
-"""Ad-hoc GEMM timing (development aid): the four 1B-layer GEMM shapes at a given token count, both tiles."""
+"""Ad-hoc GEMM timing (development aid): the four 1B-layer GEMM shapes at a given token count, tile x persist A/B."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -23,10 +23,10 @@ if __name__ == "__main__":
     shapes = [("qkv", 3072, 2048, 0), ("o", 2048, 2048, 1), ("gate_up", 16384, 2048, 2), ("down", 2048, 8192, 1)]
     for M in Ms:
         for tile in ("128", "256"):
-            os.environ["SR_GEMM_TILE"] = tile
-            tot_ms, tot_fl = 0, 0
-            row = {}
-            for name, N, K, epi in shapes:
-                ms, tf = run(M, N, K, epi)
-                row[name] = round(tf, 1); tot_ms += ms; tot_fl += 2.0 * M * N * K
-            print(json.dumps({"M": M, "tile": tile, "TF": row, "layer_TF": round(tot_fl / tot_ms / 1e9, 1), "layer_ms": round(tot_ms, 3)}), flush=True)
+            for persist in ("0", "1"):
+                os.environ["SR_GEMM_TILE"] = tile; os.environ["SR_GEMM_PERSIST"] = persist
+                tot_ms, tot_fl, row = 0, 0, {}
+                for name, N, K, epi in shapes:
+                    ms, tf = run(M, N, K, epi)
+                    row[name] = round(tf, 1); tot_ms += ms; tot_fl += 2.0 * M * N * K
+                print(json.dumps({"M": M, "tile": tile, "persist": persist, "TF": row, "layer_TF": round(tot_fl / tot_ms / 1e9, 1)}), flush=True)
