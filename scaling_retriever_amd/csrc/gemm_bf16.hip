@@ -79,6 +79,10 @@ void gemm_bf16_kernel(GemmArgs g) {
     const int nk = K / G_BK;
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    const bool stamp = g.stamps != nullptr && tid == 0;
+    unsigned long long* stp = g.stamps ? g.stamps + (size_t)blockIdx.x * 64 : nullptr;   // up to 16 tiles x 4 stamps
+    int titer = 0;
+    if (stamp) stp[0] = __builtin_amdgcn_s_memrealtime();
     set_tile(tile);
     stage(0, 0);
     __syncthreads();
@@ -91,6 +95,7 @@ void gemm_bf16_kernel(GemmArgs g) {
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) {
             stage(buf ^ 1, (kt + 1) * G_BK);
@@ -120,6 +125,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         buf ^= 1;
     }
 
+    if (stamp && titer < 16) stp[titer * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
     if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) {
 #pragma unroll
@@ -253,6 +259,12 @@ void gemm_bf16_kernel(GemmArgs g) {
             buf = 0;
         }
     }
+    if (stamp && titer < 16) {
+        __builtin_amdgcn_s_waitcnt(0);   // diagnostic build path only: let this wave's stores retire before the stamp
+        stp[titer * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (titer + 1 < 16) stp[(titer + 1) * 4] = stp[titer * 4 + 3];
+    }
+    ++titer;
     }  // tile loop
 }
 

@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* rope_sin;
     int n_rope;             // features [0, n_rope) are rotated (q heads then k heads), the rest (v) stored as is
     int head_dim;           // 64 or 128
+    unsigned long long* stamps;  // diagnostics only (tools/micro): 4 s_memrealtime stamps (100 MHz) per workgroup-tile, else null
 };
 
 // y = A @ W^T with fused epilogue. Requirements: K % 64 == 0, N % 16 == 0 (N % 32 for SWIGLU),
