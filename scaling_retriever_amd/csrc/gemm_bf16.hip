@@ -27,7 +27,9 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 #define G_BK 64
 
 // WAVES_N x WAVES_M waves; each wave owns (16 * NB) features x (16 * MB) tokens.
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
+// PIPE: fragment double-buffering - the ds_reads of the next half k-step are in flight while the MFMAs of the current
+// half run, stages are issued two k-steps ahead, still one barrier per k-step (placed between the two halves).
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
 void gemm_bf16_kernel(GemmArgs g) {
     constexpr int NW = WAVES_N * WAVES_M;
@@ -85,44 +87,104 @@ void gemm_bf16_kernel(GemmArgs g) {
     if (stamp) stp[0] = __builtin_amdgcn_s_memrealtime();
     set_tile(tile);
     stage(0, 0);
+    if constexpr (PIPE) stage(1, G_BK);     // PIPE needs nk >= 2 (checked at launch)
     __syncthreads();
     int buf = 0;
-    // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile of the NEXT output tile is
-    // prefetched during the last k-step of the current one, so only the epilogue's stores stay exposed between tiles.
+    auto load_frags = [&](int st, int kk, mfma_bf16x8 (&wf)[NB], mfma_bf16x8 (&af)[MB]) {
+        const unsigned char* wt = smem + st * STAGE_BYTES;
+        const unsigned char* at = wt + W_BYTES;
+        const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + i * 16 + frow) * 128 + pos);
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+            af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
+    };
+    auto mfma_all = [&](const mfma_bf16x8 (&wf)[NB], const mfma_bf16x8 (&af)[MB]) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    };
+    // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile(s) of the NEXT output tile are
+    // prefetched during the last k-step(s) of the current one, so only the epilogue's stores stay exposed between tiles.
     for (; tile < n_tiles; tile += gridDim.x) {
     const int n0 = (tile % tiles_n) * BN, m0 = (tile / tiles_n) * BM;
+    const bool has_next = tile + (int)gridDim.x < n_tiles;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            stage(buf ^ 1, (kt + 1) * G_BK);
-        } else if (CROSS_PREFETCH && tile + (int)gridDim.x < n_tiles) {
-            set_tile(tile + gridDim.x);
-            stage(buf ^ 1, 0);
-        }
-        const unsigned char* wt = smem + buf * STAGE_BYTES;
-        const unsigned char* at = wt + W_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+    if constexpr (PIPE) {
+        // 4 phases per k-step: (kk, half of the wave's feature blocks).  While a phase's 16 MFMAs run, the fragments of the
+        // next phase are being read from LDS (rolling wx / wy, a0 / a1).  The k-step barrier sits before the LAST phase's
+        // MFMAs: by then every read of stage `buf` has been issued and waited for, so the stage can be refilled (k-step
+        // kt + 2) and the next k-step's first fragments can be requested from stage buf ^ 1 under those MFMAs.
+        constexpr int HB = NB / 2;
+        mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
+        auto load_w = [&](int st, int kk, int h, mfma_bf16x8 (&wf)[HB]) {
+            const unsigned char* wt = smem + st * STAGE_BYTES;
             const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
-            mfma_bf16x8 wf[NB], af[MB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + i * 16 + frow) * 128 + pos);
+            for (int i = 0; i < HB; ++i)
+                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + (h * HB + i) * 16 + frow) * 128 + pos);
+        };
+        auto load_a = [&](int st, int kk, mfma_bf16x8 (&af)[MB]) {
+            const unsigned char* at = smem + st * STAGE_BYTES + W_BYTES;
+            const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
 #pragma unroll
             for (int j = 0; j < MB; ++j)
                 af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
+        };
+#define SR_MFMA_HALF(H, WF, AF)                                                                              \
+        _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                   \
+                acc[(H) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(H) * HB + i][j], 0, 0, 0);
+        load_w(buf, 0, 0, wx);
+        load_a(buf, 0, a0);
+        for (int kt = 0; kt < nk; ++kt) {
+            load_w(buf, 0, 1, wy);
+            SR_MFMA_HALF(0, wx, a0)
+            load_w(buf, 1, 0, wx);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(1, wy, a0)
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+            __syncthreads();
+            if (kt + 2 < nk) {
+                stage(buf, (kt + 2) * G_BK);
+            } else if (has_next) {
+                if (kt + 2 == nk) set_tile(tile + gridDim.x);
+                stage(buf, (kt + 2 - nk) * G_BK);
+            }
+            if (kt + 1 < nk) {
+                load_w(buf ^ 1, 0, 0, wx);
+                load_a(buf ^ 1, 0, a0);
+            }
+            SR_MFMA_HALF(1, wy, a1)
+            buf ^= 1;
+        }
+#undef SR_MFMA_HALF
+    } else {
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            stage(buf ^ 1, (kt + 1) * G_BK);
+        } else if (CROSS_PREFETCH && has_next) {
+            set_tile(tile + gridDim.x);
+            stage(buf ^ 1, 0);
+        }
+        mfma_bf16x8 wf[NB], af[MB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int j = 0; j < MB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+            load_frags(buf, kk, wf, af);
+            mfma_all(wf, af);
         }
         __syncthreads();
         buf ^= 1;
+    }
     }
 
     if (stamp && titer < 16) stp[titer * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -268,13 +330,13 @@ void gemm_bf16_kernel(GemmArgs g) {
     }  // tile loop
 }
 
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB>
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr size_t lds = 2 * (size_t)(BN + BM) * 128 + (EPI == EPI_SEGMAX ? 512 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -282,7 +344,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
     const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? 2 : 1);   // resident workgroups on 256 CUs
     if (!(env && *env == '0') && tiles > slots) tiles = slots;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
     SR_CHECK_LAUNCH();
     return SR_OK;
@@ -301,17 +363,24 @@ static bool prefer_big_tile(const GemmArgs& g) {
 }
 
 template <int EPI>
+static int launch_big(const GemmArgs& g, hipStream_t s) {
+    const char* env = getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
+    if (g.K / G_BK >= 4 && !(env && *env == '0')) return launch_cfg<EPI, 2, 4, 8, 4, true>(g, s);
+    return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);
+}
+
+template <int EPI>
 static int launch_one(const GemmArgs& g, hipStream_t s) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
-        if (prefer_big_tile(g)) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);       // wave covers 128 features
+        if (prefer_big_tile(g)) return launch_big<EPI>(g, s);       // wave covers 128 features
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
         return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
     } else {
         if constexpr (EPI != EPI_SEGMAX) {
-            if (prefer_big_tile(g)) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);
+            if (prefer_big_tile(g)) return launch_big<EPI>(g, s);
         }
         return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
     }
