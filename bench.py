@@ -69,19 +69,20 @@ def random_weights(cfg, device, seed):
     return w
 
 
-def synth_batches(n, batch, mu, sigma, lo, hi, vocab, seed, device):
+def synth_batches(n, batch, mu, sigma, lo, hi, vocab, seed, device, rows=None):
     """Left-padded, pad-to-longest batches like the reference's collator + padding_side='left'
-    (data_collator.py:184-186, eval_dense.py:185,206)."""
-    rng = np.random.default_rng(seed)
-    lens = np.clip(np.round(rng.lognormal(mu, sigma, size=n)), lo, hi).astype(np.int64)
+    (data_collator.py:184-186, eval_dense.py:185,206).  Row r's tokens depend only on (seed, r), so a rank that
+    encodes rows [rows[0], rows[1]) of the set sees exactly the tokens a single-GPU run sees for those rows."""
+    lens = np.clip(np.round(np.random.default_rng(seed).lognormal(mu, sigma, size=n)), lo, hi).astype(np.int64)
+    r0, r1 = rows if rows is not None else (0, n)
     out = []
-    for b0 in range(0, n, batch):
-        ls = lens[b0:b0 + batch]
+    for b0 in range(r0, r1, batch):
+        ls = lens[b0:min(b0 + batch, r1)]
         L = int(ls.max())
         ids = np.full((len(ls), L), vocab - 1, dtype=np.int64)
         mask = np.zeros((len(ls), L), dtype=np.int64)
         for r, l in enumerate(ls):
-            ids[r, L - l:] = rng.integers(0, vocab - 1, size=l)
+            ids[r, L - l:] = np.random.default_rng((seed, b0 + r)).integers(0, vocab - 1, size=l)
             mask[r, L - l:] = 1
         out.append((torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)))
     return out, lens
@@ -113,7 +114,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from scaling_retriever_amd import _lib
-    from scaling_retriever_amd.distributed import gather_topk, shard_size
+    from scaling_retriever_amd.distributed import all_gather_query_reps, gather_topk, query_slice, shard_size
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     from scaling_retriever_amd.scoring import DenseIndexHIP, topk_merge
     lib = _lib.load()
@@ -124,7 +125,9 @@ def main():
     H = cfg["hidden_size"]
     t_setup = time.time()
     model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=4096).to(device).eval()
-    q_batches, q_lens = synth_batches(args.n_queries, args.query_batch, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device)
+    # every rank encodes only its block of the queries; the embeddings are all-gathered (second, 57 MB collective)
+    q_rows = query_slice(args.n_queries, rank, world)
+    q_batches, q_lens = synth_batches(args.n_queries, args.query_batch, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device, rows=q_rows)
     n_local = shard_size(args.n_docs, rank, world)
     D = torch.empty((n_local, H), dtype=torch.float32, device=device)
     g = torch.Generator(device=device).manual_seed(1 + rank)
@@ -136,8 +139,13 @@ def main():
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s: {n_local} docs x {H} fp32 = {n_local * H * 4 / 1e9:.1f} GB resident; "
         f"{args.n_queries} queries, mean {q_lens.mean():.1f} tokens")
 
+    def encode_queries():
+        local = [model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches]
+        local = torch.cat(local) if local else torch.zeros((0, H), dtype=torch.float32, device=device)
+        return all_gather_query_reps(local, args.n_queries)
+
     def step():
-        reps = torch.cat([model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches])
+        reps = encode_queries()
         s, i = index.search(reps, args.topk)
         if world > 1:
             gs, gi = gather_topk(s, i, dst=0)
@@ -189,7 +197,7 @@ def main():
     # ---- where a step's time goes (one extra pass of each stage, synchronised; not part of the timed region) ----
     torch.cuda.synchronize()
     tb = time.perf_counter()
-    reps_b = torch.cat([model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches])
+    reps_b = encode_queries()
     torch.cuda.synchronize()
     t_enc = time.perf_counter() - tb
     tb = time.perf_counter()
@@ -256,7 +264,7 @@ def main():
         from oracle import scoring as SC
         ns, nqs = min(n_local, 400_000), min(args.n_queries, 1024)
         Dh = D[:ns].cpu().numpy()
-        Qh = torch.cat([model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches[:(nqs + 127) // 128]])[:nqs].cpu().numpy()
+        Qh = encode_queries()[:nqs].cpu().numpy()
         SC.flat_ip_search_fast(Qh[:64], Dh[:20000], min(args.topk, 1000))
         tc = time.perf_counter()
         SC.flat_ip_search_fast(Qh, Dh, args.topk)
@@ -278,7 +286,8 @@ def main():
                                    f"+ brute-force fp32 top-{args.topk} over {args.n_docs} x {H} passage embeddings resident in HBM",
                        "n_docs": args.n_docs, "n_queries": args.n_queries, "hidden": H, "topk": args.topk,
                        "query_batch": args.query_batch, "layers": cfg["num_hidden_layers"],
-                       "parallelism": f"doc-shard x{world}" + (" + 1 RCCL gather of per-shard top-k" if world > 1 else "")},
+                       "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
+                                                                       "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "breakdown": breakdown, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)

@@ -106,6 +106,40 @@ def generate_query_vecs(model, dataloader, device):
     return torch.cat(reps), qids
 
 
+class DenseRetriever:
+    """eval_dense.py:88-106."""
+
+    def __init__(self, model, device):
+        self.model = model
+        self.model.eval()
+        self.device = device
+
+    def generate_query_vecs(self, dataloader):
+        reps, qids = generate_query_vecs(self.model, dataloader, self.device)
+        return reps.cpu().numpy(), qids
+
+
+class LocalFaissDenseRetriever(DenseRetriever):
+    """eval_dense.py:108-135 with the flat index resident in HBM (DenseFlatIndexer over the HIP scorer)."""
+
+    def __init__(self, model, device, index):
+        super().__init__(model, device)
+        self.index = index
+
+    def index_encoded_data(self, doc_vec_files, doc_id_files):
+        # one HBM segment per shard file instead of one concatenated host copy (eval_dense.py:113-121)
+        total = 0
+        for doc_file, id_file in zip(doc_vec_files, doc_id_files):
+            total += self.index.index_data(np.load(doc_file), np.load(id_file).tolist())
+        print("size of doc reps indexed: ", total)
+
+    def get_top_docs(self, dataloader, top_docs):
+        query_reps, qids = self.generate_query_vecs(dataloader)
+        top_doc_ids, top_scores = self.index.search_knn(query_reps, top_docs)
+        assert len(qids) == len(query_reps), (len(qids), len(query_reps))
+        return qids, top_doc_ids, top_scores
+
+
 def retrieval(args):
     from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
     from scaling_retriever_amd.dataset.dataset import MSMARCOQueryDataset

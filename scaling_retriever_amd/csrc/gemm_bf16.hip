@@ -118,6 +118,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (stamp && titer == 1) stp[62] = __builtin_amdgcn_s_memtime();        // shader-clock ticks at the start of tile 1's k-loop
     if constexpr (PIPE) {
         // 4 phases per k-step: (kk, half of the wave's feature blocks).  While a phase's 16 MFMAs run, the fragments of the
         // next phase are being read from LDS (rolling wx / wy, a0 / a1).  The k-step barrier sits before the LAST phase's
@@ -188,6 +189,7 @@ void gemm_bf16_kernel(GemmArgs g) {
     }
 
     if (stamp && titer < 16) stp[titer * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (stamp && titer == 1) stp[63] = __builtin_amdgcn_s_memtime();        // ... and at its end: clock = d(memtime) / d(realtime) * 100 MHz
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
     if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) {
 #pragma unroll

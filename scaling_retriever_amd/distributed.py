@@ -46,12 +46,42 @@ def gather_topk(scores, ids, dst=0, group=None):
         return scores.unsqueeze(0), ids.unsqueeze(0)
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     packed = pack_topk(scores, ids)
+    device = packed.device
+    if dist.get_backend(group) == "gloo" and packed.is_cuda:
+        packed = packed.cpu()        # gloo (CPU tests, or several ranks sharing one GPU) has no CUDA gather
     bufs = [torch.empty_like(packed) for _ in range(W)] if rank == dst else None
     dist.gather(packed, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
         return None, None
-    s, i = zip(*[unpack_topk(b) for b in bufs])
+    s, i = zip(*[unpack_topk(b.to(device)) for b in bufs])
     return torch.stack(s), torch.stack(i)
+
+
+def query_slice(n_queries, rank, world_size):
+    """Contiguous block of queries rank `rank` encodes: [lo, hi) of ceil(n/W)-sized blocks (the last ones may be short)."""
+    per = (n_queries + world_size - 1) // world_size
+    return min(rank * per, n_queries), min((rank + 1) * per, n_queries)
+
+
+def all_gather_query_reps(local_reps, n_queries, group=None):
+    """Second (small) collective of the sharded path: every rank encodes only ITS block of queries
+    (query_slice) and the fp32 embeddings are all-gathered (6980 x 2048 x 4 B = 57 MB in total), instead of every
+    rank re-encoding all queries.  local_reps: [hi - lo, H]; returns [n_queries, H] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_reps
+    W = dist.get_world_size(group)
+    per = (n_queries + W - 1) // W
+    H = local_reps.shape[1]
+    padded = torch.zeros((per, H), dtype=local_reps.dtype, device=local_reps.device)
+    padded[:local_reps.shape[0]] = local_reps
+    out = torch.empty((W * per, H), dtype=local_reps.dtype, device=local_reps.device)
+    if dist.get_backend(group) == "gloo" and padded.is_cuda:
+        chunks = [torch.empty((per, H), dtype=padded.dtype) for _ in range(W)]
+        dist.all_gather(chunks, padded.cpu(), group=group)
+        out = torch.cat(chunks).to(local_reps.device)
+    else:
+        dist.all_gather_into_tensor(out, padded, group=group)
+    return out[:n_queries].contiguous()
 
 
 class ShardedDenseRetriever:

@@ -127,6 +127,26 @@ def test_eval_dense_and_sparse_drivers_end_to_end(golden_dir, tmp_path):
     eval_dense.main(["--task_name", "retrieval", "--model_name_or_path", lora, "--query_path", str(tmp_path / "queries.tsv"),
                      "--doc_embed_dir", emb_dir, "--out_dir", out_dir, "--top_k", "10", "--query_max_length", "8"])
     run = json.load(open(os.path.join(out_dir, "run.json")))
+    # the class-shaped caller of the reference (LocalFaissDenseRetriever, eval_dense.py:108-135) gives the same run
+    from torch.utils.data import DataLoader
+    from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
+    from scaling_retriever_amd.dataset.dataset import MSMARCOQueryDataset
+    from scaling_retriever_amd.indexer import DenseFlatIndexer
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    from scaling_retriever_amd.utils.utils import obtain_doc_vec_dir_files
+    model = LlamaBiDense.load_from_lora(lora).to("cuda").eval()
+    ptok = eval_dense._tokenizer(lora)
+    index = DenseFlatIndexer()
+    index.init_index(model.hidden_size)
+    retriever = eval_dense.LocalFaissDenseRetriever(model, index=index, device="cuda")
+    retriever.index_encoded_data(*obtain_doc_vec_dir_files(emb_dir))
+    q_loader = DataLoader(MSMARCOQueryDataset(str(tmp_path / "queries.tsv")), batch_size=4, shuffle=False,
+                          collate_fn=LlamaDenseCollectionCollator(tokenizer=ptok, max_length=8))
+    qids, top_ids, top_scores = retriever.get_top_docs(q_loader, top_docs=10)
+    for qid, ids_, scores_ in zip(qids, top_ids, top_scores):
+        assert list(run[qid].keys()) == [str(i) for i in ids_]
+        np.testing.assert_allclose(np.array(list(run[qid].values()), np.float32), scores_, rtol=2e-3, atol=2e-3)
+
     tok = AutoTokenizer.from_pretrained(lora)
     d_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, docs, 16)
     q_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, queries, 8)

@@ -117,6 +117,11 @@ from scaling_retriever_amd.distributed import gather_topk, shard_rows
 from oracle import scoring as SC
 dist.init_process_group("gloo")
 rank, W = dist.get_rank(), dist.get_world_size()
+from scaling_retriever_amd.distributed import all_gather_query_reps, query_slice
+for nq in (7, 8, 1):                                     # ragged, even and fewer-queries-than-ranks splits
+    Qall = torch.arange(nq * 3, dtype=torch.float32).reshape(nq, 3)
+    lo, hi = query_slice(nq, rank, W)
+    assert torch.equal(all_gather_query_reps(Qall[lo:hi].contiguous(), nq), Qall), nq
 rng = np.random.default_rng(0)
 D = rng.standard_normal((501, 32), dtype=np.float32); Q = rng.standard_normal((6, 32), dtype=np.float32); k = 20
 rows = np.array(list(shard_rows(len(D), rank, W)))

@@ -1,0 +1,54 @@
+"""GPU: the N > 1 path with real HIP kernels - 2 processes (gloo rendezvous, both on cuda:0), each holding the doc
+shard rank, rank + W, ... in HBM, ShardedDenseRetriever.search = local sr_dense_search + ONE gather + sr_topk_merge
+on rank 0; the result must equal the single-index search bit for bit.  (On the 8-GPU node the same code runs with
+backend "nccl" = RCCL; only the transport differs.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from scaling_retriever_amd.distributed import ShardedDenseRetriever, shard_rows
+from scaling_retriever_amd.scoring import DenseIndexHIP
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, W = dist.get_rank(), dist.get_world_size()
+g = torch.Generator(device="cuda").manual_seed(0)
+n, h, k = 30001, 128, 200
+D = torch.randn((n, h), device="cuda", generator=g)
+Q = torch.randn((150, h), device="cuda", generator=g)           # identical on every rank (same seed)
+from scaling_retriever_amd.distributed import all_gather_query_reps, query_slice
+lo, hi = query_slice(Q.shape[0], rank, W)                        # each rank "encodes" only its block of queries
+Qg = all_gather_query_reps(Q[lo:hi].contiguous(), Q.shape[0])
+assert torch.equal(Qg, Q)
+r = ShardedDenseRetriever(h)
+assert (r.rank, r.world_size) == (rank, W)
+r.add_local_rows(D[torch.arange(rank, n, W, device="cuda")].contiguous())
+for nq in (150, 7):                                              # MFMA-tiled and streaming kernels
+    s, i = r.search(Q[:nq].contiguous(), k)
+    if rank == 0:
+        full = DenseIndexHIP(h); full.add_device_rows(D)
+        fs, fi = full.search(Q[:nq].contiguous(), k)
+        assert torch.equal(i, fi) and torch.equal(s, fs), nq
+    else:
+        assert s is None and i is None
+if rank == 0: print("SHARDED_OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_dense_retriever_two_processes(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29633", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "SHARDED_OK" in out.stdout
