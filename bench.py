@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--encode-batches", type=int, default=16, help="passage batches (x128) for the encode figure")
     ap.add_argument("--layers", type=int, default=None, help="override num layers (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 precision measurement")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 / bf16x6 precision-mode measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,12 +207,11 @@ def main():
     breakdown = {"query_encode_ms": round(t_enc * 1e3, 1), "search_ms": round(t_search * 1e3, 1),
                  "query_tokens": int(q_lens.sum()), "query_encode_calls": len(q_batches)}
 
-    # ---- the same step with the score kernel in bf16x3 arithmetic (opt-in precision mode; fp32 operands split into
-    #      bf16 hi + lo, three bf16 MFMA products, fp32 accumulate: within 2.5e-6 |q||d| of the fp32 scores) ----
-    fast = None
-    if not args.no_fast_mode:
+    # ---- the same step with the score kernel in split-bf16 arithmetic (opt-in precision modes of sr_dense_search;
+    #      fp32 operands split into bf16 planes, 3 / 6 plane products on the bf16 MFMA pipe, fp32 accumulate) ----
+    def timed_mode(mode, n_prod, note):
         try:
-            index.set_precision("bf16x3")
+            index.set_precision(mode)
             step()
             _lib.check(lib.sr_dense_index_profile(index._h, 1))
             barrier()
@@ -228,16 +227,25 @@ def main():
                 dtf = float(t.item())
             _lib.check(lib.sr_dense_index_profile_read(index._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
             eq_tf = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-            fast = {"precision": "bf16x3", "value": round(args.n_queries * args.steps / dtf, 2), "unit": "queries/s",
+            return {"precision": mode, "value": round(args.n_queries * args.steps / dtf, 2), "unit": "queries/s",
                     "ms_per_step": round(dtf / args.steps * 1e3, 2),
-                    "roofline": {"kernel": "dense_split_kernel (bf16 MFMA 16x16x32, 3 products per fp32-equivalent FMA)", "bound": "mfma",
-                                 "achieved": round(3 * eq_tf, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s (bf16 MFMA work = 3 x algorithmic)",
-                                 "frac": round(3 * eq_tf / PEAK_BF16_MFMA_TF, 4), "fp32_equivalent_TFLOPs": round(eq_tf, 1),
+                    "roofline": {"kernel": f"dense_split_kernel (bf16 MFMA 16x16x32, {n_prod} products per fp32-equivalent FMA)", "bound": "mfma",
+                                 "achieved": round(n_prod * eq_tf, 1), "peak": PEAK_BF16_MFMA_TF,
+                                 "unit": f"TFLOP/s (bf16 MFMA work = {n_prod} x algorithmic)",
+                                 "frac": round(n_prod * eq_tf / PEAK_BF16_MFMA_TF, 4), "fp32_equivalent_TFLOPs": round(eq_tf, 1),
                                  "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4)},
-                    "note": "scores within 2.5e-6*|q||d| of the exact fp32 path (tests/test_dense_bf16x3_gpu.py); needs a bf16 copy of D (+72 GB)"}
-            index.set_precision("fp32")
+                    "note": note}
         except MemoryError as e:
-            fast = {"precision": "bf16x3", "skipped": str(e)}
+            return {"precision": mode, "skipped": str(e)}
+        finally:
+            index.set_precision("fp32")
+
+    fast = fp32_class = None
+    if not args.no_fast_mode:
+        fp32_class = timed_mode("bf16x6", 6, "3 bf16 planes = the whole fp32 significand: scores within 4e-7*|q||d| of the exact fp32 path, the "
+                                "error class of an fp32 dot product (tests/test_dense_bf16x3_gpu.py); needs 3 bf16 planes of D (+1.5x)")
+        fast = timed_mode("bf16x3", 3, "scores within 2.5e-6*|q||d| of the exact fp32 path (tests/test_dense_bf16x3_gpu.py); "
+                          "uses the first 2 bf16 planes of D")
 
     # ---- secondary figure: passages/s of doc_encode (same engine, doc-length batches) ----
     def encode_rate(batch):
@@ -288,7 +296,7 @@ def main():
                        "query_batch": args.query_batch, "layers": cfg["num_hidden_layers"],
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
-            "roofline": roofline, "breakdown": breakdown, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
+            "roofline": roofline, "breakdown": breakdown, "fp32_class_mode": fp32_class, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

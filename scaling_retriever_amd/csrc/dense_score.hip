@@ -167,8 +167,8 @@ struct DenseSegment {
     const float* rows;
     int64_t n;
     int64_t id_base, id_stride;
-    unsigned short* hi = nullptr;   // library-owned bf16 planes (precision = bf16x3 only)
-    unsigned short* lo = nullptr;
+    unsigned short* pl[3] = {nullptr, nullptr, nullptr};   // library-owned bf16 planes (split precisions only)
+    int n_planes = 0;
 };
 
 struct sr_dense_index {
@@ -177,25 +177,29 @@ struct sr_dense_index {
     int64_t ntotal = 0;
     int64_t ws_limit = 4ll << 30;
     int precision = SR_PRECISION_FP32;
-    unsigned short* qhi = nullptr;   // query planes for the bf16x3 path
-    unsigned short* qlo = nullptr;
+    unsigned short* qpl[3] = {nullptr, nullptr, nullptr};   // query planes for the split precisions
     int64_t q_cap = 0;
     TopkWS ws;
     LaunchProfile prof;
     std::mutex mu;
 };
 
-static int split_segment(sr_dense_index* idx, DenseSegment& seg) {
-    if (seg.hi) return SR_OK;
+static int planes_of(int precision) { return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : 0); }
+
+static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
+    if (seg.n_planes >= want) return SR_OK;
     const size_t bytes = (size_t)seg.n * (size_t)idx->dim * 2;
-    if (hipMalloc((void**)&seg.hi, bytes) != hipSuccess || hipMalloc((void**)&seg.lo, bytes) != hipSuccess) {
-        if (seg.hi) (void)hipFree(seg.hi);
-        seg.hi = seg.lo = nullptr;
-        sr_set_error("bf16x3 precision needs %zu more bytes of device memory for this segment", 2 * bytes);
-        return SR_ERR_NOMEM;
+    for (int p = seg.n_planes; p < want; ++p) {
+        if (hipMalloc((void**)&seg.pl[p], bytes) != hipSuccess) {
+            seg.pl[p] = nullptr;
+            sr_set_error("split precision needs %zu more bytes of device memory per plane of this segment", bytes);
+            return SR_ERR_NOMEM;
+        }
     }
-    SR_TRY(launch_split_bf16(seg.rows, seg.hi, seg.lo, seg.n * (int64_t)idx->dim, nullptr));
+    // (re)compute all planes: cheap next to one search, and keeps the planes consistent
+    SR_TRY(launch_split_bf16(seg.rows, seg.pl[0], seg.pl[1], want == 3 ? seg.pl[2] : nullptr, seg.n * (int64_t)idx->dim, nullptr));
     SR_CHECK_HIP(hipStreamSynchronize(nullptr));
+    seg.n_planes = want;
     return SR_OK;
 }
 
@@ -234,7 +238,7 @@ extern "C" int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int6
     std::lock_guard<std::mutex> lock(idx->mu);
     DenseSegment seg;
     seg.rows = d_rows; seg.n = n_rows; seg.id_base = id_base; seg.id_stride = id_stride;
-    if (idx->precision == SR_PRECISION_BF16X3) SR_TRY(split_segment(idx, seg));
+    if (planes_of(idx->precision)) SR_TRY(split_segment(idx, seg, planes_of(idx->precision)));
     idx->segs.push_back(seg);
     idx->ntotal += n_rows;
     return SR_OK;
@@ -251,23 +255,23 @@ extern "C" int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t b
 extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
-    for (DenseSegment& seg : idx->segs) {
-        if (seg.hi) (void)hipFree(seg.hi);
-        if (seg.lo) (void)hipFree(seg.lo);
-    }
-    if (idx->qhi) (void)hipFree(idx->qhi);
-    if (idx->qlo) (void)hipFree(idx->qlo);
+    for (DenseSegment& seg : idx->segs)
+        for (int p = 0; p < 3; ++p)
+            if (seg.pl[p]) (void)hipFree(seg.pl[p]);
+    for (int p = 0; p < 3; ++p)
+        if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
     delete idx;
     return SR_OK;
 }
 
 extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
     SR_REQUIRE(idx, "sr_dense_index_set_precision: null index");
-    SR_REQUIRE(mode == SR_PRECISION_FP32 || mode == SR_PRECISION_BF16X3, "sr_dense_index_set_precision: unknown mode %d", mode);
+    SR_REQUIRE(mode == SR_PRECISION_FP32 || mode == SR_PRECISION_BF16X3 || mode == SR_PRECISION_BF16X6,
+               "sr_dense_index_set_precision: unknown mode %d", mode);
     std::lock_guard<std::mutex> lock(idx->mu);
-    if (mode == SR_PRECISION_BF16X3) {
-        SR_REQUIRE(idx->dim % 64 == 0, "bf16x3 precision needs dim %% 64 == 0 (dim = %d)", idx->dim);
-        for (DenseSegment& seg : idx->segs) SR_TRY(split_segment(idx, seg));
+    if (planes_of(mode)) {
+        SR_REQUIRE(idx->dim % 64 == 0, "split precisions need dim %% 64 == 0 (dim = %d)", idx->dim);
+        for (DenseSegment& seg : idx->segs) SR_TRY(split_segment(idx, seg, planes_of(mode)));
     }
     idx->precision = mode;
     return SR_OK;
@@ -305,25 +309,35 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if (idx->precision == SR_PRECISION_BF16X3 && nq > 64) {
-        // fp32-equivalent scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
+    if (planes_of(idx->precision) && nq > 64) {
+        // fp32-class scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
+        const int np = planes_of(idx->precision);
         if (idx->q_cap < nq) {
-            if (idx->qhi) (void)hipFree(idx->qhi);
-            if (idx->qlo) (void)hipFree(idx->qlo);
-            idx->qhi = idx->qlo = nullptr;
+            for (int p = 0; p < 3; ++p) {
+                if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
+                idx->qpl[p] = nullptr;
+            }
             idx->q_cap = 0;
-            SR_CHECK_HIP(hipMalloc((void**)&idx->qhi, (size_t)nq * idx->dim * 2));
-            SR_CHECK_HIP(hipMalloc((void**)&idx->qlo, (size_t)nq * idx->dim * 2));
+            for (int p = 0; p < 3; ++p) SR_CHECK_HIP(hipMalloc((void**)&idx->qpl[p], (size_t)nq * idx->dim * 2));
             idx->q_cap = nq;
         }
-        SR_TRY(launch_split_bf16(d_queries, idx->qhi, idx->qlo, nq * (int64_t)idx->dim, s));
+        SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
         SR_TRY(idx->ws.ensure(nq, k, chunk));
         SR_TRY(topk_reset(idx->ws, nq, s));
         for (const DenseSegment& seg : idx->segs) {
             for (int64_t r0 = 0; r0 < seg.n; r0 += chunk) {
                 const int64_t r1 = r0 + chunk < seg.n ? r0 + chunk : seg.n;
                 DenseSplitArgs a;
-                a.Dhi = seg.hi; a.Dlo = seg.lo; a.Qhi = idx->qhi; a.Qlo = idx->qlo;
+                for (int p = 0; p < 3; ++p) { a.D[p] = seg.pl[p]; a.Q[p] = idx->qpl[p]; }
+                if (np == 2) {            // (d plane, q plane), smallest products first
+                    a.n_pairs = 3;
+                    const int pd[3] = {1, 0, 0}, pq[3] = {0, 1, 0};
+                    for (int i = 0; i < 3; ++i) { a.pair_d[i] = pd[i]; a.pair_q[i] = pq[i]; }
+                } else {
+                    a.n_pairs = 6;
+                    const int pd[6] = {2, 0, 1, 1, 0, 0}, pq[6] = {0, 2, 1, 0, 1, 0};
+                    for (int i = 0; i < 6; ++i) { a.pair_d[i] = pd[i]; a.pair_q[i] = pq[i]; }
+                }
                 a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
                 a.tau = idx->ws.tau; a.cand_keys = idx->ws.cand_keys; a.cand_count = idx->ws.cand_count;
                 a.cand_cap = idx->ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;

@@ -1,53 +1,59 @@
-// Dense scoring in "bf16x3" arithmetic: fp32-equivalent inner products on the bf16 MFMA pipe.
+// Dense scoring in split-bf16 arithmetic: fp32-class inner products on the bf16 MFMA pipe.
 //
-// Every fp32 operand is split x = hi + lo (+ O(2^-18 |x|)) into two bf16 numbers; then
-//     q . d  ~=  qh.dh + qh.dl + ql.dh           (the dropped ql.dl term is O(2^-18))
-// Products of bf16 pairs are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the
-// result differs from an fp32 dot product by ~1e-7 relative - the same size as the difference between
-// two fp32 summation orders (e.g. two BLAS libraries under faiss' IndexFlatIP, indexer.py:211) - while
-// running 3 bf16 MFMAs (2.5 PF peak) instead of 16x slower fp32 MFMAs (157 TF peak).
+// Every fp32 operand is split into bf16 planes, x = p0 + p1 (+ p2), each plane the bf16 rounding of what
+// the previous ones left over (the subtractions are exact in fp32):
+//   bf16x3:  q . d ~= q0.d0 + q0.d1 + q1.d0                        (dropped terms O(2^-17 |q||d|))
+//   bf16x6:  q . d ~= q0.d0 + q0.d1 + q1.d0 + q1.d1 + q0.d2 + q2.d0  (dropped terms O(2^-25): three planes carry
+//            the full 24-bit fp32 significand, so the result is in the error class of an fp32 dot product)
+// Products of bf16 pairs are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32.  The plane pairs are
+// accumulated smallest first.  3 (6) bf16 MFMAs at the 2.5 PF bf16 rate replace one fp32 MFMA at 157 TF.
 //
-// Implementation: one GEMM with a 3x longer k loop.  k-tile kt in [0, 3 H/64): plane = kt / (H/64);
-// the doc operand streams (Dhi, Dlo, Dhi)[plane], the query operand (Qhi, Qhi, Qlo)[plane].  Tile
-// 256 docs x 256 queries, 8 waves, LDS-DMA staging with source-side swizzle (as csrc/gemm_bf16.hip).
-// Docs sit on the accumulator registers and queries on the lanes, so the tau filter is lane-local and
-// survivors are appended as 64-bit keys exactly as in dense_score.hip.
+// Implementation: ONE GEMM with an n_pairs x longer k loop.  k-tile kt in [0, n_pairs * H/64): pair = kt / (H/64);
+// the doc operand streams D plane pair_d[pair], the query operand Q plane pair_q[pair].  Tile 256 docs x 256
+// queries, 8 waves, LDS-DMA staging with source-side swizzle and the 4-phase fragment pipeline of
+// csrc/gemm_bf16.hip.  Docs sit on the accumulator registers and queries on the lanes, so the tau filter is
+// lane-local and survivors are appended as 64-bit keys exactly as in dense_score.hip.
 #include "dense_split.h"
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 
-// ---- fp32 -> (hi, lo) bf16 planes ---------------------------------------------------------------
-__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                  int64_t n4) {
+// ---- fp32 -> bf16 planes ---------------------------------------------------------------------------
+__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ p0, unsigned short* __restrict__ p1,
+                                  unsigned short* __restrict__ p2, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    bf16x4 h, l;
+    bf16x4 a, b, c;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const unsigned short hb = f32_to_bf16(v[c]);
-        h[c] = (short)hb;
-        l[c] = (short)f32_to_bf16(v[c] - bf16_to_f32(hb));
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short h = f32_to_bf16(v[e]);
+        const float r1 = v[e] - bf16_to_f32(h);          // exact
+        const unsigned short m = f32_to_bf16(r1);
+        const float r2 = r1 - bf16_to_f32(m);            // exact
+        a[e] = (short)h;
+        b[e] = (short)m;
+        c[e] = (short)f32_to_bf16(r2);
     }
-    reinterpret_cast<bf16x4*>(hi)[i] = h;
-    reinterpret_cast<bf16x4*>(lo)[i] = l;
+    reinterpret_cast<bf16x4*>(p0)[i] = a;
+    reinterpret_cast<bf16x4*>(p1)[i] = b;
+    if (p2) reinterpret_cast<bf16x4*>(p2)[i] = c;
 }
 
-int launch_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, int64_t n_elems, hipStream_t s) {
+int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, unsigned short* p2, int64_t n_elems, hipStream_t s) {
     const int64_t n4 = n_elems / 4;
     if (n4 == 0) return SR_OK;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, src, hi, lo, n4);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, src, p0, p1, p2, n4);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
 
-// ---- scoring kernel ------------------------------------------------------------------------------
+// ---- scoring kernel ----------------------------------------------------------------------------------
 #define SP_BN 256   // docs per workgroup
 #define SP_BM 256   // queries per workgroup
 __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
-    constexpr int NB = 8, MB = 4, WAVES_M = 4;          // wave tile: 128 docs x 64 queries
+    constexpr int NB = 8, MB = 4, WAVES_M = 4, HB = NB / 2;   // wave tile: 128 docs x 64 queries
     constexpr int W_BYTES = SP_BN * 128, STAGE_BYTES = (SP_BN + SP_BM) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,9 +76,9 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     }
     const int nk = H / 64;
     auto stage = [&](int st, int kt) {
-        const int plane = kt / nk, k0 = (kt - plane * nk) * 64;
-        const unsigned short* dsrc = (plane == 1) ? a.Dlo : a.Dhi;
-        const unsigned short* qsrc = (plane == 2) ? a.Qlo : a.Qhi;
+        const int pair = kt / nk, k0 = (kt - pair * nk) * 64;
+        const unsigned short* dsrc = a.D[a.pair_d[pair]];
+        const unsigned short* qsrc = a.Q[a.pair_q[pair]];
         unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 4) * 1024;
         unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 4) * 1024;
 #pragma unroll
@@ -90,32 +96,54 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int nkt = 3 * nk;
+    const int nkt = a.n_pairs * nk;      // >= 3 * (H / 64) >= 3
+    mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
+    auto load_w = [&](int st, int kk, int h, mfma_bf16x8 (&wf)[HB]) {
+        const unsigned char* wt = smem + st * STAGE_BYTES;
+        const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+            wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + (h * HB + i) * 16 + frow) * 128 + pos);
+    };
+    auto load_a = [&](int st, int kk, mfma_bf16x8 (&af)[MB]) {
+        const unsigned char* at = smem + st * STAGE_BYTES + W_BYTES;
+        const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+            af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
+    };
+#define SR_MFMA_HALF(HH, WF, AF)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                        \
+            acc[(HH) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(HH) * HB + i][j], 0, 0, 0);
+
     stage(0, 0);
+    stage(1, 1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-        const unsigned char* wt = smem + cur * STAGE_BYTES;
-        const unsigned char* at = wt + W_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
-            mfma_bf16x8 wf[NB], af[MB];
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + i * 16 + frow) * 128 + pos);
-#pragma unroll
-            for (int j = 0; j < MB; ++j)
-                af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int j = 0; j < MB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-        }
+    int buf = 0;
+    load_w(buf, 0, 0, wx);
+    load_a(buf, 0, a0);
+    for (int kt = 0; kt < nkt; ++kt) {     // 4 phases per k-step, see gemm_bf16.hip
+        load_w(buf, 0, 1, wy);
+        SR_MFMA_HALF(0, wx, a0)
+        load_w(buf, 1, 0, wx);
+        load_a(buf, 1, a1);
+        SR_MFMA_HALF(1, wy, a0)
+        load_w(buf, 1, 1, wy);
+        SR_MFMA_HALF(0, wx, a1)
+        // The LDS-DMA of k-step kt + 1 was issued in the PREVIOUS iteration: hipcc does not see it as pending here and
+        // emits no vmcnt wait for this barrier, so drain it by hand (every wave its own pieces, then the barrier).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (kt + 2 < nkt) stage(buf, kt + 2);
+        if (kt + 1 < nkt) {
+            load_w(buf ^ 1, 0, 0, wx);
+            load_a(buf ^ 1, 0, a0);
+        }
+        SR_MFMA_HALF(1, wy, a1)
+        buf ^= 1;
     }
+#undef SR_MFMA_HALF
 
     // ---- epilogue: lane = query (frow + 16 j), registers = docs (16 i + 4 fg + r) --------------------
     const int64_t left = a.row_end - row0;
@@ -155,6 +183,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     const int64_t rows = a.row_end - a.row_begin;
     if (rows <= 0) return SR_OK;
     SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
+    SR_REQUIRE(a.n_pairs >= 3 && a.n_pairs <= 6, "dense_split: bad plane-pair count %d", a.n_pairs);
     constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128;
     static bool attr_set = false;
     if (!attr_set) {

@@ -154,6 +154,9 @@ void gemm_bf16_kernel(GemmArgs g) {
             SR_MFMA_HALF(1, wy, a0)
             load_w(buf, 1, 1, wy);
             SR_MFMA_HALF(0, wx, a1)
+            // The LDS-DMA of k-step kt + 1 was issued in the PREVIOUS iteration: hipcc does not see it as pending here and
+            // emits no vmcnt wait for this barrier, so drain it by hand (every wave its own pieces, then the barrier).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt + 2 < nk) {
                 stage(buf, (kt + 2) * G_BK);

@@ -61,7 +61,7 @@ class DenseIndexHIP:
 
     def set_precision(self, mode):
         """"fp32" (default, exact) or "bf16x3" (fp32-equivalent on the bf16 MFMA pipe, query batches > 64)."""
-        code = {"fp32": 0, "bf16x3": 1}[mode]
+        code = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}[mode]   # bf16x6: 3 planes, 6 products, fp32-class error
         _lib.check(self.lib.sr_dense_index_set_precision(self._h, code), "sr_dense_index_set_precision")
 
     def search(self, queries, k):

@@ -94,3 +94,22 @@ def test_attention_prerotated_inputs(nh, nkv, hd, lens):
     err = (out.float() - ref).norm() / ref.norm()
     assert err < 1e-2, err
     torch.testing.assert_close(out.float(), ref, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+def test_gemm_many_tiles_under_load(tile, monkeypatch):
+    """1024 output tiles of 256 x 256 (4 per persistent workgroup) with K = 2048: the software-pipelined k-loop and the
+    cross-tile prefetch only race when every CU streams (a single-tile case hides a missing LDS-DMA wait)."""
+    monkeypatch.setenv("SR_GEMM_TILE", tile)
+    L, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M = N = 8192
+    K = 2048
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    ref = A.float() @ W.float().T
+    for _ in range(3):
+        C = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert (C - ref).abs().max().item() < 1e-3
