@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -355,16 +356,49 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     return SR_OK;
 }
 
-// 256^2 tiles when they fill the chip about as well as 128^2 tiles would (one 256^2 workgroup per CU,
-// two 128^2 workgroups per CU): compare the two tilings' round quantisation.
-static bool prefer_big_tile(const GemmArgs& g) {
-    const char* env = getenv("SR_GEMM_TILE");   // test / A-B switch: 128 | 256 (read per call)
-    if (env && *env) return atoi(env) == 256;
-    const double t256 = (double)(ceil_div64(g.N, 256) * ceil_div64(g.M, 256));
-    const double t128 = (double)(ceil_div64(g.N, 128) * ceil_div64(g.M, 128));
-    const double eff256 = t256 / (ceil(t256 / 256.0) * 256.0);
-    const double eff128 = t128 / (ceil(t128 / 512.0) * 512.0);
-    return eff256 >= 0.9 * eff128 && t256 >= 128;
+// ---- tile plan --------------------------------------------------------------------------------------
+// Workgroups are persistent and take tiles round-robin, so a launch costs ceil(tiles / resident workgroups) rounds
+// and a last round that is mostly empty is paid in full (M = 9600 tokens x N = 2048: 304 tiles of 256^2 on 256 CUs = 2
+// rounds for 1.19 rounds of work).  The plan cuts the token rows once: rows [0, m_big) run as whole rounds of 256^2
+// tiles, the rest as 128^2 tiles (two resident per CU, a quarter of the work each).  Every output element is still
+// one k-ordered MFMA chain, so the result does not depend on the cut.
+// Costs in units of one 256^2 round, from tools/quick_gemm_bench.py (1120 vs 920 TFLOP/s at M = 38400): a full round
+// of 512 128^2 tiles is half the FLOPs of a 256^2 round at 1.22 x the time per FLOP; with at most one 128^2
+// workgroup per CU a round finishes sooner.
+static double plan_cost(int64_t big_tiles, int64_t small_tiles) {
+    double c = (double)ceil_div64(big_tiles, 256);
+    if (small_tiles > 0) {
+        const int64_t full = small_tiles / 512, rest = small_tiles % 512;
+        c += 0.61 * (double)full + (rest == 0 ? 0.0 : (rest <= 256 ? 0.45 : 0.61));
+        c += 0.03;                       // second launch
+    }
+    return c;
+}
+
+// rows of g.M handled with 256^2 tiles (0 = none, g.M = all)
+static int plan_big_rows(const GemmArgs& g, bool small_allowed) {
+    const char* env = getenv("SR_GEMM_TILE");   // test / A-B switch: 128 | 256 | split (read per call)
+    if (env && *env) {
+        if (atoi(env) == 256) return g.M;
+        if (atoi(env) == 128) return 0;
+        if (!strncmp(env, "split:", 6)) {          // split:<rows> forces the cut (tests)
+            const int rows = atoi(env + 6) / 256 * 256;
+            return rows < g.M ? rows : g.M;
+        }
+    }
+    if (!small_allowed) return g.M;
+    const int64_t tn256 = ceil_div64(g.N, 256), tn128 = ceil_div64(g.N, 128);
+    int best_rows = 0;
+    double best = plan_cost(0, tn128 * ceil_div64(g.M, 128));
+    if (tn256 * ceil_div64(g.M, 256) >= 128) {              // a handful of 256^2 tiles cannot fill the chip
+        const double all_big = plan_cost(tn256 * ceil_div64(g.M, 256), 0);
+        if (all_big <= best) { best = all_big; best_rows = g.M; }
+        for (int rows = 256; rows < g.M; rows += 256) {
+            const double c = plan_cost(tn256 * (rows / 256), tn128 * ceil_div64(g.M - rows, 128));
+            if (c < best - 1e-9) { best = c; best_rows = rows; }
+        }
+    }
+    return best_rows;
 }
 
 template <int EPI>
@@ -375,19 +409,45 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 }
 
 template <int EPI>
+static int launch_small(const GemmArgs& g, hipStream_t s) {
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
+    }
+    return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+}
+
+// the token rows [row0, M) of the same problem
+template <int EPI>
+static GemmArgs rows_from(const GemmArgs& g, int row0) {
+    GemmArgs t = g;
+    t.A = g.A + (int64_t)row0 * g.K;
+    t.M = g.M - row0;
+    const int64_t ldc = (EPI == EPI_SWIGLU) ? g.N / 2 : g.N;
+    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) ? 4 : 2;
+    if constexpr (EPI != EPI_SEGMAX) t.C = reinterpret_cast<unsigned char*>(g.C) + (int64_t)row0 * ldc * esz;
+    if (g.seq_of) t.seq_of = g.seq_of + row0;
+    if (g.pos) t.pos = g.pos + row0;
+    t.stamps = nullptr;
+    return t;
+}
+
+template <int EPI>
 static int launch_one(const GemmArgs& g, hipStream_t s) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
-        if (prefer_big_tile(g)) return launch_big<EPI>(g, s);       // wave covers 128 features
-        if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
-        return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+    }
+    if constexpr (EPI == EPI_SEGMAX) {
+        return launch_small<EPI>(g, s);          // the segmented max runs in the 128^2 tile's LDS
     } else {
-        if constexpr (EPI != EPI_SEGMAX) {
-            if (prefer_big_tile(g)) return launch_big<EPI>(g, s);
-        }
-        return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+        const int big_rows = plan_big_rows(g, true);
+        if (big_rows >= g.M) return launch_big<EPI>(g, s);
+        if (big_rows <= 0) return launch_small<EPI>(g, s);
+        GemmArgs head = g;
+        head.M = big_rows;
+        SR_TRY(launch_big<EPI>(head, s));
+        return launch_small<EPI>(rows_from<EPI>(g, big_rows), s);
     }
 }
 

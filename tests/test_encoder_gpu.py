@@ -389,12 +389,12 @@ def test_sparse_compact_matches_torch_nonzero():
     assert rc == L.SR_ERR_NOMEM and n.value == len(r)
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["128", "256", "split:512"])
 def test_gemm_both_tile_configs_all_epilogues(tile, monkeypatch):
-    """The 256 x 256 (8-wave) and 128 x 128 (4-wave) configurations of the GEMM template, forced through
-    the SR_GEMM_TILE switch, on ragged shapes."""
+    """The 256 x 256 (8-wave) and 128 x 128 (4-wave) configurations of the GEMM template and the row cut between them
+    (first 512 token rows on 256^2 tiles, the rest on 128^2), forced through the SR_GEMM_TILE switch, on ragged shapes."""
     monkeypatch.setenv("SR_GEMM_TILE", tile)
-    g = torch.Generator(device="cuda").manual_seed(int(tile))
+    g = torch.Generator(device="cuda").manual_seed(len(tile))
     M, N, K = 700, 800, 256
     A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
     W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
@@ -414,3 +414,17 @@ def test_gemm_both_tile_configs_all_epilogues(tile, monkeypatch):
     eye = torch.eye(K, device="cuda").bfloat16()
     Wa = (torch.arange(512 * K, device="cuda").reshape(512, K) % 251).float().bfloat16()
     assert torch.equal(_gemm(eye, Wa, 4), Wa.float().T.contiguous())
+
+
+def test_gemm_tile_plan_does_not_change_the_result(monkeypatch):
+    """Every output element is one k-ordered MFMA chain whatever tile computes it: the automatic plan (which cuts
+    9600 x 2048 into 8192 rows of 256^2 tiles + 1408 rows of 128^2 tiles) is bit-identical to either forced tiling."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    M, N, K = 9600, 2048, 1024
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    auto = _gemm(A, W, 4)
+    torch.testing.assert_close(auto, A.float() @ W.float().T, rtol=1e-4, atol=1e-4)
+    for tile in ("128", "256", "split:4096"):
+        monkeypatch.setenv("SR_GEMM_TILE", tile)
+        assert torch.equal(_gemm(A, W, 4), auto), tile

@@ -29,7 +29,7 @@ def _rotate(x, pos, cos, sin, hd):
     return x * c + rot * s
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["128", "256", "split:256"])
 @pytest.mark.parametrize("nh,nkv,hd,M,K", [(4, 1, 64, 333, 256), (2, 1, 128, 200, 128), (32, 8, 64, 130, 256)])
 def test_qkv_gemm_with_fused_rope(tile, nh, nkv, hd, M, K, monkeypatch):
     monkeypatch.setenv("SR_GEMM_TILE", tile)

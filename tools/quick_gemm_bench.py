@@ -1,4 +1,4 @@
-"""Ad-hoc GEMM timing (development aid): the four 1B-layer GEMM shapes at a given token count, tile x persist A/B."""
+"""Ad-hoc GEMM timing (development aid): the four 1B-layer GEMM shapes at a given token count, forced tilings vs the automatic tile plan."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,11 +20,11 @@ def run(M, N, K, epi, iters=20):
     return ms, 2.0 * M * N * K / ms / 1e9
 if __name__ == "__main__":
     Ms = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "9600,38400").split(",")]
-    shapes = [("qkv", 3072, 2048, 0), ("o", 2048, 2048, 1), ("gate_up", 16384, 2048, 2), ("down", 2048, 8192, 1)]
+    shapes = [("qkv", 3072, 2048, 0), ("o", 2048, 2048, 0), ("gate_up", 16384, 2048, 2), ("down", 2048, 8192, 0)]
     for M in Ms:
-        for tile in ("128", "256"):
-            for persist in ("0", "1"):
-                os.environ["SR_GEMM_TILE"] = tile; os.environ["SR_GEMM_PERSIST"] = persist
+        for tile in ("128", "256", "auto"):
+            for persist in ("1",):
+                os.environ["SR_GEMM_TILE"] = "" if tile == "auto" else tile; os.environ["SR_GEMM_PERSIST"] = persist
                 tot_ms, tot_fl, row = 0, 0, {}
                 for name, N, K, epi in shapes:
                     ms, tf = run(M, N, K, epi)
