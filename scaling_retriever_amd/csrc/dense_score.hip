@@ -162,6 +162,184 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void dense_score_kerne
     }
 }
 
+// ---- the same tile (256 docs x 256 queries, 8 waves, wave tile 128 x 64), software-pipelined ---------------------
+// In dense_score_kernel every k-step ends  MFMAs -> ds_write -> barrier -> ds_read -> MFMAs: both waves of a SIMD belong
+// to the same workgroup, reach the barrier together and then wait for their first fragments together, so the MFMA pipe
+// drains once per k-step (rocprofv3 PMC: waves parked 14 % of their cycles, MFMA busy 84 %).  Here three LDS stages make
+// the hand-offs a whole k-step old: during step kt the registers fetched two steps ahead are written to stage (kt + 2) % 3
+// (last read in step kt - 1), and the first fragments of step kt + 1 are read - from a stage made visible by the
+// PREVIOUS barrier - under the last MFMAs of step kt.  One barrier per k-step remains, with MFMAs issued right up to
+// it and right after it.  Same k order per accumulator as dense_score_kernel: bit-identical scores.
+__global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
+    constexpr int WAVES_N = 4, WM = 4, WN = 2, BK = 16;
+    constexpr int NT = 512, TM = 256, TN = 256, LDK = BK + 4, KC = BK / 4, NSTAGE = 3;
+    constexpr int PER_T = TM * KC / NT;                 // 16-B chunks per thread and operand tile (= 2)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [NSTAGE][TM][LDK]
+    float* Bs = smem + NSTAGE * TM * LDK;   // [NSTAGE][TN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * TM;
+    const int q0 = blockIdx.y * TN;
+    const int H = a.H;
+
+    // staging: thread t moves chunks t and t + 512 of each operand tile (row = chunk / 4, k-chunk = chunk % 4);
+    // rows past the end are clamped (their scores are never emitted)
+    const float* asrc[PER_T];
+    const float* bsrc[PER_T];
+    int soff[PER_T];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int c = tid + i * NT, r = c / KC, kc = c % KC;
+        int64_t row = row0 + r;
+        row = row < a.row_end ? row : a.row_end - 1;
+        int q = q0 + r;
+        q = q < a.nq ? q : a.nq - 1;
+        asrc[i] = a.D + row * H + kc * 4;
+        bsrc[i] = a.Q + (int64_t)q * H + kc * 4;
+        soff[i] = r * LDK + kc * 4;
+    }
+    f32x4 ra[PER_T], rb[PER_T];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) ra[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+    };
+    auto sstore = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&As[st * TM * LDK + soff[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&Bs[st * TN * LDK + soff[i]]) = rb[i];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int aoff = (wm * WM * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    const int boff = (wn * WN * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    auto frag = [&](int st, int sub, f32x4 (&af)[WM], f32x4 (&bf)[WN]) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m) af[m] = *reinterpret_cast<const f32x4*>(&As[st * TM * LDK + aoff + m * 32 * LDK + 8 * sub]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) bf[n] = *reinterpret_cast<const f32x4*>(&Bs[st * TN * LDK + boff + n * 32 * LDK + 8 * sub]);
+    };
+#define SR_DENSE_MFMAS(AF, BF)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+        _Pragma("unroll") for (int m = 0; m < WM; ++m)                                                           \
+            _Pragma("unroll") for (int n = 0; n < WN; ++n)                                                       \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[m][j], BF[n][j], acc[m][n], 0, 0, 0);
+
+    const int nk = H / BK;
+    gload(0);
+    sstore(0);
+    gload(nk > 1 ? BK : 0);
+    sstore(1);
+    gload(nk > 2 ? 2 * BK : 0);
+    __syncthreads();
+    f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
+    frag(0, 0, a0, b0);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st1 = st == NSTAGE - 1 ? 0 : st + 1;
+        const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;
+        // branch-free body (a branch makes hipcc wait for ALL outstanding LDS reads at the join): past the last k-steps
+        // the extra stage writes / fragment reads / re-loads of the last k-block touch valid memory and are never used
+        // Issue order inside a half (sched_group_barrier): the half's MFMAs start at once and its LDS / global operations are
+        // dealt out between them, two MFMAs (128 cycles of pipe time) apart, so nothing queues up in front of the MFMA pipe
+        // after the barrier.  First half: fragment reads of the second half, stage write of k-step kt + 2, global loads of
+        // k-step kt + 3 (a whole k-step ahead of the write that consumes them).  Second half: first fragments of k-step kt + 1.
+        frag(st, 1, a1, b1);
+        sstore(st2);
+        gload(kt + 3 < nk ? (kt + 3) * BK : H - BK);
+        SR_DENSE_MFMAS(a0, b0)
+#pragma unroll
+        for (int i = 0; i < WM + WN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * PER_T; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // 1 DS write
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * PER_T; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * (WM + WN + 4 * PER_T), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(st1, 0, a0, b0);
+        SR_DENSE_MFMAS(a1, b1)
+#pragma unroll
+        for (int i = 0; i < WM + WN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * (WM + WN), 1);
+        __builtin_amdgcn_sched_barrier(0);      // the barrier (and its lgkmcnt(0)) after the MFMAs that cover the reads
+        __syncthreads();
+        st = st1;
+    }
+#undef SR_DENSE_MFMAS
+
+    // ---- epilogue: lane-local tau filter, append survivors (as dense_score_kernel) -------------------
+    const int half = lane >> 5;
+    const int64_t left = a.row_end - row0;
+    const int rows_valid = left < TM ? (int)left : TM;
+    const int lr0 = wm * WM * 32 + 4 * half;
+    const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int q = q0 + wn * WN * 32 + n * 32 + (lane & 31);
+        if (q >= a.nq) continue;
+        const float tq = a.tau[q];
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = lr0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                cnt += (lr < rows_valid && acc[m][n][r] >= tq) ? 1 : 0;
+            }
+        if (cnt == 0) continue;
+        int pos = atomicAdd(&a.cand_count[q], cnt);
+        uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = lr0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                const float sc = acc[m][n][r];
+                if (lr < rows_valid && sc >= tq) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
+                    ++pos;
+                }
+            }
+    }
+}
+
+static int launch_dense_pipe(const DenseArgs& a, int64_t rows, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 3 * (256 + 256) * (16 + 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div64(rows, 256), (unsigned)ceil_div64(a.nq, 256));
+    hipLaunchKernelGGL(dense_score_pipe_kernel, grid, dim3(512), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 // --------------------------------------------------------------------- host ---
 struct DenseSegment {
     const float* rows;
@@ -291,8 +469,8 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
     int TN;
-    static const char* env_variant = getenv("SR_DENSE_VARIANT");   // development A/B switch
-    const int variant = env_variant ? atoi(env_variant) : 1;
+    const char* env_variant = getenv("SR_DENSE_VARIANT");   // A/B switch, read per call: 5 = pipelined kernel (default), 1 = plain double buffer
+    const int variant = env_variant ? atoi(env_variant) : 5;
     if (nq > 128) { cfg = 0; TN = (variant == 4) ? 128 : 256; }
     else if (nq > 64) { cfg = 1; TN = 128; }
     else if (nq > 32) { cfg = 2; TN = 64; }
@@ -404,6 +582,7 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
                     else if (variant == 1) SR_TRY((launch_dense<2, 4, 4, 2>(a, r1 - r0, s)));
                     else if (variant == 2) SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
                     else if (variant == 3) SR_TRY((launch_dense<4, 4, 2, 2>(a, r1 - r0, s)));
+                    else if (variant == 5) SR_TRY(launch_dense_pipe(a, r1 - r0, s));
                     else SR_TRY((launch_dense<4, 2, 2, 2, 16, 4>(a, r1 - r0, s)));   // 256 x 128 tile, 2 workgroups per CU
                     break;
                 case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;

@@ -268,3 +268,20 @@ def test_topk_merge_equals_global_topk():
         keep = ci >= 0
         o = np.lexsort((ci[keep], -cs[keep].astype(np.float64)))[:k]
         assert np.array_equal(i[q], ci[keep][o]) and np.array_equal(s[q], cs[keep][o])
+
+
+@pytest.mark.parametrize("nq,n,h,k", [(300, 70001, 256, 100), (700, 33000, 2048, 1000), (129, 513, 64, 10)])
+def test_dense_pipelined_kernel_equals_plain_kernel(nq, n, h, k, monkeypatch):
+    """The default score kernel for nq > 128 (three LDS stages, fragment prefetch across the barrier, memory operations
+    dealt out between the MFMAs) accumulates every score in the same k order as the plain double-buffered kernel:
+    ids and fp32 scores are bit-identical, ragged tiles included."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    g = torch.Generator(device="cuda").manual_seed(nq + n + h)
+    D = torch.randn((n, h), device="cuda", generator=g)
+    Q = torch.randn((nq, h), device="cuda", generator=g)
+    idx = DenseIndexHIP(h)
+    idx.add_device_rows(D)
+    s5, i5 = idx.search(Q, k)
+    monkeypatch.setenv("SR_DENSE_VARIANT", "1")
+    s1, i1 = idx.search(Q, k)
+    assert torch.equal(s1, s5) and torch.equal(i1, i5)
