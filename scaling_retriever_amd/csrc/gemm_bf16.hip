@@ -147,7 +147,49 @@ void gemm_bf16_kernel(GemmArgs g) {
                 acc[(H) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(H) * HB + i][j], 0, 0, 0);
         load_w(buf, 0, 0, wx);
         load_a(buf, 0, a0);
-        for (int kt = 0; kt < nk; ++kt) {
+        int kt = 0;
+        // Steady state (all but the last two k-steps): branch-free body with the issue order pinned - each phase's MFMAs
+        // start at once and its LDS reads / LDS-DMA pieces are dealt out one per MFMA, so a read has the rest of its phase
+        // (and the partner wave's MFMAs) to land before the next phase consumes it.  Left to itself hipcc sinks the reads
+        // to just before their first use and waits for them there.
+#define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
+        for (; kt + 2 < nk; ++kt) {
+            // reads per phase: 8 (wy, a1) / 4 (wx) / 4 (wy) / 8 (wx, a0 of the next k-step) + the 8 LDS-DMA pieces;
+            // a1 is dead from the previous k-step's last phase on, so it is fetched two phases before its first use
+            load_w(buf, 0, 1, wy);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(0, wx, a0)
+#pragma unroll
+            for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 0); SR_SGB(0x100, 1, 0); }
+            SR_SGB(0x008, HB * MB - HB - MB, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 0, wx);
+            SR_MFMA_HALF(1, wy, a0)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 1); SR_SGB(0x100, 1, 1); }
+            SR_SGB(0x008, HB * MB - HB, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 2); SR_SGB(0x100, 1, 2); }
+            SR_SGB(0x008, HB * MB - HB, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA of k-step kt + 1 (see below)
+            __syncthreads();
+            load_w(buf ^ 1, 0, 0, wx);
+            load_a(buf ^ 1, 0, a0);
+            stage(buf, (kt + 2) * G_BK);
+            SR_MFMA_HALF(1, wy, a1)
+#pragma unroll
+            for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x100, 1, 3); }
+#pragma unroll
+            for (int i = 0; i < W_INSTR + A_INSTR; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x010, 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+#undef SR_SGB
+        for (; kt < nk; ++kt) {
             load_w(buf, 0, 1, wy);
             SR_MFMA_HALF(0, wx, a0)
             load_w(buf, 1, 0, wx);
