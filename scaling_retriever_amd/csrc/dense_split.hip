@@ -123,7 +123,44 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     int buf = 0;
     load_w(buf, 0, 0, wx);
     load_a(buf, 0, a0);
-    for (int kt = 0; kt < nkt; ++kt) {     // 4 phases per k-step, see gemm_bf16.hip
+    int kt = 0;
+    // steady state with the issue order pinned (see gemm_bf16.hip): reads and LDS-DMA pieces dealt out one per MFMA
+#define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
+    for (; kt + 2 < nkt; ++kt) {
+        load_w(buf, 0, 1, wy);
+        load_a(buf, 1, a1);
+        SR_MFMA_HALF(0, wx, a0)
+#pragma unroll
+        for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 0); SR_SGB(0x100, 1, 0); }
+        SR_SGB(0x008, HB * MB - HB - MB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(buf, 1, 0, wx);
+        SR_MFMA_HALF(1, wy, a0)
+#pragma unroll
+        for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 1); SR_SGB(0x100, 1, 1); }
+        SR_SGB(0x008, HB * MB - HB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(buf, 1, 1, wy);
+        SR_MFMA_HALF(0, wx, a1)
+#pragma unroll
+        for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 2); SR_SGB(0x100, 1, 2); }
+        SR_SGB(0x008, HB * MB - HB, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_w(buf ^ 1, 0, 0, wx);
+        load_a(buf ^ 1, 0, a0);
+        stage(buf, kt + 2);
+        SR_MFMA_HALF(1, wy, a1)
+#pragma unroll
+        for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x100, 1, 3); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x010, 1, 3); }
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+    }
+#undef SR_SGB
+    for (; kt < nkt; ++kt) {     // last two k-steps: 4 phases per k-step, see gemm_bf16.hip
         load_w(buf, 0, 1, wy);
         SR_MFMA_HALF(0, wx, a0)
         load_w(buf, 1, 0, wx);
