@@ -185,10 +185,10 @@ def main():
         shape = pmc["dense_score_launch"]
         docs_per_launch = fl.value / max(1, n_l.value) / (2.0 * args.n_queries * H)
         if shape["nq"] == args.n_queries and shape["dim"] == H and abs(docs_per_launch / shape["docs_per_launch"] - 1) < 0.02:
-            traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("dense_score_kernel")][0]
+            traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("dense_score_pipe_kernel")][0]
     except Exception:
         traffic = None
-    roofline = {"kernel": "dense_score_kernel<2,4,4,2> (fp32 MFMA 32x32x2, 256 docs x 256 queries per workgroup, 8 waves)",
+    roofline = {"kernel": "dense_score_pipe_kernel (fp32 MFMA 32x32x2, 256 docs x 256 queries per workgroup, 8 waves, 3 LDS stages)",
                 "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                 "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4),
