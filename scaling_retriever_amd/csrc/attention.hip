@@ -252,16 +252,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // Fast path for sequences of at most 256 tokens (every MS MARCO batch: doc_max_length 192,
-// query_max_length 64) with q/k already rotated by the QKV GEMM epilogue: K and V^T are staged
-// once, every wave walks its (q head, 32-row q tile) items with ALL score blocks of the row held in
-// registers - one QK^T pass, exact softmax, no rescaling, no restaging.
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attention_small_kernel(AttnArgs a) {
-    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = AT_KC / 32;
+// query_max_length 64) with q/k already rotated by the QKV GEMM epilogue.  A workgroup = (sequence, kv head, group of
+// 4 work items); a work item = (q head of the group, 32-row q tile), one per wave, with ALL score blocks of the row held
+// in registers - one QK^T pass, exact softmax, no rescaling.  Work per sequence grows with S^2, so the items of a long
+// sequence are spread over several workgroups (each stages K and V^T of the sequence again - a few KB from L2) instead
+// of one workgroup walking them while the rest of the chip has finished.  MAXKB = key blocks (of 32) the batch needs:
+// it sizes the LDS image and the score registers, so short batches run at higher occupancy.
+template <int HD, int MAXKB>
+__global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void attention_small_kernel(AttnArgs a) {
+    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, KC = MAXKB * 32, VT_LD = KC + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vt = Ks + AT_KC * HD;
-    unsigned char* kval = reinterpret_cast<unsigned char*>(Vt + HD * AT_VT_LD);
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [KC][HD], chunk-swizzled
+    bf16_t* Vt = Ks + KC * HD;                          // [HD][VT_LD]
+    unsigned char* kval = reinterpret_cast<unsigned char*>(Vt + HD * VT_LD);
 
     const int b = blockIdx.x, kvh = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,10 +272,11 @@ __global__ __launch_bounds__(256, 2) void attention_small_kernel(AttnArgs a) {
     const int S = a.cu_seqlens[b + 1] - t0;
     if (S <= 0) return;
     const int G = a.nh / a.nkv;
+    const int n_qt = (S + 31) / 32, n_items = G * n_qt, nkb = n_qt;
+    if ((int)blockIdx.z * 4 >= n_items) return;          // this sequence has fewer item groups than the longest one
     const int ldq = (a.nh + 2 * a.nkv) * HD;
     const int koff = a.nh * HD + kvh * HD;
     const int voff = (a.nh + a.nkv) * HD + kvh * HD;
-    const int n_qt = (S + 31) / 32, n_items = G * n_qt, nkb = n_qt;
     const float sc_log2 = a.scale * 1.4426950408889634f;
     const int r = lane & 31, h = lane >> 5;
 
@@ -288,12 +292,14 @@ __global__ __launch_bounds__(256, 2) void attention_small_kernel(AttnArgs a) {
         }
         *reinterpret_cast<uint4*>(Ks + key * HD + ((c ^ (key & 7)) * 8)) = kx;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * AT_VT_LD + key] = vx.u[j];
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VT_LD + key] = vx.u[j];
     }
     for (int key = tid; key < nkb * 32; key += 256) kval[key] = (key < S) ? a.key_valid[t0 + key] : 0;
     __syncthreads();
 
-    for (int item = wave; item < n_items; item += 4) {
+    const int item = (int)blockIdx.z * 4 + wave;
+    if (item >= n_items) return;
+    {
         const int qh = kvh * G + item / n_qt;
         const int q0 = (item % n_qt) * 32;
         int qrow = q0 + r;
@@ -361,22 +367,46 @@ __global__ __launch_bounds__(256, 2) void attention_small_kernel(AttnArgs a) {
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) {
                         Frag8 vf;
-                        const bf16_t* vp = Vt + (db * 32 + r) * AT_VT_LD + kb * 32 + 16 * s2 + 4 * h;
+                        const bf16_t* vp = Vt + (db * 32 + r) * VT_LD + kb * 32 + 16 * s2 + 4 * h;
                         vf.d2[0] = *reinterpret_cast<const uint2*>(vp);
                         vf.d2[1] = *reinterpret_cast<const uint2*>(vp + 8);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.v, vf.v, o[db], 0, 0, 0);
+                        // V^T as the A operand: the result is O^T (rows = head dims, column = this lane's q row), so a lane
+                        // ends up with 4 consecutive head dims per register group and stores 8 B at a time
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
                     }
                 }
             }
         }
+        if (q0 + r < S) {
+            bf16_t* orow = a.out + (int64_t)(t0 + q0 + r) * (a.nh * HD) + qh * HD + 4 * h;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                const int qr = q0 + (x & 3) + 8 * (x >> 2) + 4 * h;
-                if (qr < S) a.out[(int64_t)(t0 + qr) * (a.nh * HD) + qh * HD + db * 32 + r] = f32_to_bf16(o[db][x]);
-            }
+                for (int gq = 0; gq < 4; ++gq) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (short)f32_to_bf16(o[db][4 * gq + e]);
+                    *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * gq) = v;
+                }
+        }
     }
+}
+
+template <int HD, int MAXKB>
+static int launch_small(const AttnArgs& a, hipStream_t s) {
+    constexpr int KC = MAXKB * 32;
+    constexpr size_t lds = (size_t)KC * HD * 2 + (size_t)HD * (KC + 4) * 2 + KC;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<HD, MAXKB>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
+    const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 3) / 4));
+    hipLaunchKernelGGL((attention_small_kernel<HD, MAXKB>), grid, dim3(256), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
 }
 
 template <int HD>
@@ -388,13 +418,16 @@ static int launch_hd(const AttnArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<HD>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
+    }
+    if (!a.apply_rope && a.max_seqlen > 0 && a.max_seqlen <= AT_KC) {
+        if (a.max_seqlen <= 64) return launch_small<HD, 2>(a, s);
+        if (a.max_seqlen <= 128) return launch_small<HD, 4>(a, s);
+        if (a.max_seqlen <= 192) return launch_small<HD, 6>(a, s);
+        return launch_small<HD, 8>(a, s);
     }
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv);
     if (a.apply_rope) hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), lds, s, a);
-    else if (a.max_seqlen > 0 && a.max_seqlen <= AT_KC) hipLaunchKernelGGL((attention_small_kernel<HD>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;

@@ -110,6 +110,9 @@ __global__ void plan_tokens_kernel(const int64_t* __restrict__ ids, const int64_
 //                                     reference's autocast nn.Linear returns bf16, which is then added to the fp32
 //                                     residual stream; doing the add here keeps the GEMM epilogue at 2 B per element)
 // xn[t] = bf16( x * rsqrt(mean(x^2) + eps) * w )
+// NCH > 0: H == 256 * NCH and the row stays in registers between the two passes (all its loads in flight at once, no
+// re-read of the freshly written row); NCH == 0: any H % 4 == 0, second pass re-reads the row.  Same arithmetic order.
+template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ embed,
                                                       const int* __restrict__ tok_id, const bf16_t* __restrict__ delta,
                                                       const float* __restrict__ w, bf16_t* __restrict__ xn,
@@ -121,33 +124,90 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
     const float* src = embed ? embed + (int64_t)tok_id[t] * H : xr;
     const bf16_t* dr = delta ? delta + (int64_t)t * H : nullptr;
     float ss = 0.f;
-    for (int i = lane * 4; i < H; i += 256) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+    if constexpr (NCH > 0) {
+        f32x4 v[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const f32x4*>(src + lane * 4 + c * 256);
         if (dr) {
-            const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + i);
+            bf16x4 d[NCH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += bf16_to_f32((unsigned short)d[c]);
+            for (int c = 0; c < NCH; ++c) d[c] = *reinterpret_cast<const bf16x4*>(dr + lane * 4 + c * 256);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] += bf16_to_f32((unsigned short)d[c][e]);
         }
-        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        if (embed || dr) *reinterpret_cast<f32x4*>(xr + i) = v;
-    }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
-    if (!w) return;   // residual add only
-    for (int i = lane * 4; i < H; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);   // this lane's own writes (or the unchanged row)
-        const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
-        f32x4 y;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = (v[c] * rs) * g[c];
-        if (xn) {
-            bf16x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = (short)f32_to_bf16(y[c]);
-            *reinterpret_cast<bf16x4*>(xn + (int64_t)t * H + i) = o;
+        for (int c = 0; c < NCH; ++c) {
+            ss += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
+            if (embed || dr) *reinterpret_cast<f32x4*>(xr + lane * 4 + c * 256) = v[c];
         }
-        if (xn_f32) *reinterpret_cast<f32x4*>(xn_f32 + (int64_t)t * H + i) = y;
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+        if (!w) return;   // residual add only
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = lane * 4 + c * 256;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[c][e] * rs) * g[e];
+            if (xn) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (short)f32_to_bf16(y[e]);
+                *reinterpret_cast<bf16x4*>(xn + (int64_t)t * H + i) = o;
+            }
+            if (xn_f32) *reinterpret_cast<f32x4*>(xn_f32 + (int64_t)t * H + i) = y;
+        }
+    } else {
+        for (int i = lane * 4; i < H; i += 256) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            if (dr) {
+                const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + i);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += bf16_to_f32((unsigned short)d[c]);
+            }
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            if (embed || dr) *reinterpret_cast<f32x4*>(xr + i) = v;
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+        if (!w) return;   // residual add only
+        for (int i = lane * 4; i < H; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);   // this lane's own writes (or the unchanged row)
+            const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = (v[c] * rs) * g[c];
+            if (xn) {
+                bf16x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (short)f32_to_bf16(y[c]);
+                *reinterpret_cast<bf16x4*>(xn + (int64_t)t * H + i) = o;
+            }
+            if (xn_f32) *reinterpret_cast<f32x4*>(xn_f32 + (int64_t)t * H + i) = y;
+        }
     }
+}
+
+static int launch_rmsnorm(float* x, const float* embed, const int* tok_id, const bf16_t* delta, const float* w, bf16_t* xn,
+                          float* xn_f32, int T, int H, float eps, hipStream_t s) {
+    if (T == 0) return SR_OK;
+    const dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
+#define SR_RMS(NCH) hipLaunchKernelGGL(rmsnorm_kernel<NCH>, grid, block, 0, s, x, embed, tok_id, delta, w, xn, xn_f32, T, H, eps)
+    switch (H) {
+        case 256: SR_RMS(1); break;
+        case 512: SR_RMS(2); break;
+        case 1024: SR_RMS(4); break;
+        case 2048: SR_RMS(8); break;
+        case 3072: SR_RMS(12); break;
+        case 4096: SR_RMS(16); break;
+        default: SR_RMS(0); break;
+    }
+#undef SR_RMS
+    SR_CHECK_LAUNCH();
+    return SR_OK;
 }
 
 // ---- dense head: final RMSNorm -> per-token L2 normalise -> mean over pooled tokens -----
@@ -549,18 +609,15 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
                        m->pos, m->key_valid, m->seq_of, c.vocab_size, mode);
     SR_CHECK_LAUNCH();
 
-    const unsigned nblk = (unsigned)ceil_div64(T, 4);
     // embedding gather fused with the first input_layernorm
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, m->embed, m->tok_id, (const bf16_t*)nullptr, m->layers[0].ln1, m->xn,
-                       (float*)nullptr, T, H, c.rms_norm_eps);
-    SR_CHECK_LAUNCH();
+    SR_TRY(launch_rmsnorm(m->x, m->embed, m->tok_id, (const bf16_t*)nullptr, m->layers[0].ln1, m->xn,
+                       (float*)nullptr, T, H, c.rms_norm_eps, s));
     for (int li = 0; li < c.num_layers; ++li) {
         LayerW& l = m->layers[li];
         if (li > 0) {
             // adds the previous layer's down_proj output, then input_layernorm
-            hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
-                               (const bf16_t*)m->delta, l.ln1, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
-            SR_CHECK_LAUNCH();
+            SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr, (const int*)nullptr,
+                               (const bf16_t*)m->delta, l.ln1, m->xn, (float*)nullptr, T, H, c.rms_norm_eps, s));
         }
         GemmArgs g{};
         g.A = m->xn; g.W = l.wqkv; g.M = T; g.N = nq + 2 * nkv; g.K = H; g.C = m->qkv;
@@ -576,9 +633,8 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         g.A = m->attn; g.W = l.wo; g.M = T; g.N = H; g.K = nq; g.C = m->delta;
         SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));
         // x += o_proj output, then post_attention_layernorm
-        hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
-                           (const bf16_t*)m->delta, l.ln2, m->xn, (float*)nullptr, T, H, c.rms_norm_eps);
-        SR_CHECK_LAUNCH();
+        SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr, (const int*)nullptr,
+                           (const bf16_t*)m->delta, l.ln2, m->xn, (float*)nullptr, T, H, c.rms_norm_eps, s));
         g = GemmArgs{};
         g.A = m->xn; g.W = l.wgu; g.M = T; g.N = 2 * I; g.K = H; g.C = m->act;
         SR_TRY(launch_gemm_bf16(EPI_SWIGLU, g, s));
@@ -587,9 +643,8 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         SR_TRY(launch_gemm_bf16(EPI_STORE_BF16, g, s));   // added to x by the next norm kernel (or the head)
     }
     // fold the last down_proj output into the residual stream so that the heads see the complete hidden state
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(nblk), dim3(256), 0, s, m->x, (const float*)nullptr, (const int*)nullptr,
-                       (const bf16_t*)m->delta, (const float*)nullptr, (bf16_t*)nullptr, (float*)nullptr, T, H, c.rms_norm_eps);
-    SR_CHECK_LAUNCH();
+    SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr, (const int*)nullptr,
+                       (const bf16_t*)m->delta, (const float*)nullptr, (bf16_t*)nullptr, (float*)nullptr, T, H, c.rms_norm_eps, s));
     return SR_OK;
 }
 
@@ -620,9 +675,8 @@ extern "C" int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const i
     SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, s, &T));
     const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
     // final norm -> bf16 GEMM input
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
-                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps);
-    SR_CHECK_LAUNCH();
+    SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr,
+                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps, s));
     SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
     GemmArgs g{};
     g.A = m->xn; g.W = m->lm_head; g.M = T; g.N = V; g.K = H; g.C = d_out; g.seq_of = m->seq_of; g.out_ld = V;
@@ -643,9 +697,8 @@ extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_
     *n_tokens = T;
     SR_REQUIRE(capacity_rows >= T, "sr_model_last_hidden: capacity %lld < %d tokens", (long long)capacity_rows, T);
     if (T == 0) return SR_OK;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
-                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, (bf16_t*)nullptr, d_out, T, m->cfg.hidden_size, m->cfg.rms_norm_eps);
-    SR_CHECK_LAUNCH();
+    SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr,
+                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, (bf16_t*)nullptr, d_out, T, m->cfg.hidden_size, m->cfg.rms_norm_eps, s));
     return SR_OK;
 }
 
