@@ -390,7 +390,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     }
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
     const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
-    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? 2 : 1);   // resident workgroups on 256 CUs
+    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (BM <= 64 ? 3 : 2) : 1);   // resident workgroups on 256 CUs
     if (!(env && *env == '0') && tiles > slots) tiles = slots;
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
@@ -454,6 +454,13 @@ template <int EPI>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
+    }
+    if constexpr (EPI != EPI_SEGMAX && EPI != EPI_QKV_ROPE) {
+        // few 128^2 tiles (a short tail behind the 256^2 rounds, or a small problem): halve the token tile so that two or
+        // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
+        const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
+        const char* e = getenv("SR_GEMM_TAIL64");
+        if (t128 < 384 && g.M > 64 && !(e && *e == '0')) return launch_cfg<EPI, 2, 2, 4, 2>(g, s);
     }
     return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
 }
