@@ -16,7 +16,10 @@
 #include <mutex>
 
 #define SP_TILE 8192
-#define SP_TERMS 256  // query terms staged per batch
+#define SP_TERMS 64   // query terms staged per batch (one wave builds the batch's work list)
+#define SP_U 4        // postings per thread and group
+#define SP_GROUP (SP_U * 256)                              // postings per group
+#define SP_MAXG (SP_TERMS * (SP_TILE / SP_GROUP))          // groups per batch of terms, worst case
 
 struct SparseArgs {
     const int64_t* indptr;
@@ -38,12 +41,19 @@ struct SparseArgs {
     uint32_t id_base, id_stride;
 };
 
+// The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term (work list in
+// LDS, built by wave 0 from the skip table).  The groups are walked in term order with the loads of group i + 1 (8 per
+// thread, clamped so that they are always issued) in flight while group i is applied to the LDS score tile, and the
+// barrier - an s_barrier behind lgkmcnt(0) only, so that it does not drain those loads - is taken only after the last
+// group of a term: postings of one term never share a doc, terms do.  Same per-doc addition order as before.
 __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 #pragma clang fp contract(off)
     __shared__ float sc[SP_TILE];
     __shared__ int64_t seg_b[SP_TERMS];
     __shared__ int seg_n[SP_TERMS];
     __shared__ float seg_w[SP_TERMS];
+    __shared__ int glist[SP_MAXG];             // term | group << 8 | last-group-of-term << 16
+    __shared__ int s_ng;
     __shared__ int wave_tot[4];
     __shared__ int s_base;
 
@@ -56,30 +66,82 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 
     for (int d = tid; d < SP_TILE; d += 256) sc[d] = 0.f;
 
+    auto load_group = [&](int e, bool live, int (&dd)[SP_U], float (&vv)[SP_U], float& w, unsigned& ok) {
+        ok = 0;
+        const int j = e & 255, g = (e >> 8) & 255;
+        const int64_t b = seg_b[j];
+        const int n = seg_n[j];              // >= 1 for every listed group
+        w = seg_w[j];
+#pragma unroll
+        for (int u = 0; u < SP_U; ++u) {
+            const int p = (g * SP_U + u) * 256 + tid;
+            const int pc = p < n ? p : n - 1;
+            dd[u] = a.doc_ids[b + pc];       // raw: nothing may depend on the loaded values before apply_group
+            vv[u] = a.vals[b + pc];
+            ok |= (live && p < n) ? (1u << u) : 0u;
+        }
+    };
+
     const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
     for (int64_t t0 = tb; t0 < te; t0 += SP_TERMS) {
         const int nt = (int)((te - t0) < SP_TERMS ? (te - t0) : SP_TERMS);
         __syncthreads();  // previous batch fully applied (also covers the zero fill)
-        if (tid < nt) {
-            const int term = a.q_cols[t0 + tid];
-            const int32_t* sk = a.skip + (int64_t)term * (a.n_tiles + 1) + tile;
-            const int b = sk[0], e = sk[1];
-            seg_b[tid] = a.indptr[term] + b;
-            seg_n[tid] = e - b;
-            seg_w[tid] = a.q_vals[t0 + tid];
+        if (tid < 64) {
+            int n = 0;
+            if (tid < nt) {
+                const int term = a.q_cols[t0 + tid];
+                const int32_t* sk = a.skip + (int64_t)term * (a.n_tiles + 1) + tile;
+                const int b = sk[0], e = sk[1];
+                n = e - b;
+                seg_b[tid] = a.indptr[term] + b;
+                seg_n[tid] = n;
+                seg_w[tid] = a.q_vals[t0 + tid];
+            }
+            const int ngr = (n + SP_GROUP - 1) / SP_GROUP;
+            int incl = ngr;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (tid >= off) incl += o;
+            }
+            const int pre = incl - ngr;
+            for (int g = 0; g < ngr; ++g) glist[pre + g] = tid | (g << 8) | ((g == ngr - 1) ? (1 << 16) : 0);
+            if (tid == 63) s_ng = incl;
         }
         __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            const int n = seg_n[j];
-            if (n == 0) continue;  // uniform: nothing written, no barrier needed
-            const int64_t b = seg_b[j];
-            const float w = seg_w[j];
-            for (int p = tid; p < n; p += 256) {
-                const int d = a.doc_ids[b + p] - (int)doc0;
-                const float prod = w * a.vals[b + p];
-                sc[d] = sc[d] + prod;  // doc ids are unique inside one posting list
+        const int ng = s_ng;
+        if (ng == 0) continue;
+        int dA[SP_U], dB[SP_U];
+        float vA[SP_U], vB[SP_U], wA, wB;
+        auto apply_group = [&](const int (&dd)[SP_U], const float (&vv)[SP_U], float w, unsigned ok, int e) {
+            // doc ids are unique inside one posting list: the group's reads can all be in flight before its writes
+            int d[SP_U];
+            float cur[SP_U];
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                d[u] = (ok & (1u << u)) ? dd[u] - (int)doc0 : 0;
+                cur[u] = sc[d[u]];
             }
-            __syncthreads();  // term-serial: next term may touch the same docs
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u)
+                if (ok & (1u << u)) {
+                    const float prod = w * vv[u];
+                    sc[d[u]] = cur[u] + prod;
+                }
+            if (e & (1 << 16))   // term-serial: the next term may touch the same docs
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // two groups per trip, the register sets swapping roles (a copy would have to wait for the loads it copies)
+        int eA = glist[0], eB;
+        unsigned okA, okB;
+        load_group(eA, true, dA, vA, wA, okA);
+        for (int i = 0; i < ng; i += 2) {
+            eB = glist[i + 1 < ng ? i + 1 : i];
+            load_group(eB, i + 1 < ng, dB, vB, wB, okB);
+            apply_group(dA, vA, wA, okA, eA);
+            if (i + 1 >= ng) break;
+            eA = glist[i + 2 < ng ? i + 2 : i + 1];
+            load_group(eA, i + 2 < ng, dA, vA, wA, okA);
+            apply_group(dB, vB, wB, okB, eB);
         }
     }
     __syncthreads();
