@@ -44,7 +44,7 @@ void gemm_bf16_kernel(GemmArgs g) {
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     const int n_tiles = tiles_n * tiles_m;
     const int K = g.K;
-    constexpr bool CROSS_PREFETCH = (EPI != EPI_SEGMAX);   // the segmented-max epilogue reuses the staging LDS
+    constexpr bool CROSS_PREFETCH = true;
 
     // ---- staging addresses: wave w moves rows [w*R, (w+1)*R) of each tile, 8 rows per instruction
     const int srow = lane >> 3;                       // row inside an 8-row piece
@@ -324,49 +324,52 @@ void gemm_bf16_kernel(GemmArgs g) {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * half_n + n) = o;
             }
         }
-    } else {  // EPI_SEGMAX (128 x 128 tile only): logits tile -> LDS, per-column segmented max over token rows
-        static_assert(EPI != EPI_SEGMAX || (BN == 128 && BM == 128), "segmented max uses the 128^2 tile");
-        float* L = reinterpret_cast<float*>(smem);            // [128 m][128 n], column index XOR-swizzled by row
-        int* seq_s = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);  // [128]
-        if (tid < 128) seq_s[tid] = (m0 + tid < g.M) ? g.seq_of[m0 + tid] : -1;
+    } else {  // EPI_SEGMAX: per-sequence max over this tile's token rows, straight from the accumulators
+        // A lane owns token rows (lane & 15) + 16 j of its wave's slab and, per row, features 4 (lane >> 4) + r of each
+        // block i: the rows of one feature sit in the 16 lanes of a DPP row (and in j).  Sequence ids ascend along the
+        // rows (-2 = masked token, -1 = past the last token), so for every sequence q present in the slab - usually one
+        // or two - each lane maxes its own rows of q, four DPP steps finish the max over the 16 lanes, and lane 0 of
+        // the row folds the (positive) result into out[q][n] with an integer atomicMax.  No LDS, no barrier: the
+        // staging buffers stay free for the cross-tile prefetch.
+        int sj[MB];
+        int lo = 0x7fffffff, hi = -1;
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
-            const int ml = wm * MB * 16 + j * 16 + frow;
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            sj[j] = m < g.M ? g.seq_of[m] : -1;
+            if (sj[j] >= 0) {
+                lo = sj[j] < lo ? sj[j] : lo;
+                hi = sj[j] > hi ? sj[j] : hi;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        float* out = reinterpret_cast<float*>(g.C);
+        auto row_max = [](float v) {
+            v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+            v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+            v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+            v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));   // row_mirror
+            return v;
+        };
+        for (int q = lo; q <= hi; ++q) {       // wave-uniform
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int nl = wn * NB * 16 + i * 16 + fg * 4;
-                *reinterpret_cast<f32x4*>(L + ml * 128 + (nl ^ ((ml & 15) << 2))) = acc[i][j];
-            }
-        }
-        __syncthreads();
-        const int col = tid & 127, rbeg = (tid >> 7) * 64;
-        const int n = n0 + col;
-        if (n < g.N) {
-            float* out = reinterpret_cast<float*>(g.C);
-            int cur_seq = -1;
-            float cur_max = 0.f;
-            for (int r = rbeg; r < rbeg + 64; ++r) {
-                const int sq = seq_s[r];
-                if (sq == -1) break;      // past the last token
-                if (sq < 0) continue;     // masked token: not part of any max
-                const float v = L[r * 128 + (col ^ ((r & 15) << 2))];
-                if (sq != cur_seq) {
-                    if (cur_seq >= 0 && cur_max > 0.f)
-                        atomicMax(reinterpret_cast<int*>(out + (int64_t)cur_seq * g.out_ld + n), __float_as_int(cur_max));
-                    cur_seq = sq;
-                    cur_max = 0.f;
+                const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = 0.f;             // log(1 + relu(x)): only positive maxima matter
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) v = (sj[j] == q) ? fmaxf(v, acc[i][j][r]) : v;
+                    v = row_max(v);
+                    if (frow == 0 && v > 0.f && n + r < g.N)
+                        atomicMax(reinterpret_cast<int*>(out + (int64_t)q * g.out_ld + n + r), __float_as_int(v));
                 }
-                cur_max = v > cur_max ? v : cur_max;
             }
-            if (cur_seq >= 0 && cur_max > 0.f)
-                atomicMax(reinterpret_cast<int*>(out + (int64_t)cur_seq * g.out_ld + n), __float_as_int(cur_max));
-        }
-        if (tile + (int)gridDim.x < n_tiles) {   // no cross-tile prefetch here: restage after the LDS epilogue
-            __syncthreads();
-            set_tile(tile + gridDim.x);
-            stage(0, 0);
-            __syncthreads();
-            buf = 0;
         }
     }
     if (stamp && titer < 16) {
@@ -381,7 +384,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
-    constexpr size_t lds = 2 * (size_t)(BN + BM) * 128 + (EPI == EPI_SEGMAX ? 512 : 0);
+    constexpr size_t lds = 2 * (size_t)(BN + BM) * 128;
     static bool attr_set = false;
     if (!attr_set) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>),
@@ -455,7 +458,7 @@ static int launch_small(const GemmArgs& g, hipStream_t s) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
     }
-    if constexpr (EPI != EPI_SEGMAX && EPI != EPI_QKV_ROPE) {
+    if constexpr (EPI != EPI_QKV_ROPE) {
         // few 128^2 tiles (a short tail behind the 256^2 rounds, or a small problem): halve the token tile so that two or
         // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
         const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
@@ -487,9 +490,7 @@ static int launch_one(const GemmArgs& g, hipStream_t s) {
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
     }
-    if constexpr (EPI == EPI_SEGMAX) {
-        return launch_small<EPI>(g, s);          // the segmented max runs in the 128^2 tile's LDS
-    } else {
+    {
         const int big_rows = plan_big_rows(g, true);
         if (big_rows >= g.M) return launch_big<EPI>(g, s);
         if (big_rows <= 0) return launch_small<EPI>(g, s);

@@ -100,14 +100,19 @@ def test_gemm_swiglu_epilogue():
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
 
 
-def test_gemm_segmented_max_epilogue():
+@pytest.mark.parametrize("tile", ["", "128", "256", "split:256"])
+@pytest.mark.parametrize("lens", [[5, 130, 1, 64, 63, 200, 17], [3] * 90 + [1, 2, 250], [700]])
+def test_gemm_segmented_max_epilogue(tile, lens, monkeypatch):
+    """Per-sequence max of the logits straight from the accumulators (DPP row reduction + integer atomicMax): sequences
+    shorter than, equal to and longer than a wave's 64-row slab, many sequences per slab, masked rows, every tiling."""
+    monkeypatch.setenv("SR_GEMM_TILE", tile)
     g = torch.Generator(device="cuda").manual_seed(3)
-    lens = [5, 130, 1, 64, 63, 200, 17]
     M, N, K = sum(lens), 320, 128
     A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
     W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
     seq = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens)).int()
-    seq[7] = -2                                  # a masked token inside sequence 1: skipped
+    seq[7] = -2                                  # a masked token inside a sequence: skipped
+    seq[M - 1] = -2
     out = _gemm(A, W, 3, seq_of=seq.cuda(), n_seq=len(lens))
     logits = A.float() @ W.float().T
     ref = torch.zeros((len(lens), N), device="cuda")
