@@ -52,7 +52,7 @@ void gemm_bf16_kernel(GemmArgs g) {
     const bf16_t* wsrc[W_INSTR];
     const bf16_t* asrc[A_INSTR];
     auto set_tile = [&](int tile) {
-        const int tn0 = (tile % tiles_n) * BN, tm0 = (tile / tiles_n) * BM;
+        const int tn0 = (g.m_fastest ? tile / tiles_m : tile % tiles_n) * BN, tm0 = (g.m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
 #pragma unroll
         for (int i = 0; i < W_INSTR; ++i) {
             int rn = tn0 + (wave * W_INSTR + i) * 8 + srow;
@@ -112,12 +112,20 @@ void gemm_bf16_kernel(GemmArgs g) {
     // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile(s) of the NEXT output tile are
     // prefetched during the last k-step(s) of the current one, so only the epilogue's stores stay exposed between tiles.
     for (; tile < n_tiles; tile += gridDim.x) {
-    const int n0 = (tile % tiles_n) * BN, m0 = (tile / tiles_n) * BM;
+    const int n0 = (g.m_fastest ? tile / tiles_m : tile % tiles_n) * BN, m0 = (g.m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
     const bool has_next = tile + (int)gridDim.x < n_tiles;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sj[MB];      // EPI_SEGMAX: sequence ids of this lane's token rows, fetched here so that the k-loop covers the latency
+    if constexpr (EPI == EPI_SEGMAX) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            sj[j] = m < g.M ? g.seq_of[m] : -1;
+        }
+    }
     if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (stamp && titer == 1) stp[62] = __builtin_amdgcn_s_memtime();        // shader-clock ticks at the start of tile 1's k-loop
     if constexpr (PIPE) {
@@ -328,15 +336,13 @@ void gemm_bf16_kernel(GemmArgs g) {
         // A lane owns token rows (lane & 15) + 16 j of its wave's slab and, per row, features 4 (lane >> 4) + r of each
         // block i: the rows of one feature sit in the 16 lanes of a DPP row (and in j).  Sequence ids ascend along the
         // rows (-2 = masked token, -1 = past the last token), so for every sequence q present in the slab - usually one
-        // or two - each lane maxes its own rows of q, four DPP steps finish the max over the 16 lanes, and lane 0 of
-        // the row folds the (positive) result into out[q][n] with an integer atomicMax.  No LDS, no barrier: the
+        // or two - each lane maxes its own rows of q, four DPP steps finish the max over the 16 lanes, and the lanes of
+        // the row share out the (positive) results and fold them into out[q][n] with integer atomicMax - all 64 lanes
+        // active per atomic instruction (a wave stalls once ~16 atomics are outstanding).  No LDS, no barrier: the
         // staging buffers stay free for the cross-tile prefetch.
-        int sj[MB];
         int lo = 0x7fffffff, hi = -1;
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
-            const int m = m0 + wm * MB * 16 + j * 16 + frow;
-            sj[j] = m < g.M ? g.seq_of[m] : -1;
             if (sj[j] >= 0) {
                 lo = sj[j] < lo ? sj[j] : lo;
                 hi = sj[j] > hi ? sj[j] : hi;
@@ -356,19 +362,27 @@ void gemm_bf16_kernel(GemmArgs g) {
             v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));   // row_mirror
             return v;
         };
+        constexpr int PER_LANE = NB * 4 / 16;       // after the row reduction all 16 lanes hold every maximum: lane f keeps
+        static_assert(NB * 4 % 16 == 0, "");        // those of the (block, register) pairs f, f + 16, ... and issues their atomics
         for (int q = lo; q <= hi; ++q) {       // wave-uniform
+            float mine[PER_LANE];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = 0.f;             // log(1 + relu(x)): only positive maxima matter
 #pragma unroll
                     for (int j = 0; j < MB; ++j) v = (sj[j] == q) ? fmaxf(v, acc[i][j][r]) : v;
                     v = row_max(v);
-                    if (frow == 0 && v > 0.f && n + r < g.N)
-                        atomicMax(reinterpret_cast<int*>(out + (int64_t)q * g.out_ld + n + r), __float_as_int(v));
+                    const int idx = i * 4 + r;
+                    if ((idx & 15) == frow) mine[idx >> 4] = v;
                 }
+#pragma unroll
+            for (int k = 0; k < PER_LANE; ++k) {
+                const int idx = frow + 16 * k;
+                const int n = n0 + wn * NB * 16 + (idx >> 2) * 16 + fg * 4 + (idx & 3);
+                if (mine[k] > 0.f && n < g.N)
+                    atomicMax(reinterpret_cast<int*>(out + (int64_t)q * g.out_ld + n), __float_as_int(mine[k]));
             }
         }
     }
@@ -382,7 +396,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 }
 
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
-static int launch_cfg(const GemmArgs& g, hipStream_t s) {
+static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr size_t lds = 2 * (size_t)(BN + BM) * 128;
     static bool attr_set = false;
@@ -391,6 +405,12 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    GemmArgs g = g_in;
+    // Tile order.  Feature-tile-fastest keeps an XCD on the same 1/8 of W (good while W fits the Infinity Cache).  A weight
+    // matrix far larger than that (the 525 MB vocabulary head) would be streamed from HBM once per token tile: walk the
+    // token tiles fastest instead, so that a W tile is used by all of them while it is hot and W is read once.
+    g.m_fastest = ((int64_t)g.N * g.K * 2 > (128ll << 20) && (int64_t)g.N > 4 * (int64_t)g.M) ? 1 : 0;
+    if (const char* e = getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
     const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
     const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (BM <= 64 ? 3 : 2) : 1);   // resident workgroups on 256 CUs

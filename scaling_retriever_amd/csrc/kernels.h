@@ -27,6 +27,7 @@ struct GemmArgs {
     int n_rope;             // features [0, n_rope) are rotated (q heads then k heads), the rest (v) stored as is
     int head_dim;           // 64 or 128
     unsigned long long* stamps;  // diagnostics only (tools/micro): 4 s_memrealtime stamps (100 MHz) per workgroup-tile, else null
+    int m_fastest;     // tile order, chosen by launch_gemm_bf16: 1 = token tiles fastest (W far larger than the caches)
 };
 
 // y = A @ W^T with fused epilogue. Requirements: K % 64 == 0, N % 16 == 0 (N % 32 for SWIGLU),
