@@ -90,6 +90,27 @@ int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_s
 
 // ---- per-launch HIP event log (measurement hook of the search handles) ----
 #include <vector>
+// A search handle owns ONE top-k workspace.  The handle's mutex serialises the host side of concurrent calls; this
+// chains their device side when they arrive on different streams: the next call's stream waits for an event the
+// previous call recorded after its last kernel.
+struct StreamOrder {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+    struct Scope {
+        StreamOrder& o;
+        hipStream_t s;
+        Scope(StreamOrder& o_, hipStream_t s_) : o(o_), s(s_) {
+            if (o.used && o.last != s && o.ev) (void)hipStreamWaitEvent(s, o.ev, 0);
+        }
+        ~Scope() {
+            if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) { o.ev = nullptr; return; }
+            if (hipEventRecord(o.ev, s) == hipSuccess) { o.last = s; o.used = true; }
+        }
+    };
+    void release() { if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } }
+};
+
 struct LaunchProfile {
     bool enabled = false;
     std::vector<hipEvent_t> ev;   // pairs: start, stop

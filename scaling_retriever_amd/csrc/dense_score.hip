@@ -358,6 +358,7 @@ struct sr_dense_index {
     unsigned short* qpl[3] = {nullptr, nullptr, nullptr};   // query planes for the split precisions
     int64_t q_cap = 0;
     TopkWS ws;
+    StreamOrder order;
     LaunchProfile prof;
     std::mutex mu;
 };
@@ -433,6 +434,7 @@ extern "C" int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t b
 extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
+    idx->order.release();
     for (DenseSegment& seg : idx->segs)
         for (int p = 0; p < 3; ++p)
             if (seg.pl[p]) (void)hipFree(seg.pl[p]);
@@ -465,6 +467,7 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     SR_REQUIRE(((uintptr_t)d_queries & 15) == 0, "sr_dense_search: queries must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(idx->mu);
+    StreamOrder::Scope in_order(idx->order, s);
 
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;

@@ -375,6 +375,7 @@ struct sr_model {
     int* h_cu = nullptr;       // pinned host copy of cu_seqlens
     int last_T = 0;
     std::mutex mu;
+    StreamOrder order;     // chains calls that arrive on different streams (one set of activation buffers)
 };
 
 static void model_free(sr_model* m) {
@@ -503,6 +504,7 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
 extern "C" int sr_model_destroy(sr_model* m) {
     if (!m) return SR_OK;
     model_free(m);
+    m->order.release();
     delete m;
     return SR_OK;
 }
@@ -653,6 +655,7 @@ extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const in
     SR_REQUIRE(m && d_out, "sr_encode_dense: null argument");
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(m->mu);
+    StreamOrder::Scope in_order(m->order, s);
     int T = 0;
     SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, s, &T));
     const int H = m->cfg.hidden_size;
@@ -671,6 +674,7 @@ extern "C" int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const i
     SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_sparse: model was created without an lm_head (LlamaBiModel)");
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(m->mu);
+    StreamOrder::Scope in_order(m->order, s);
     int T = 0;
     SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, s, &T));
     const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
@@ -693,6 +697,7 @@ extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_
     SR_REQUIRE(m && d_out && n_tokens, "sr_model_last_hidden: null argument");
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(m->mu);
+    StreamOrder::Scope in_order(m->order, s);
     const int T = m->last_T;
     *n_tokens = T;
     SR_REQUIRE(capacity_rows >= T, "sr_model_last_hidden: capacity %lld < %d tokens", (long long)capacity_rows, T);

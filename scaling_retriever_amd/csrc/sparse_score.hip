@@ -225,6 +225,7 @@ struct sr_sparse_index {
     int32_t* skip = nullptr;
     int64_t ws_limit = 4ll << 30;
     TopkWS ws;
+    StreamOrder order;
     LaunchProfile prof;
     unsigned long long* d_postings = nullptr;  // device counter of postings touched (profiling only)
     std::mutex mu;
@@ -306,6 +307,7 @@ extern "C" int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t
 extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
+    idx->order.release();
     if (idx->skip) (void)hipFree(idx->skip);
     if (idx->d_postings) (void)hipFree(idx->d_postings);
     delete idx;
@@ -350,6 +352,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
     SR_REQUIRE(d_q_indptr && d_out_scores && d_out_ids, "sr_sparse_search: null pointer");
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(idx->mu);
+    StreamOrder::Scope in_order(idx->order, s);
 
     // query batches bound the candidate workspace: cap (slots per query) = docs per launch
     const int64_t q_batch = nq < 1024 ? nq : 1024;

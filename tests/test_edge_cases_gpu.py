@@ -99,3 +99,57 @@ def test_sparse_search_empty_and_degenerate():
     one = SparseIndexHIP(indptr, np.array([N - 1], np.int32), np.array([2.0], np.float32), N)
     s, i, c = one.search(np.array([0, 1, 1], np.int64), np.array([7], np.int32), np.array([1.5], np.float32), 1)
     assert c.cpu().tolist() == [1, 0] and int(i[0, 0]) == N - 1 and float(s[0, 0]) == 3.0
+
+
+def test_search_handles_serialise_concurrent_callers():
+    """The reference drives retrieval from a 4-thread ThreadPoolExecutor (indexer.py:459).  A search handle owns one
+    top-k workspace, so concurrent sr_dense_search / sr_sparse_search calls on the SAME handle must serialise inside the
+    library: four threads, each on its own stream, get exactly the single-threaded answers."""
+    import threading
+    from scaling_retriever_amd.scoring import DenseIndexHIP, SparseIndexHIP
+    g = torch.Generator(device="cuda").manual_seed(21)
+    N, H, V = 30000, 128, 500
+    D = torch.randn((N, H), device="cuda", generator=g)
+    dense = DenseIndexHIP(H)
+    dense.add_device_rows(D)
+    Qs = [torch.randn((n, H), device="cuda", generator=g) for n in (7, 150, 64, 300)]
+    want_dense = [dense.search(Q, 25) for Q in Qs]
+    # sparse index: random postings, doc ids ascending inside each term
+    term = torch.randint(0, V, (200000,), device="cuda", generator=g)
+    doc = torch.randint(0, N, (200000,), device="cuda", generator=g)
+    key = torch.unique(term.long() * N + doc.long())
+    t_of = torch.div(key, N, rounding_mode="floor")
+    ids = (key - t_of * N).int().contiguous()
+    vals = torch.rand(ids.numel(), device="cuda", generator=g)
+    indptr = torch.zeros(V + 1, dtype=torch.int64, device="cuda")
+    indptr[1:] = torch.cumsum(torch.bincount(t_of, minlength=V), 0)
+    sparse = SparseIndexHIP(indptr, ids, vals, N)
+    qsets = []
+    for nq in (3, 40, 11, 90):
+        cols = torch.stack([torch.randperm(V, device="cuda", generator=g)[:12].sort().values for _ in range(nq)]).int().reshape(-1)
+        qsets.append((torch.arange(0, nq * 12 + 1, 12, device="cuda", dtype=torch.int64), cols.contiguous(),
+                      torch.rand(nq * 12, device="cuda", generator=g)))
+    want_sparse = [sparse.search(*q, 20) for q in qsets]
+    torch.cuda.synchronize()
+    got_dense, got_sparse, errors = [None] * 4, [None] * 4, []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    got_dense[t] = dense.search(Qs[t], 25)
+                    got_sparse[t] = sparse.search(*qsets[t], 20)
+            st.synchronize()
+        except Exception as e:          # noqa: BLE001 - surfaced below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert all(torch.equal(a, b) for a, b in zip(got_dense[t], want_dense[t]))
+        assert all(torch.equal(a, b) for a, b in zip(got_sparse[t], want_sparse[t]))
