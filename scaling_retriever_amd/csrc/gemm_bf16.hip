@@ -3,19 +3,20 @@
 // y[M,N] = A[M,K] @ W[N,K]^T  (nn.Linear).  Replaces the cuBLAS GEMMs HF's
 // LlamaModel issues under torch.autocast(bf16) (scaling_retriever/indexer.py:46-52).
 //
-// Two tile configurations of one kernel template (BK = 64, v_mfma_f32_16x16x32_bf16):
-//   128(n) x 128(m), 4 waves (2 x 2), wave tile 64 x 64, 64 KB LDS, 2 workgroups per CU
-//   256(n) x 256(m), 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS, 1 workgroup per CU:
-//       half the L2->LDS bytes per FLOP and a full k-step (2048 MFMA cycles per SIMD) of
-//       prefetch lead, used when the problem fills the 256 CUs with 256^2 tiles.
+// Tile configurations of one kernel template (BK = 64, v_mfma_f32_16x16x32_bf16):
+//   256(n) x 256(m), 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS, 1 workgroup per CU, software-pipelined k-loop:
+//       half the L2->LDS bytes per FLOP of the small tile; runs whole rounds of 256 tiles (see the tile plan below)
+//   128(n) x 128(m), 4 waves (2 x 2), wave tile 64 x 64, 64 KB LDS, 2 workgroups per CU: small problems and ragged tails
+//   128(n) x  64(m), 4 waves, 48 KB LDS, 3 workgroups per CU: tails of fewer than 384 tiles
 // The WEIGHT tile is the MFMA A operand and the activation tile the B operand, so an
 // accumulator lane owns one token row m (lane & 15) and 4 consecutive output features n in
 // its 4 registers: epilogue stores are 8 B (bf16x4) or 16 B (fp32x4) per lane, gate/up
 // partners sit in the same lane.
 // Staging: global_load_lds 16 B (LDS-DMA), two LDS stages, one barrier per k-step; the XOR
 // swizzle (16-B chunk ^ (row & 7)) is applied on the global SOURCE address and on the
-// ds_read_b128 address (the LDS image is lane-linear).  Grid is n-tile-fastest so that, with
-// round-robin XCD placement, an XCD keeps touching the same 1/8 of W.
+// ds_read_b128 address (the LDS image is lane-linear).  Workgroups are persistent over tiles; the tile order is
+// feature-tile-fastest (with round-robin XCD placement an XCD keeps touching the same 1/8 of W) unless W is far
+// larger than the caches, then token-tile-fastest (launch_cfg).
 #include "kernels.h"
 #include <math.h>
 #include <stdlib.h>
