@@ -505,9 +505,12 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
         SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
         SR_TRY(idx->ws.ensure(nq, k, chunk));
         SR_TRY(topk_reset(idx->ws, nq, s));
+        int64_t step = k + 1024 < chunk ? ceil_div64((int64_t)k + 1024, TM) * TM : chunk;   // short first launches, see below
         for (const DenseSegment& seg : idx->segs) {
-            for (int64_t r0 = 0; r0 < seg.n; r0 += chunk) {
-                const int64_t r1 = r0 + chunk < seg.n ? r0 + chunk : seg.n;
+            for (int64_t r0 = 0; r0 < seg.n;) {
+                const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
+                const int64_t r0_next = r1;
+                step = step * 2 < chunk ? step * 2 : chunk;
                 DenseSplitArgs a;
                 for (int p = 0; p < 3; ++p) { a.D[p] = seg.pl[p]; a.Q[p] = idx->qpl[p]; }
                 if (np == 2) {            // (d plane, q plane), smallest products first
@@ -526,6 +529,7 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
                 SR_TRY(launch_dense_split(a, s));
                 idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
                 SR_TRY(topk_compact(idx->ws, nq, k, s));
+                r0 = r0_next;
             }
         }
         SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
@@ -562,9 +566,15 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     SR_TRY(idx->ws.ensure(nq, k, chunk));
     SR_TRY(topk_reset(idx->ws, nq, s));
 
+    // The first launches see no threshold yet (every doc is a candidate until k have been seen), so they are kept short
+    // and doubled - 2048, 4096, ... docs - until the regular chunk: each then appends about k survivors per query
+    // instead of a whole chunk's worth for the first one (32 768 keys per query, 1.8 GB at 6980 queries).
+    int64_t step = k + 1024 < chunk ? ceil_div64((int64_t)k + 1024, TM) * TM : chunk;
     for (const DenseSegment& seg : idx->segs) {
-        for (int64_t r0 = 0; r0 < seg.n; r0 += chunk) {
-            const int64_t r1 = r0 + chunk < seg.n ? r0 + chunk : seg.n;
+        for (int64_t r0 = 0; r0 < seg.n;) {
+            const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
+            const int64_t r0_next = r1;
+            step = step * 2 < chunk ? step * 2 : chunk;
             DenseArgs a;
             a.D = seg.rows;
             a.Q = d_queries;
@@ -594,6 +604,7 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
             }
             idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
             SR_TRY(topk_compact(idx->ws, nq, k, s));
+            r0 = r0_next;
         }
     }
     SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
