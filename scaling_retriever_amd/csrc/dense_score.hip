@@ -237,11 +237,26 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[m][j], BF[n][j], acc[m][n], 0, 0, 0);
 
     const int nk = H / BK;
-    gload(0);
-    sstore(0);
-    gload(nk > 1 ? BK : 0);
-    sstore(1);
-    gload(nk > 2 ? 2 * BK : 0);
+    {   // prologue: the first three k-steps' loads are all in flight before the first stage is written (one memory
+        // latency instead of three)
+        f32x4 pa[2][PER_T], pb[2][PER_T];
+#pragma unroll
+        for (int st0 = 0; st0 < 2; ++st0) {
+            const int k0 = (st0 < nk ? st0 : 0) * BK;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pa[st0][i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pb[st0][i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+        }
+        gload(nk > 2 ? 2 * BK : 0);
+#pragma unroll
+        for (int st0 = 0; st0 < 2; ++st0) {
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&As[st0 * TM * LDK + soff[i]]) = pa[st0][i];
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&Bs[st0 * TN * LDK + soff[i]]) = pb[st0][i];
+        }
+    }
     __syncthreads();
     f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
     frag(0, 0, a0, b0);
