@@ -96,6 +96,27 @@ def test_attention_prerotated_inputs(nh, nkv, hd, lens):
     torch.testing.assert_close(out.float(), ref, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_gemm_tile_order_does_not_change_the_result(order, monkeypatch):
+    """Feature-tile-fastest (default) and token-tile-fastest (chosen for weight matrices far larger than the caches)
+    tile orders visit the same tiles: identical output, ragged edges included."""
+    L, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 1300, 2100 // 16 * 16, 256
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    out = []
+    for tile in ("128", "256", "split:512"):
+        monkeypatch.setenv("SR_GEMM_TILE", tile)
+        monkeypatch.setenv("SR_GEMM_MFAST", order)
+        C = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()))
+        torch.cuda.synchronize()
+        out.append(C)
+    torch.testing.assert_close(out[0], A.float() @ W.float().T, rtol=1e-4, atol=1e-4)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+
+
 @pytest.mark.parametrize("tile", ["128", "256"])
 def test_gemm_many_tiles_under_load(tile, monkeypatch):
     """1024 output tiles of 256 x 256 (4 per persistent workgroup) with K = 2048: the software-pipelined k-loop and the
