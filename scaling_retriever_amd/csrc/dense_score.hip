@@ -170,10 +170,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void dense_score_kerne
 // (last read in step kt - 1), and the first fragments of step kt + 1 are read - from a stage made visible by the
 // PREVIOUS barrier - under the last MFMAs of step kt.  One barrier per k-step remains, with MFMAs issued right up to
 // it and right after it.  Same k order per accumulator as dense_score_kernel: bit-identical scores.
+// WN = 32-query blocks per wave: 2 -> 256 docs x 256 queries (wave tile 128 x 64), 1 -> 256 x 128 for 65-128 queries.
+template <int WN>
 __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
-    constexpr int WAVES_N = 4, WM = 4, WN = 2, BK = 16;
-    constexpr int NT = 512, TM = 256, TN = 256, LDK = BK + 4, KC = BK / 4, NSTAGE = 3;
-    constexpr int PER_T = TM * KC / NT;                 // 16-B chunks per thread and operand tile (= 2)
+    constexpr int WAVES_N = 4, WM = 4, BK = 16;
+    constexpr int NT = 512, TM = 256, TN = 32 * WN * WAVES_N, LDK = BK + 4, KC = BK / 4, NSTAGE = 3;
+    constexpr int PER_T = TM * KC / NT;                 // 16-B chunks per thread of the doc tile (= 2)
+    constexpr int PER_TB = TN * KC / NT;                // ... of the query tile (2 or 1)
+    constexpr int HALF_MFMAS = 4 * WM * WN;             // MFMAs per half k-step and wave
+    constexpr int MPO = WN == 2 ? 2 : 1;                // MFMAs between two memory operations
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [NSTAGE][TM][LDK]
     float* Bs = smem + NSTAGE * TM * LDK;   // [NSTAGE][TN][LDK]
@@ -187,31 +192,33 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
     // staging: thread t moves chunks t and t + 512 of each operand tile (row = chunk / 4, k-chunk = chunk % 4);
     // rows past the end are clamped (their scores are never emitted)
     const float* asrc[PER_T];
-    const float* bsrc[PER_T];
+    const float* bsrc[PER_TB];
     int soff[PER_T];
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
         const int c = tid + i * NT, r = c / KC, kc = c % KC;
         int64_t row = row0 + r;
         row = row < a.row_end ? row : a.row_end - 1;
-        int q = q0 + r;
-        q = q < a.nq ? q : a.nq - 1;
         asrc[i] = a.D + row * H + kc * 4;
-        bsrc[i] = a.Q + (int64_t)q * H + kc * 4;
         soff[i] = r * LDK + kc * 4;
+        if (i < PER_TB) {
+            int q = q0 + r;
+            q = q < a.nq ? q : a.nq - 1;
+            bsrc[i] = a.Q + (int64_t)q * H + kc * 4;
+        }
     }
-    f32x4 ra[PER_T], rb[PER_T];
+    f32x4 ra[PER_T], rb[PER_TB];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) ra[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
 #pragma unroll
-        for (int i = 0; i < PER_T; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+        for (int i = 0; i < PER_TB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
     };
     auto sstore = [&](int st) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&As[st * TM * LDK + soff[i]]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&Bs[st * TN * LDK + soff[i]]) = rb[i];
+        for (int i = 0; i < PER_TB; ++i) *reinterpret_cast<f32x4*>(&Bs[st * TN * LDK + soff[i]]) = rb[i];
     };
 
     f32x16 acc[WM][WN];
@@ -239,14 +246,14 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
     const int nk = H / BK;
     {   // prologue: the first three k-steps' loads are all in flight before the first stage is written (one memory
         // latency instead of three)
-        f32x4 pa[2][PER_T], pb[2][PER_T];
+        f32x4 pa[2][PER_T], pb[2][PER_TB];
 #pragma unroll
         for (int st0 = 0; st0 < 2; ++st0) {
             const int k0 = (st0 < nk ? st0 : 0) * BK;
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) pa[st0][i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) pb[st0][i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+            for (int i = 0; i < PER_TB; ++i) pb[st0][i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
         }
         gload(nk > 2 ? 2 * BK : 0);
 #pragma unroll
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&As[st0 * TM * LDK + soff[i]]) = pa[st0][i];
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) *reinterpret_cast<f32x4*>(&Bs[st0 * TN * LDK + soff[i]]) = pb[st0][i];
+            for (int i = 0; i < PER_TB; ++i) *reinterpret_cast<f32x4*>(&Bs[st0 * TN * LDK + soff[i]]) = pb[st0][i];
         }
     }
     __syncthreads();
@@ -276,29 +283,29 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
         SR_DENSE_MFMAS(a0, b0)
 #pragma unroll
         for (int i = 0; i < WM + WN; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, MPO, 0);  // MFMAs
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
         }
 #pragma unroll
-        for (int i = 0; i < 2 * PER_T; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int i = 0; i < PER_T + PER_TB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPO, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // 1 DS write
         }
 #pragma unroll
-        for (int i = 0; i < 2 * PER_T; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int i = 0; i < PER_T + PER_TB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPO, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * (WM + WN + 4 * PER_T), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, HALF_MFMAS - MPO * (WM + WN + 2 * (PER_T + PER_TB)), 0);
         __builtin_amdgcn_sched_barrier(0);
         frag(st1, 0, a0, b0);
         SR_DENSE_MFMAS(a1, b1)
 #pragma unroll
         for (int i = 0; i < WM + WN; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, MPO, 1);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * (WM + WN), 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, HALF_MFMAS - MPO * (WM + WN), 1);
         __builtin_amdgcn_sched_barrier(0);      // the barrier (and its lgkmcnt(0)) after the MFMAs that cover the reads
         __syncthreads();
         st = st1;
@@ -341,16 +348,18 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
     }
 }
 
+template <int WN>
 static int launch_dense_pipe(const DenseArgs& a, int64_t rows, hipStream_t s) {
-    constexpr size_t lds = sizeof(float) * 3 * (256 + 256) * (16 + 4);
+    constexpr int TN = 128 * WN;
+    constexpr size_t lds = sizeof(float) * 3 * (256 + TN) * (16 + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_pipe_kernel<WN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)ceil_div64(rows, 256), (unsigned)ceil_div64(a.nq, 256));
-    hipLaunchKernelGGL(dense_score_pipe_kernel, grid, dim3(512), lds, s, a);
+    dim3 grid((unsigned)ceil_div64(rows, 256), (unsigned)ceil_div64(a.nq, TN));
+    hipLaunchKernelGGL(dense_score_pipe_kernel<WN>, grid, dim3(512), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -610,10 +619,13 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
                     else if (variant == 1) SR_TRY((launch_dense<2, 4, 4, 2>(a, r1 - r0, s)));
                     else if (variant == 2) SR_TRY((launch_dense<2, 4, 4, 2, 32>(a, r1 - r0, s)));
                     else if (variant == 3) SR_TRY((launch_dense<4, 4, 2, 2>(a, r1 - r0, s)));
-                    else if (variant == 5) SR_TRY(launch_dense_pipe(a, r1 - r0, s));
+                    else if (variant == 5) SR_TRY(launch_dense_pipe<2>(a, r1 - r0, s));
                     else SR_TRY((launch_dense<4, 2, 2, 2, 16, 4>(a, r1 - r0, s)));   // 256 x 128 tile, 2 workgroups per CU
                     break;
-                case 1: SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s))); break;
+                case 1:
+                    if (variant == 5) SR_TRY(launch_dense_pipe<1>(a, r1 - r0, s));
+                    else SR_TRY((launch_dense<2, 2, 4, 2>(a, r1 - r0, s)));
+                    break;
                 case 2: SR_TRY((launch_dense<4, 1, 2, 2>(a, r1 - r0, s))); break;
                 default: SR_TRY((launch_dense<4, 1, 2, 1>(a, r1 - r0, s))); break;
             }

@@ -270,7 +270,8 @@ def test_topk_merge_equals_global_topk():
         assert np.array_equal(i[q], ci[keep][o]) and np.array_equal(s[q], cs[keep][o])
 
 
-@pytest.mark.parametrize("nq,n,h,k", [(300, 70001, 256, 100), (700, 33000, 2048, 1000), (129, 513, 64, 10)])
+@pytest.mark.parametrize("nq,n,h,k", [(300, 70001, 256, 100), (700, 33000, 2048, 1000), (129, 513, 64, 10), (100, 50001, 512, 100),
+                                      (65, 700, 64, 10), (128, 33000, 2048, 1000)])
 def test_dense_pipelined_kernel_equals_plain_kernel(nq, n, h, k, monkeypatch):
     """The default score kernel for nq > 128 (three LDS stages, fragment prefetch across the barrier, memory operations
     dealt out between the MFMAs) accumulates every score in the same k order as the plain double-buffered kernel:
