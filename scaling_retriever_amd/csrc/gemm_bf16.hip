@@ -474,8 +474,14 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
     return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);
 }
 
+static bool env_off(const char* name) {
+    const char* e = getenv(name);
+    return e && *e == '0';
+}
+
 template <int EPI>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
+    const bool pipe = g.K / G_BK >= 4 && !env_off("SR_GEMM_PIPE");      // the pipelined k-loop needs >= 4 k-steps
     if constexpr (EPI == EPI_QKV_ROPE) {
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
     }
@@ -483,10 +489,10 @@ static int launch_small(const GemmArgs& g, hipStream_t s) {
         // few 128^2 tiles (a short tail behind the 256^2 rounds, or a small problem): halve the token tile so that two or
         // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
         const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
-        const char* e = getenv("SR_GEMM_TAIL64");
-        if (t128 < 384 && g.M > 64 && !(e && *e == '0')) return launch_cfg<EPI, 2, 2, 4, 2>(g, s);
+        if (t128 < 384 && g.M > 64 && !env_off("SR_GEMM_TAIL64"))
+            return pipe ? launch_cfg<EPI, 2, 2, 4, 2, true>(g, s) : launch_cfg<EPI, 2, 2, 4, 2>(g, s);
     }
-    return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+    return pipe ? launch_cfg<EPI, 2, 2, 4, 4, true>(g, s) : launch_cfg<EPI, 2, 2, 4, 4>(g, s);
 }
 
 // the token rows [row0, M) of the same problem
