@@ -67,3 +67,22 @@ def test_sparse_encode_at_1b_width(weights):
     assert _rel(out, ref) < REL_TOL, _rel(out, ref)
     flips = (out > 0) != (ref > 0)
     assert np.all(np.maximum(out, ref)[flips] < 0.05)
+
+
+def test_encode_is_bitwise_reproducible_under_load(weights):
+    """Races in the pipelined kernels (a missed wait, a stage refilled too early) show up as run-to-run differences long
+    before they move a tolerance: the same batch encoded five times, with other batches in between, gives identical bits."""
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense, LlamaBiSparse
+    ids, mask = _batch(128, 8, 160, 7)
+    ids2, mask2 = _batch(96, 8, 192, 8)
+    for cls, n in ((LlamaBiDense, 5), (LlamaBiSparse, 3)):
+        model = cls.from_weights(CFG, weights).to("cuda").eval()
+        a = (torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+        b = (torch.from_numpy(ids2).cuda(), torch.from_numpy(mask2).cuda())
+        first = model.doc_encode(input_ids=a[0], attention_mask=a[1]).clone()
+        for _ in range(n - 1):
+            model.doc_encode(input_ids=b[0], attention_mask=b[1])
+            again = model.doc_encode(input_ids=a[0], attention_mask=a[1])
+            assert torch.equal(again, first)
+        del model
+        torch.cuda.empty_cache()
