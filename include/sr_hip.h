@@ -13,7 +13,9 @@
  * released (scaling_retriever/indexer.py:325,459), so search entry points are
  * re-entrant: each handle owns its workspace and serialises concurrent calls on
  * an internal mutex (the GPU runs a whole query batch per call; threads are a
- * CPU artefact of the reference).  Different handles never share mutable state.
+ * CPU artefact of the reference) and, when those calls arrive on different
+ * streams, chains their device work through an event so that the workspace is
+ * never used by two calls at once.  Different handles never share mutable state.
  */
 #ifndef SR_HIP_H
 #define SR_HIP_H
