@@ -109,10 +109,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    # SR_BENCH_SHARE_GPU=1: dry run of the multi-rank path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL,
+    # which refuses two ranks on one device); the driver's real runs leave it unset
+    share_gpu = os.environ.get("SR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from scaling_retriever_amd import _lib
     from scaling_retriever_amd.distributed import all_gather_query_reps, gather_topk, query_slice, shard_size
@@ -170,7 +178,7 @@ def main():
     dt = time.perf_counter() - t0
     _lib.check(lib.sr_dense_index_profile(index._h, 0))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -223,7 +231,7 @@ def main():
             dtf = time.perf_counter() - tf0
             _lib.check(lib.sr_dense_index_profile(index._h, 0))
             if world > 1:
-                t = torch.tensor([dtf], dtype=torch.float64, device=device)
+                t = torch.tensor([dtf], dtype=torch.float64, device="cpu" if share_gpu else device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dtf = float(t.item())
             _lib.check(lib.sr_dense_index_profile_read(index._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))

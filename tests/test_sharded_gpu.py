@@ -52,3 +52,25 @@ def test_sharded_dense_retriever_two_processes(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "SHARDED_OK" in out.stdout
+
+
+def test_bench_multi_rank_path_dry_run():
+    """bench.py's N > 1 path (query-sharded encode + all-gather, doc-sharded search, one gather of the per-shard top-k,
+    merge on rank 0, max-over-ranks timing, the precision-mode and small-batch legs) end to end with two ranks sharing
+    this GPU over gloo (SR_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one device).  Small corpus: plumbing, not speed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SR_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-docs", "300000",
+           "--encode-batches", "1", "--layers", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
+    assert res["fast_mode"]["value"] > 0 and res["small_batch"][0]["nq"] == 1
