@@ -295,7 +295,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import scoring as SC
-        ns, nqs = min(n_local, 400_000), min(args.n_queries, 1024)
+        ns, nqs = min(n_local, 1_200_000), min(args.n_queries, 1024)   # ~10 s of host work on the GPU box
         Dh = D[:ns].cpu().numpy()
         Qh = encode_queries()[:nqs].cpu().numpy()
         SC.flat_ip_search_fast(Qh[:64], Dh[:20000], min(args.topk, 1000))
