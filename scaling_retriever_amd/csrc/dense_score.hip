@@ -196,7 +196,11 @@ __global__ __launch_bounds__(512, 2) void dense_score_pipe_kernel(DenseArgs a) {
     int soff[PER_T];
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-        const int c = tid + i * NT, r = c / KC, kc = c % KC;
+        // chunk c -> (row r, k-chunk kc): the 8 lanes of a ds_write_b128 group take rows r and r + 4, whose 80-byte pitch
+        // puts them 16 banks apart (rows r and r + 1 would overlap: 2-way conflicts on every stage write); a row is still
+        // fetched as one 64-byte piece by 4 neighbouring lanes
+        const int c = tid + i * NT, kc = c & 3, grp = c >> 3;
+        const int r = (grp >> 2) * 8 + (grp & 3) + 4 * ((c >> 2) & 1);
         int64_t row = row0 + r;
         row = row < a.row_end ? row : a.row_end - 1;
         asrc[i] = a.D + row * H + kc * 4;
@@ -529,7 +533,9 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
         SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
         SR_TRY(idx->ws.ensure(nq, k, chunk));
         SR_TRY(topk_reset(idx->ws, nq, s));
-        int64_t step = k + 1024 < chunk ? ceil_div64((int64_t)k + 1024, TM) * TM : chunk;   // short first launches, see below
+        int64_t step = ceil_div64((int64_t)k + 1024, TM) * TM;   // short first launches, see below
+        if (step < TM * ceil_div64(256, qtiles)) step = TM * ceil_div64(256, qtiles);
+        if (step > chunk) step = chunk;
         for (const DenseSegment& seg : idx->segs) {
             for (int64_t r0 = 0; r0 < seg.n;) {
                 const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
@@ -593,7 +599,10 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     // The first launches see no threshold yet (every doc is a candidate until k have been seen), so they are kept short
     // and doubled - 2048, 4096, ... docs - until the regular chunk: each then appends about k survivors per query
     // instead of a whole chunk's worth for the first one (32 768 keys per query, 1.8 GB at 6980 queries).
-    int64_t step = k + 1024 < chunk ? ceil_div64((int64_t)k + 1024, TM) * TM : chunk;
+    // ... but never shorter than one workgroup per CU
+    int64_t step = ceil_div64((int64_t)k + 1024, TM) * TM;
+    if (step < TM * ceil_div64(256, qtiles)) step = TM * ceil_div64(256, qtiles);
+    if (step > chunk) step = chunk;
     for (const DenseSegment& seg : idx->segs) {
         for (int64_t r0 = 0; r0 < seg.n;) {
             const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
