@@ -7,7 +7,8 @@
 //   256(n) x 256(m), 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS, 1 workgroup per CU, software-pipelined k-loop:
 //       half the L2->LDS bytes per FLOP of the small tile; runs whole rounds of 256 tiles (see the tile plan below)
 //   128(n) x 128(m), 4 waves (2 x 2), wave tile 64 x 64, 64 KB LDS, 2 workgroups per CU: small problems and ragged tails
-//   128(n) x  64(m), 4 waves, 48 KB LDS, 3 workgroups per CU: tails of fewer than 384 tiles
+//   128(n) x  64(m), 4 waves, three 24 KB LDS stages (LDS-DMA issued three k-steps ahead, counted vmcnt before a bare
+//       s_barrier), 2 workgroups per CU: tails of fewer than 384 tiles
 // The WEIGHT tile is the MFMA A operand and the activation tile the B operand, so an
 // accumulator lane owns one token row m (lane & 15) and 4 consecutive output features n in
 // its 4 registers: epilogue stores are 8 B (bf16x4) or 16 B (fp32x4) per lane, gate/up
@@ -31,7 +32,7 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 // WAVES_N x WAVES_M waves; each wave owns (16 * NB) features x (16 * MB) tokens.
 // PIPE: fragment double-buffering - the ds_reads of the next half k-step are in flight while the MFMAs of the current
 // half run, stages are issued two k-steps ahead, still one barrier per k-step (placed between the two halves).
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
 void gemm_bf16_kernel(GemmArgs g) {
     constexpr int NW = WAVES_N * WAVES_M;
@@ -90,6 +91,10 @@ void gemm_bf16_kernel(GemmArgs g) {
     set_tile(tile);
     stage(0, 0);
     if constexpr (PIPE) stage(1, G_BK);     // PIPE needs nk >= 2 (checked at launch)
+    if constexpr (PIPE && NS > 2) {
+#pragma unroll
+        for (int st = 2; st < NS; ++st) stage(st, st * G_BK);     // NS stages need nk >= NS (checked at launch)
+    }
     __syncthreads();
     int buf = 0;
     auto load_frags = [&](int st, int kk, mfma_bf16x8 (&wf)[NB], mfma_bf16x8 (&af)[MB]) {
@@ -129,7 +134,89 @@ void gemm_bf16_kernel(GemmArgs g) {
     }
     if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (stamp && titer == 1) stp[62] = __builtin_amdgcn_s_memtime();        // shader-clock ticks at the start of tile 1's k-loop
-    if constexpr (PIPE) {
+    if constexpr (PIPE && NS > 2) {
+        // NS LDS stages (small tiles, where a workgroup has a CU's MFMA pipe to itself or shares it with one other):
+        // the LDS-DMA of k-step kt + NS is issued when k-step kt's stage is released, so a piece has NS - 1 k-steps to
+        // land and the wait before the barrier only covers pieces issued NS - 1 k-steps ago (counted vmcnt; the barrier is
+        // a bare s_barrier - __syncthreads() would drain every outstanding piece).  Same four phases as below.
+        constexpr int HB = NB / 2, PIECES = W_INSTR + A_INSTR;
+        mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
+        auto load_w = [&](int st, int kk, int h, mfma_bf16x8 (&wf)[HB]) {
+            const unsigned char* wt = smem + st * STAGE_BYTES;
+            const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+                wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + (h * HB + i) * 16 + frow) * 128 + pos);
+        };
+        auto load_a = [&](int st, int kk, mfma_bf16x8 (&af)[MB]) {
+            const unsigned char* at = smem + st * STAGE_BYTES + W_BYTES;
+            const int pos = ((4 * kk + fg) ^ (frow & 7)) * 16;
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * 128 + pos);
+        };
+#define SR_MFMA_HALF(H, WF, AF)                                                                              \
+        _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                       \
+            _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                   \
+                acc[(H) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(H) * HB + i][j], 0, 0, 0);
+        load_w(buf, 0, 0, wx);
+        load_a(buf, 0, a0);
+        int kt = 0;
+#define SR_SGB2(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
+        constexpr int PH = HB * MB;                                   // MFMAs per phase
+        constexpr int R0 = HB + MB < PH ? HB + MB : PH, R1 = HB < PH ? HB : PH;
+        for (; kt + NS < nk; ++kt) {
+            const int nxt = buf + 1 == NS ? 0 : buf + 1;
+            load_w(buf, 0, 1, wy);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(0, wx, a0)
+#pragma unroll
+            for (int i = 0; i < R0; ++i) { SR_SGB2(0x008, 1, 0); SR_SGB2(0x100, 1, 0); }
+            if constexpr (PH > R0) SR_SGB2(0x008, PH - R0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 0, wx);
+            SR_MFMA_HALF(1, wy, a0)
+#pragma unroll
+            for (int i = 0; i < R1; ++i) { SR_SGB2(0x008, 1, 1); SR_SGB2(0x100, 1, 1); }
+            if constexpr (PH > R1) SR_SGB2(0x008, PH - R1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+#pragma unroll
+            for (int i = 0; i < R1; ++i) { SR_SGB2(0x008, 1, 2); SR_SGB2(0x100, 1, 2); }
+            if constexpr (PH > R1) SR_SGB2(0x008, PH - R1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // pieces of k-steps kt + 2 .. kt + NS - 1 may still be in flight; k-step kt + 1 (read next) must have landed
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * PIECES) : "memory");
+            load_w(nxt, 0, 0, wx);
+            load_a(nxt, 0, a0);
+            stage(buf, (kt + NS) * G_BK);
+            SR_MFMA_HALF(1, wy, a1)
+#pragma unroll
+            for (int i = 0; i < R0; ++i) { SR_SGB2(0x008, 1, 3); SR_SGB2(0x100, 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nxt;
+        }
+#undef SR_SGB2
+        for (; kt < nk; ++kt) {        // drain: every remaining k-step is already on its way
+            const int nxt = buf + 1 == NS ? 0 : buf + 1;
+            load_w(buf, 0, 1, wy);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(0, wx, a0)
+            load_w(buf, 1, 0, wx);
+            SR_MFMA_HALF(1, wy, a0)
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 1 < nk) {
+                load_w(nxt, 0, 0, wx);
+                load_a(nxt, 0, a0);
+            }
+            SR_MFMA_HALF(1, wy, a1)
+            buf = nxt;
+        }
+#undef SR_MFMA_HALF
+    } else if constexpr (PIPE) {
         // 4 phases per k-step: (kk, half of the wave's feature blocks).  While a phase's 16 MFMAs run, the fragments of the
         // next phase are being read from LDS (rolling wx / wy, a0 / a1).  The k-step barrier sits before the LAST phase's
         // MFMAs: by then every read of stage `buf` has been issued and waited for, so the stage can be refilled (k-step
@@ -393,16 +480,26 @@ void gemm_bf16_kernel(GemmArgs g) {
         if (titer + 1 < 16) stp[(titer + 1) * 4] = stp[titer * 4 + 3];
     }
     ++titer;
+    if constexpr (PIPE && NS > 2) {
+        if (has_next) {                 // no cross-tile prefetch with NS stages: stage the next tile's first k-steps now
+            __syncthreads();
+            set_tile(tile + gridDim.x);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) stage(st, st * G_BK);
+            __syncthreads();
+            buf = 0;
+        }
+    }
     }  // tile loop
 }
 
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false>
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2>
 static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
-    constexpr size_t lds = 2 * (size_t)(BN + BM) * 128;
+    constexpr size_t lds = NS * (size_t)(BN + BM) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -414,9 +511,9 @@ static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     if (const char* e = getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
     const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
-    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (BM <= 64 ? 3 : 2) : 1);   // resident workgroups on 256 CUs
+    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (int64_t)((160 * 1024) / lds > 3 ? 3 : (160 * 1024) / lds) : 1);   // resident workgroups on 256 CUs
     if (!(env && *env == '0') && tiles > slots) tiles = slots;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
     SR_CHECK_LAUNCH();
     return SR_OK;
@@ -490,7 +587,8 @@ static int launch_small(const GemmArgs& g, hipStream_t s) {
         // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
         const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
         if (t128 < 384 && g.M > 64 && !env_off("SR_GEMM_TAIL64"))
-            return pipe ? launch_cfg<EPI, 2, 2, 4, 2, true>(g, s) : launch_cfg<EPI, 2, 2, 4, 2>(g, s);
+            return pipe ? (env_off("SR_GEMM_NS3") ? launch_cfg<EPI, 2, 2, 4, 2, true>(g, s) : launch_cfg<EPI, 2, 2, 4, 2, true, 3>(g, s))
+                        : launch_cfg<EPI, 2, 2, 4, 2>(g, s);
     }
     return pipe ? launch_cfg<EPI, 2, 2, 4, 4, true>(g, s) : launch_cfg<EPI, 2, 2, 4, 4>(g, s);
 }
