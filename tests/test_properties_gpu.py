@@ -1,0 +1,59 @@
+"""GPU property tests (hypothesis): sr_dense_search / sr_sparse_search through the C ABI against the oracle on random
+shapes - ragged tiles, every kernel regime (streaming <= 64 queries, 128- and 256-query tiles, the template fallbacks for
+dims that are not a multiple of 256), k above and below the corpus size, ties.  Bit-exact ids and fp32 scores."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from oracle import scoring as SC
+
+pytestmark = pytest.mark.gpu
+SET = settings(max_examples=30, deadline=None)
+
+
+@SET
+@given(st.integers(0, 2 ** 31 - 1), st.sampled_from([1, 3, 17, 64, 65, 100, 128, 129, 200, 257, 300]), st.integers(1, 3000),
+       st.sampled_from([16, 48, 64, 128, 256, 272, 512]), st.integers(1, 70), st.booleans())
+def test_dense_search_random_shapes(seed, nq, n, h, k, ties):
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(seed)
+    D = rng.standard_normal((n, h), dtype=np.float32)
+    if ties and n > 4:
+        D[n // 2] = D[1]
+        D[n - 1] = D[1]
+    Q = rng.standard_normal((nq, h), dtype=np.float32)
+    idx = DenseIndexHIP(h)
+    idx.add_device_rows(torch.from_numpy(D).cuda())
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    m = min(k, n)
+    es, ei = SC.topk_rows(SC.dense_scores_fma(Q, D, SC.dense_korder(nq, h)), m)
+    assert np.array_equal(i[:, :m], ei) and np.array_equal(s[:, :m], es)
+    assert np.all(i[:, m:] == -1)
+    idx.close()
+
+
+@SET
+@given(st.integers(0, 2 ** 31 - 1), st.integers(1, 60), st.integers(1, 20000), st.floats(0.0, 0.3), st.integers(1, 40),
+       st.integers(1, 25), st.integers(1, 50), st.sampled_from([0.0, 0.7]))
+def test_sparse_search_random_shapes(seed, V, N, density, nq, nterms, k, threshold):
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(seed)
+    lists = [np.sort(rng.choice(N, size=rng.binomial(N, density), replace=False)).astype(np.int32) for _ in range(V)]
+    indptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+    doc_ids = np.concatenate(lists).astype(np.int32)
+    vals = (rng.random(len(doc_ids), dtype=np.float32) * 3).astype(np.float32)
+    nterms = min(nterms, V)
+    cols = np.concatenate([np.sort(rng.choice(V, size=nterms, replace=False)) for _ in range(nq)]).astype(np.int32)
+    qv = (rng.random(nq * nterms, dtype=np.float32) * 2).astype(np.float32)
+    q_indptr = np.arange(0, nq * nterms + 1, nterms, dtype=np.int64)
+    index = SparseIndexHIP(torch.from_numpy(indptr).cuda(), torch.from_numpy(doc_ids).cuda(), torch.from_numpy(vals).cuda(), N)
+    s, i, c = index.search(torch.from_numpy(q_indptr).cuda(), torch.from_numpy(cols).cuda(), torch.from_numpy(qv).cuda(), k,
+                           threshold=threshold)
+    oi, os_, oc = SC.sparse_retrieve_c(indptr, doc_ids, vals, q_indptr, cols, qv, k, threshold, N, q_threads=2)
+    s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
+    assert np.array_equal(c, oc)
+    for q in range(nq):
+        assert np.array_equal(i[q, :c[q]], oi[q, :c[q]]) and np.array_equal(s[q, :c[q]], os_[q, :c[q]])
+    index.close()
