@@ -97,3 +97,49 @@ def test_encoder_random_batches(tiny_models, seed, B, max_len, side):
         # row 0 alone (same padding inside its own row span) gives the same bits as inside the batch
         alone = model.doc_encode(input_ids=t_ids[:1].contiguous(), attention_mask=t_mask[:1].contiguous())
         assert torch.equal(alone[0], out[0])
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(1, 2600), st.integers(1, 40), st.integers(1, 12), st.sampled_from([0, 1, 2, 4]),
+       st.sampled_from(["", "", "128", "256", "split:256", "split:1024"]))
+def test_gemm_random_shapes(seed, M, n32, k64, epi, tile):
+    """sr_gemm_bf16 on random shapes (any M, N = 32 n, K = 64 k) for the store / residual / SwiGLU epilogues and every
+    tiling (automatic plan, forced tiles, forced row cuts) against a plain PyTorch fp32 reference of the same op."""
+    import os
+    from scaling_retriever_amd import _lib as L
+    lib = L.load()
+    old = os.environ.get("SR_GEMM_TILE")
+    os.environ["SR_GEMM_TILE"] = tile
+    try:
+        N, K = 32 * n32, 64 * k64
+        g = torch.Generator(device="cuda").manual_seed(seed % (2 ** 31))
+        A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+        W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+        ref = A.float() @ W.float().T
+        if epi == 0:
+            C = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        elif epi == 1:
+            C = torch.randn((M, N), device="cuda", generator=g)
+            want = C + ref
+        elif epi == 2:
+            C = torch.empty((M, N // 2), dtype=torch.bfloat16, device="cuda")
+        else:
+            C = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, epi, C.data_ptr(), None, L.stream_ptr()), "sr_gemm_bf16")
+        torch.cuda.synchronize()
+        if epi == 0:
+            torch.testing.assert_close(C.float(), ref, rtol=1e-2, atol=1e-2)
+        elif epi == 1:
+            torch.testing.assert_close(C, want, rtol=1e-4, atol=1e-4)
+        elif epi == 2:
+            # gate / up rows are interleaved in 16-row blocks: block 2b = gate rows, block 2b + 1 = up rows
+            y = ref.reshape(M, N // 32, 2, 16)
+            sw = (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, N // 2)
+            torch.testing.assert_close(C.float(), sw, rtol=2e-2, atol=2e-2)
+        else:
+            torch.testing.assert_close(C, ref, rtol=1e-4, atol=1e-4)
+    finally:
+        if old is None:
+            os.environ.pop("SR_GEMM_TILE", None)
+        else:
+            os.environ["SR_GEMM_TILE"] = old
