@@ -22,6 +22,9 @@ typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 
 #define AT_KC 256          // keys per LDS chunk
 #define AT_VT_LD (AT_KC + 4)  // padded row of the transposed V image (bf16 elements)
+#ifndef AT_IPW
+#define AT_IPW 2           // work items per wave of the fast path (8 per workgroup: 52 us per layer at 9.6 k tokens, 54 with 4, 67 with all)
+#endif
 
 union Frag8 {
     mfma_bf16x8 v;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void at
     if (S <= 0) return;
     const int G = a.nh / a.nkv;
     const int n_qt = (S + 31) / 32, n_items = G * n_qt, nkb = n_qt;
-    if ((int)blockIdx.z * 4 >= n_items) return;          // this sequence has fewer item groups than the longest one
+    if ((int)blockIdx.z * 4 * AT_IPW >= n_items) return;          // this sequence has fewer item groups than the longest one
     const int ldq = (a.nh + 2 * a.nkv) * HD;
     const int koff = a.nh * HD + kvh * HD;
     const int voff = (a.nh + a.nkv) * HD + kvh * HD;
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void at
     for (int key = tid; key < nkb * 32; key += 256) kval[key] = (key < S) ? a.key_valid[t0 + key] : 0;
     __syncthreads();
 
-    const int item = (int)blockIdx.z * 4 + wave;
-    if (item >= n_items) return;
-    {
+    for (int it = 0; it < AT_IPW; ++it) {
+        const int item = ((int)blockIdx.z * AT_IPW + it) * 4 + wave;
+        if (item >= n_items) break;
         const int qh = kvh * G + item / n_qt;
         const int q0 = (item % n_qt) * 32;
         int qrow = q0 + r;
@@ -403,7 +406,7 @@ static int launch_small(const AttnArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
-    const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 3) / 4));
+    const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 4 * AT_IPW - 1) / (4 * AT_IPW)));
     hipLaunchKernelGGL((attention_small_kernel<HD, MAXKB>), grid, dim3(256), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
