@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------
 // Fast path for sequences of at most 256 tokens (every MS MARCO batch: doc_max_length 192,
 // query_max_length 64) with q/k already rotated by the QKV GEMM epilogue.  A workgroup = (sequence, kv head, group of
-// 4 work items); a work item = (q head of the group, 32-row q tile), one per wave, with ALL score blocks of the row held
+// 4 * AT_IPW work items); a work item = (q head of the group, 32-row q tile), AT_IPW per wave, with ALL score blocks of the row held
 // in registers - one QK^T pass, exact softmax, no rescaling.  Work per sequence grows with S^2, so the items of a long
 // sequence are spread over several workgroups (each stages K and V^T of the sequence again - a few KB from L2) instead
 // of one workgroup walking them while the rest of the chip has finished.  MAXKB = key blocks (of 32) the batch needs:
