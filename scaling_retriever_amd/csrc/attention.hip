@@ -395,6 +395,173 @@ __global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void at
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sequences longer than 256 tokens (BEIR passages up to 512, anything up to the position table) with pre-rotated q/k:
+// the same work-item grid as the fast path, with the keys walked in chunks of 256 and the softmax kept online
+// (running row maximum m and sum l per q row; the O^T accumulators of a lane all belong to its q row, so a rescale is
+// one multiply per register).  P stays unnormalised (<= 1) when it is rounded to bf16 for the PV MFMA; the division by l
+// happens once at the end.  One work item per wave: the chunk loop is outermost because the 4 waves share the staged K/V^T.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(AttnArgs a) {
+    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = AT_KC / 32, KC = AT_KC, VT_LD = KC + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [KC][HD], chunk-swizzled
+    bf16_t* Vt = Ks + KC * HD;                          // [HD][VT_LD]
+    unsigned char* kval = reinterpret_cast<unsigned char*>(Vt + HD * VT_LD);
+
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = a.cu_seqlens[b];
+    const int S = a.cu_seqlens[b + 1] - t0;
+    if (S <= 0) return;
+    const int G = a.nh / a.nkv;
+    const int n_qt = (S + 31) / 32, n_items = G * n_qt;
+    if ((int)blockIdx.z * 4 >= n_items) return;          // uniform for the workgroup
+    const int ldq = (a.nh + 2 * a.nkv) * HD;
+    const int koff = a.nh * HD + kvh * HD;
+    const int voff = (a.nh + a.nkv) * HD + kvh * HD;
+    const float sc_log2 = a.scale * 1.4426950408889634f;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int item = (int)blockIdx.z * 4 + wave;
+    const bool live = item < n_items;                    // a wave without an item still takes part in staging and barriers
+    const int qh = kvh * G + (live ? item / n_qt : 0);
+    const int q0 = (live ? item % n_qt : 0) * 32;
+    int qrow = q0 + r;
+    qrow = qrow < S ? qrow : S - 1;
+    const bf16_t* qp = a.qkv + (int64_t)(t0 + qrow) * ldq + qh * HD;
+    Frag8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk].q = *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * h);
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) o[db][x] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int n_chunks = (S + KC - 1) / KC;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int key0 = ch * KC;
+        const int nkeys = (S - key0) < KC ? (S - key0) : KC;
+        const int nkb = (nkeys + 31) / 32;
+        __syncthreads();                                 // previous chunk fully consumed
+        for (int idx = tid; idx < nkb * 32 * NCH; idx += 256) {
+            const int key = idx / NCH, c = idx % NCH;
+            uint4 kx = uint4{0, 0, 0, 0};
+            Frag8 vx;
+            vx.q = uint4{0, 0, 0, 0};
+            if (key < nkeys) {
+                const bf16_t* base = a.qkv + (int64_t)(t0 + key0 + key) * ldq;
+                kx = *reinterpret_cast<const uint4*>(base + koff + c * 8);
+                vx.q = *reinterpret_cast<const uint4*>(base + voff + c * 8);
+            }
+            *reinterpret_cast<uint4*>(Ks + key * HD + ((c ^ (key & 7)) * 8)) = kx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VT_LD + key] = vx.u[j];
+        }
+        for (int key = tid; key < nkb * 32; key += 256) kval[key] = (key < nkeys) ? a.key_valid[t0 + key0 + key] : 0;
+        __syncthreads();
+        if (!live) continue;
+
+        f32x16 st[MAXKB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+                f32x16 acc;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                const int key = kb * 32 + r;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    Frag8 kf;
+                    kf.q = *reinterpret_cast<const uint4*>(Ks + key * HD + (((2 * kk + h) ^ (key & 7)) * 8));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[kk].v, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int kl = kb * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                    const float v = kval[kl] ? acc[x] * sc_log2 : -INFINITY;
+                    acc[x] = v;
+                    mx = fmaxf(mx, v);
+                }
+                st[kb] = acc;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run > -INFINITY) ? __builtin_amdgcn_exp2f(m_run - m_new) : 0.f;   // o and l are 0 while m_run = -inf
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const float p = (m_new > -INFINITY) ? __builtin_amdgcn_exp2f(st[kb][x] - m_new) : 0.f;
+                    st[kb][x] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) o[db][x] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            if (kb < nkb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Frag8 pf;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) pf.w[w] = pack_bf16x2(st[kb][8 * s2 + 2 * w], st[kb][8 * s2 + 2 * w + 1]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        Frag8 vf;
+                        const bf16_t* vp = Vt + (db * 32 + r) * VT_LD + kb * 32 + 16 * s2 + 4 * h;
+                        vf.d2[0] = *reinterpret_cast<const uint2*>(vp);
+                        vf.d2[1] = *reinterpret_cast<const uint2*>(vp + 8);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);   // O^T: see the fast path
+                    }
+                }
+            }
+        }
+    }
+    if (live && q0 + r < S) {
+        const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t* orow = a.out + (int64_t)(t0 + q0 + r) * (a.nh * HD) + qh * HD + 4 * h;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (short)f32_to_bf16(o[db][4 * gq + e] * inv_l);
+                *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * gq) = v;
+            }
+    }
+}
+
+template <int HD>
+static int launch_long(const AttnArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)AT_KC * HD * 2 + (size_t)HD * (AT_KC + 4) * 2 + AT_KC;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_long_kernel<HD>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
+    const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 3) / 4));
+    hipLaunchKernelGGL((attention_long_kernel<HD>), grid, dim3(256), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 template <int HD, int MAXKB>
 static int launch_small(const AttnArgs& a, hipStream_t s) {
     constexpr int KC = MAXKB * 32;
@@ -429,6 +596,7 @@ static int launch_hd(const AttnArgs& a, hipStream_t s) {
         if (a.max_seqlen <= 192) return launch_small<HD, 6>(a, s);
         return launch_small<HD, 8>(a, s);
     }
+    if (!a.apply_rope && a.max_seqlen > AT_KC) return launch_long<HD>(a, s);
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv);
     if (a.apply_rope) hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), lds, s, a);

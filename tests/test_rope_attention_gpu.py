@@ -74,8 +74,11 @@ def _attn_ref(qkv, lens, key_valid, nh, nkv, hd):
     (2, 1, 128, [70, 3, 129, 255]),
     (8, 1, 64, [100, 31]),
     (2, 2, 64, [5]),
-    (4, 1, 64, [300, 40]),                     # general path (a sequence > 256), q/k pre-rotated
+    (4, 1, 64, [300, 40]),                     # chunked online-softmax path (a sequence > 256), q/k pre-rotated
     (2, 1, 128, [257]),
+    (32, 8, 64, [512, 300, 5, 256]),           # BEIR-length passages next to short ones
+    (8, 2, 128, [700, 33]),                    # three key chunks
+    (4, 4, 64, [513]),
 ])
 def test_attention_prerotated_inputs(nh, nkv, hd, lens):
     L, lib = _lib()
