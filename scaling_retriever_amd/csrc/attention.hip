@@ -17,6 +17,7 @@
 // pass 2 = recompute scores, p = exp(s - m) / l, accumulate O.  Attention is ~1 % of the
 // encoder FLOPs at S <= 192, so the second QK^T is cheaper than rescaling O.
 #include "kernels.h"
+#include <stdlib.h>
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -401,9 +402,13 @@ __global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void at
 // (running row maximum m and sum l per q row; the O^T accumulators of a lane all belong to its q row, so a rescale is
 // one multiply per register).  P stays unnormalised (<= 1) when it is rounded to bf16 for the PV MFMA; the division by l
 // happens once at the end.  One work item per wave: the chunk loop is outermost because the 4 waves share the staged K/V^T.
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attention_long_kernel(AttnArgs a) {
-    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = AT_KC / 32, KC = AT_KC, VT_LD = KC + 4;
+// CKB = key blocks (of 32) per chunk: it sizes the LDS image (4 * HD * 32 * CKB bytes) and the score registers, i.e. how
+// many workgroups share a CU: 8 for head dim 64; 2 for head dim 128 (33 KB), where a 256-key image (131 KB) would leave one
+// workgroup per CU - there this kernel also serves the short sequences (128 us per layer at 8B dims and 9.6 k tokens against
+// 745 us for the all-keys-in-registers kernel at one workgroup per CU).
+template <int HD, int CKB>
+__global__ __launch_bounds__(256, CKB <= 3 ? 3 : 2) void attention_long_kernel(AttnArgs a) {
+    constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = CKB, KC = CKB * 32, VT_LD = KC + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [KC][HD], chunk-swizzled
     bf16_t* Vt = Ks + KC * HD;                          // [HD][VT_LD]
@@ -546,18 +551,19 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(AttnArgs a) {
     }
 }
 
-template <int HD>
+template <int HD, int CKB>
 static int launch_long(const AttnArgs& a, hipStream_t s) {
-    constexpr size_t lds = (size_t)AT_KC * HD * 2 + (size_t)HD * (AT_KC + 4) * 2 + AT_KC;
+    constexpr int KC = CKB * 32;
+    constexpr size_t lds = (size_t)KC * HD * 2 + (size_t)HD * (KC + 4) * 2 + KC;
     static bool attr_set = false;
     if (!attr_set) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_long_kernel<HD>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_long_kernel<HD, CKB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 3) / 4));
-    hipLaunchKernelGGL((attention_long_kernel<HD>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attention_long_kernel<HD, CKB>), grid, dim3(256), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -590,13 +596,22 @@ static int launch_hd(const AttnArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    if constexpr (HD == 128) {
+        if (!a.apply_rope && a.max_seqlen > 64) {
+            const char* e = getenv("SR_ATTN_CKB");      // A/B switch: key blocks per chunk for head dim 128 (2 | 3 | 8)
+            const int ckb = e ? atoi(e) : 2;
+            if (ckb == 2) return launch_long<HD, 2>(a, s);
+            if (ckb == 3) return launch_long<HD, 3>(a, s);
+            if (a.max_seqlen > AT_KC) return launch_long<HD, 8>(a, s);
+        }
+    }
     if (!a.apply_rope && a.max_seqlen > 0 && a.max_seqlen <= AT_KC) {
         if (a.max_seqlen <= 64) return launch_small<HD, 2>(a, s);
         if (a.max_seqlen <= 128) return launch_small<HD, 4>(a, s);
         if (a.max_seqlen <= 192) return launch_small<HD, 6>(a, s);
         return launch_small<HD, 8>(a, s);
     }
-    if (!a.apply_rope && a.max_seqlen > AT_KC) return launch_long<HD>(a, s);
+    if (!a.apply_rope && a.max_seqlen > AT_KC) return launch_long<HD, 8>(a, s);
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv);
     if (a.apply_rope) hipLaunchKernelGGL((attention_kernel<HD, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((attention_kernel<HD, false>), grid, dim3(256), lds, s, a);
