@@ -7,6 +7,7 @@
 //   256(n) x 256(m), 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS, 1 workgroup per CU, software-pipelined k-loop:
 //       half the L2->LDS bytes per FLOP of the small tile; runs whole rounds of 256 tiles (see the tile plan below)
 //   128(n) x 128(m), 4 waves (2 x 2), wave tile 64 x 64, 64 KB LDS, 2 workgroups per CU: small problems and ragged tails
+//    64(n) x 16/32/64(m), ONE wave, four LDS stages: up to 64 token rows (online queries) - the work is streaming W once
 //   128(n) x  64(m), 4 waves, three 24 KB LDS stages (LDS-DMA issued three k-steps ahead, counted vmcnt before a bare
 //       s_barrier), 2 workgroups per CU: tails of fewer than 384 tiles
 // The WEIGHT tile is the MFMA A operand and the activation tile the B operand, so an
@@ -511,7 +512,9 @@ static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     if (const char* e = getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
     const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
-    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (int64_t)((160 * 1024) / lds > 3 ? 3 : (160 * 1024) / lds) : 1);   // resident workgroups on 256 CUs
+    // resident workgroups on 256 CUs: one 8-wave workgroup, up to 3 of 4 waves, up to 8 single-wave ones (LDS permitting)
+    constexpr int64_t by_lds = (160 * 1024) / lds;
+    const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (by_lds > 3 ? 3 : by_lds) : (WAVES_N * WAVES_M == 1 ? (by_lds > 8 ? 8 : by_lds) : 1));
     if (!(env && *env == '0') && tiles > slots) tiles = slots;
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
@@ -608,12 +611,40 @@ static GemmArgs rows_from(const GemmArgs& g, int row0) {
     return t;
 }
 
+// token rows up to which the single-wave streaming configurations are used (SR_GEMM_SKINNY = 0 disables, = n overrides)
+static int skinny_max_rows() {
+    const char* e = getenv("SR_GEMM_SKINNY");
+    if (!e || !*e) return 64;
+    return atoi(e);
+}
+
 template <int EPI>
 static int launch_one(const GemmArgs& g, hipStream_t s) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
+    }
+    if (g.M <= skinny_max_rows() && g.K / G_BK >= 4) {
+        if (g.M > 32) {
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 4, true, 3>(g, s);
+            }
+            return launch_cfg<EPI, 1, 1, 4, 4, true, 4>(g, s);
+        }
+        if (g.M > 16) {
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 2, true, 4>(g, s);
+            }
+            return launch_cfg<EPI, 1, 1, 4, 2, true, 4>(g, s);
+        }
+        // A handful of tokens (online queries): the work is streaming W once.  One WAVE per workgroup owns 64 features x 16
+        // tokens (N / 64 independent workgroups instead of N / 128 four-wave ones idling on a 16-token tile), four 10 KB LDS
+        // stages keep three k-steps of weights in flight per wave.  Same MFMA chain per output element as every other tile.
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 1, true, 4>(g, s);
+        }
+        return launch_cfg<EPI, 1, 1, 4, 1, true, 4>(g, s);
     }
     {
         const int big_rows = plan_big_rows(g, true);
