@@ -433,3 +433,26 @@ def test_gemm_tile_plan_does_not_change_the_result(monkeypatch):
     for tile in ("128", "256", "split:4096"):
         monkeypatch.setenv("SR_GEMM_TILE", tile)
         assert torch.equal(_gemm(A, W, 4), auto), tile
+
+
+@pytest.mark.parametrize("M", [1, 9, 16, 17, 33, 64])
+def test_gemm_few_token_rows_streaming_configuration(M, monkeypatch):
+    """Up to 64 token rows (online queries) run single-wave workgroups that stream W; every output element is the same
+    MFMA chain as in the tiled configurations: bit-identical for the store, residual, SwiGLU and per-sequence-max epilogues."""
+    g = torch.Generator(device="cuda").manual_seed(M)
+    N, K = 640, 512
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    X = torch.randn((M, N), device="cuda", generator=g)
+    seq = (torch.arange(M) // 5).int().cuda()
+    n_seq = int(seq.max().item()) + 1
+
+    def run_all():
+        return [_gemm(A, W, 4), _gemm(A, W, 0), _gemm(A, W, 2), _gemm(A, W, 1, C=X.clone()),
+                _gemm(A, W, 3, seq_of=seq, n_seq=n_seq)]
+    got = run_all()
+    monkeypatch.setenv("SR_GEMM_SKINNY", "0")
+    want = run_all()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(got[0], A.float() @ W.float().T, rtol=1e-4, atol=1e-4)
