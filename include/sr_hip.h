@@ -143,6 +143,9 @@ typedef struct {
     int32_t has_lm_head;              /* 0: LlamaBiModel (dense), 1: LlamaBiForMNTP (sparse) */
     int32_t max_batch_tokens;         /* workspace sizing: max packed tokens per encode call */
     int32_t max_batch_seqs;
+    int32_t fp32_planes;              /* fp32 regime (sr_encode_*_fp32): 0 = not available, 3 = every weight also kept as
+                                         three bf16 planes (the whole fp32 significand, 6 plane products per GEMM),
+                                         2 = two planes / 3 products (~2^-17 relative per product, half the work)   */
 } sr_model_config;
 
 int sr_model_create(sr_model** out, const sr_model_config* cfg);
@@ -160,6 +163,16 @@ int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_at
 /* d_out: fp32 [B, vocab]. */
 int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
                      int32_t B, int32_t L, float* d_out, sr_stream stream);
+/* The two calls above are the reference's torch.autocast(bf16) regime (documents: indexer.py:46-52,
+ * :255-256; sparse queries: :390-391): bf16 GEMM inputs, fp32 accumulation, fp32 everything else.
+ * The _fp32 variants are its NO-autocast regime - dense queries (eval_dense.py:94-106, no autocast at
+ * :101-102) and examples/quick_start.py: every nn.Linear is an fp32 GEMM and SDPA runs on fp32
+ * operands.  Same arguments and outputs; needs a model created with fp32_planes > 0
+ * (SR_ERR_INVALID otherwise).                                                */
+int sr_encode_dense_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
+                         int32_t B, int32_t L, float* d_out, sr_stream stream);
+int sr_encode_sparse_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
+                          int32_t B, int32_t L, float* d_out, sr_stream stream);
 /* Debug/test hook: last_hidden_state (after the final norm) of the packed
  * tokens of the last encode call, fp32 [n_tokens, hidden]; returns n_tokens
  * through *n_tokens.                                                         */

@@ -25,7 +25,7 @@ class SrModelConfig(ctypes.Structure):
         ("rms_norm_eps", c_float), ("rope_theta", c_float), ("rope_llama3", c_int32),
         ("rope_factor", c_float), ("rope_low_freq_factor", c_float), ("rope_high_freq_factor", c_float),
         ("rope_original_max_pos", c_int32), ("tie_word_embeddings", c_int32), ("has_lm_head", c_int32),
-        ("max_batch_tokens", c_int32), ("max_batch_seqs", c_int32),
+        ("max_batch_tokens", c_int32), ("max_batch_seqs", c_int32), ("fp32_planes", c_int32),
     ]
 
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "sr_model_finalize": (c_int, [c_void_p]),
     "sr_encode_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "sr_encode_sparse": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "sr_encode_dense_fp32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "sr_encode_sparse_fp32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "sr_model_last_hidden": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     "sr_model_destroy": (c_int, [c_void_p]),
     "sr_lora_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),

@@ -1,0 +1,123 @@
+// fp32 bidirectional GQA attention over packed var-len sequences (gfx950) - the fp32 regime of the encoder.
+//
+// The reference encodes dense queries WITHOUT autocast (eval_dense.py:94-106): SDPA then runs on fp32 q/k/v with an
+// fp32 softmax (math path; the float mask of scaling_retriever/modeling/bidirectional_llama.py:138-161 rules out the
+// flash kernel).  Attention is ~1 % of the encoder's FLOPs and the fp32 regime is the query side (sequences of ~9
+// tokens, 64 at most), so this kernel is plain fp32 FMA work, not MFMA:
+//   workgroup = (sequence, q head, block of 16 q rows); its 4 waves own 4 q rows each.
+//   keys are walked in chunks of 64: the K chunk is staged once in LDS ([64][hd + 1] floats: a lane = one key reads
+//   its row conflict-free, q is a broadcast read), scores / softmax are lane-local + wave reductions, the softmax is
+//   carried online across chunks (running max and sum per q row), and P.V reads V rows straight from global memory
+//   (lane = head dim: coalesced), p broadcast from LDS.
+// q/k arrive rotated (RoPE is fused into the QKV GEMM epilogue).  The output is stored as the split-bf16 plane
+// segments the o_proj GEMM consumes (kernels.h: SplitMap).
+#include "kernels.h"
+#include <math.h>
+
+#define AF_KC 64      // keys per chunk
+#define AF_RPW 4      // q rows per wave
+#define AF_ROWS 16    // q rows per workgroup
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_f32_kernel(AttnF32Args a) {
+    constexpr int DPL = HD / 64;                     // head dims per lane
+    __shared__ float Ks[AF_KC][HD + 1];
+    __shared__ float qs[AF_ROWS][HD];
+    __shared__ float ps[AF_ROWS][AF_KC];
+    __shared__ unsigned char kval[AF_KC];
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = a.cu_seqlens[b];
+    const int S = a.cu_seqlens[b + 1] - t0;
+    const int r0 = blockIdx.z * AF_ROWS;
+    if (r0 >= S) return;
+    const int G = a.nh / a.nkv, kvh = h / G;
+    const int ld = (a.nh + 2 * a.nkv) * HD;
+    const int koff = a.nh * HD + kvh * HD, voff = (a.nh + a.nkv) * HD + kvh * HD;
+    const int nrows = (S - r0) < AF_ROWS ? (S - r0) : AF_ROWS;
+
+    for (int i = tid; i < nrows * HD; i += 256) {
+        const int r = i / HD, d = i % HD;
+        qs[r][d] = a.qkv[(int64_t)(t0 + r0 + r) * ld + h * HD + d];
+    }
+    float m[AF_RPW], l[AF_RPW], o[AF_RPW][DPL];
+#pragma unroll
+    for (int r = 0; r < AF_RPW; ++r) {
+        m[r] = -INFINITY;
+        l[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[r][e] = 0.f;
+    }
+    for (int k0 = 0; k0 < S; k0 += AF_KC) {
+        const int nk = (S - k0) < AF_KC ? (S - k0) : AF_KC;
+        __syncthreads();                              // previous chunk fully consumed (and qs visible)
+        for (int i = tid; i < nk * HD; i += 256) {
+            const int k = i / HD, d = i % HD;
+            Ks[k][d] = a.qkv[(int64_t)(t0 + k0 + k) * ld + koff + d];
+        }
+        if (tid < AF_KC) kval[tid] = (tid < nk) ? a.key_valid[t0 + k0 + tid] : 0;
+        __syncthreads();
+        const bool valid = kval[lane] != 0;
+#pragma unroll
+        for (int r = 0; r < AF_RPW; ++r) {
+            const int row = wave * AF_RPW + r;      // wave-uniform
+            if (row >= nrows) break;
+            float s = 0.f;
+            for (int d = 0; d < HD; ++d) s += qs[row][d] * Ks[lane][d];
+            s = valid ? s * a.scale : -INFINITY;
+            float mx = s;
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if (mx == -INFINITY) continue;          // every key of this chunk is masked
+            const float m_new = fmaxf(m[r], mx);
+            const float corr = expf(m[r] - m_new);  // 0 on the first chunk (m = -inf)
+            const float p = valid ? expf(s - m_new) : 0.f;
+            float sum = p;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            l[r] = l[r] * corr + sum;
+            m[r] = m_new;
+            ps[row][lane] = p;                      // same wave writes and reads this row: no barrier needed
+            __builtin_amdgcn_wave_barrier();
+            float acc[DPL];
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
+            for (int k = 0; k < nk; ++k) {
+                const float pk = ps[row][k];
+                const float* vrow = a.qkv + (int64_t)(t0 + k0 + k) * ld + voff;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc[e] += pk * vrow[lane + 64 * e];
+            }
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) o[r][e] = o[r][e] * corr + acc[e];
+        }
+    }
+    const int64_t ldo = (int64_t)a.out_map.n_seg * a.nh * HD;
+#pragma unroll
+    for (int r = 0; r < AF_RPW; ++r) {
+        const int row = wave * AF_RPW + r;
+        if (row >= nrows) break;
+        const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+        bf16_t* orow = a.out + (int64_t)(t0 + r0 + row) * ldo;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            unsigned short p[3];
+            split_bf16x3(o[r][e] * inv, p[0], p[1], p[2]);
+            const int col = h * HD + lane + 64 * e;
+            for (int sg = 0; sg < a.out_map.n_seg; ++sg) orow[(int64_t)sg * a.nh * HD + col] = p[a.out_map.plane[sg]];
+        }
+    }
+}
+
+int launch_attention_f32(const AttnF32Args& a, hipStream_t s) {
+    SR_REQUIRE(a.nh % a.nkv == 0, "attention(fp32): num_heads %d not a multiple of num_kv_heads %d", a.nh, a.nkv);
+    SR_REQUIRE(a.out_map.n_seg >= 1 && a.out_map.n_seg <= SR_MAX_SEG, "attention(fp32): bad segment map");
+    if (a.B == 0 || a.max_seqlen <= 0) return SR_OK;
+    const dim3 grid((unsigned)a.B, (unsigned)a.nh, (unsigned)ceil_div64(a.max_seqlen, AF_ROWS)), block(256);
+    SR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "attention(fp32): grid too large");
+    switch (a.hd) {
+        case 64: hipLaunchKernelGGL(attention_f32_kernel<64>, grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL(attention_f32_kernel<128>, grid, block, 0, s, a); break;
+        default: sr_set_error("attention(fp32): head_dim %d not supported (64 or 128)", a.hd); return SR_ERR_UNSUPPORTED;
+    }
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}

@@ -65,6 +65,15 @@ __device__ inline unsigned short f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// fp32 -> three bf16 planes, x = p0 + p1 + p2 up to 2^-27 |x| (each residual subtraction is exact in fp32)
+__device__ inline void split_bf16x3(float v, unsigned short& p0, unsigned short& p1, unsigned short& p2) {
+    p0 = f32_to_bf16(v);
+    const float r1 = v - bf16_to_f32(p0);
+    p1 = f32_to_bf16(r1);
+    const float r2 = r1 - bf16_to_f32(p1);
+    p2 = f32_to_bf16(r2);
+}
+
 // ---- fused top-k workspace shared by the dense and sparse scorers ----
 struct TopkWS {
     int64_t nq_cap = 0;      // allocated queries

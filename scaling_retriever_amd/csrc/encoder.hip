@@ -285,6 +285,60 @@ __global__ void convert_rows_kernel(const void* __restrict__ src, int src_dtype,
     }
 }
 
+// fp32 regime: the same rows as split-bf16 plane segments, dst[row_map(r)][sg * cols + c] = plane_{map.plane[sg]}(src[r][c])
+__global__ void convert_rows_split_kernel(const void* __restrict__ src, int src_dtype, int64_t rows, int64_t cols,
+                                          bf16_t* __restrict__ dst, int64_t dst_row_base, int interleave, SplitMap map) {
+    const int64_t r = blockIdx.x;
+    int64_t dr = r;
+    if (interleave) dr = (r / 16) * 32 + (interleave == 2 ? 16 : 0) + (r % 16);
+    dr += dst_row_base;
+    bf16_t* drow = dst + dr * cols * map.n_seg;
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) {
+        float v;
+        if (src_dtype == SR_DTYPE_F32) v = reinterpret_cast<const float*>(src)[r * cols + c];
+        else v = bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[r * cols + c]);
+        unsigned short p[3];
+        split_bf16x3(v, p[0], p[1], p[2]);
+        for (int sg = 0; sg < map.n_seg; ++sg) drow[(int64_t)sg * cols + c] = p[map.plane[sg]];
+    }
+}
+
+// ---- RMSNorm of the fp32 regime: one wave per token, output as split-bf16 plane segments [T, n_seg * H] -------
+// x[t] = embed[tok_id[t]] (if embed);  y = (x * rsqrt(mean(x^2) + eps)) * w in fp32 (HF LlamaRMSNorm on fp32 input)
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* __restrict__ x, const float* __restrict__ embed,
+                                                            const int* __restrict__ tok_id, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ xs, int T, int H, float eps, SplitMap map) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float* xr = x + (int64_t)t * H;
+    const float* src = embed ? embed + (int64_t)tok_id[t] * H : xr;
+    float ss = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if (embed) *reinterpret_cast<f32x4*>(xr + i) = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+    bf16_t* orow = xs + (int64_t)t * H * map.n_seg;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(w + i);
+        bf16x4 pl[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned short a0, a1, a2;
+            split_bf16x3((v[c] * rs) * g[c], a0, a1, a2);
+            pl[0][c] = (short)a0; pl[1][c] = (short)a1; pl[2][c] = (short)a2;
+        }
+        for (int sg = 0; sg < map.n_seg; ++sg) {
+            const int pi = map.plane[sg];
+            *reinterpret_cast<bf16x4*>(orow + (int64_t)sg * H + i) = pi == 0 ? pl[0] : (pi == 1 ? pl[1] : pl[2]);
+        }
+    }
+}
+
 // ---- LoRA merge: W += scale * B @ A -----------------------------------------------------
 __global__ void lora_merge_kernel(float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
                                   int64_t out_f, int64_t in_f, int r, float scale) {
@@ -349,6 +403,8 @@ struct LayerW {
     float* ln1 = nullptr;     // [H]
     float* ln2 = nullptr;     // [H]
     unsigned have = 0;        // bit per tensor: q k v o gate up down ln1 ln2
+    // fp32 regime (cfg.fp32_planes > 0): the same matrices as split-bf16 plane segments along K, [rows, n_seg * K]
+    bf16_t *wqkv_s = nullptr, *wo_s = nullptr, *wgu_s = nullptr, *wdown_s = nullptr;
 };
 
 struct sr_model {
@@ -357,6 +413,12 @@ struct sr_model {
     int max_pos = 0;
     float* embed = nullptr;    // fp32 [V, H]
     bf16_t* lm_head = nullptr; // bf16 [V, H] (sparse head)
+    bf16_t* lm_head_s = nullptr;   // fp32 regime: [V, n_seg * H] plane segments
+    // fp32-regime workspace, allocated by the first fp32 encode call
+    bf16_t* xs = nullptr;      // [Tm, n_seg * H]    normed hidden state, plane segments
+    float* qkv_f = nullptr;    // [Tm, (nh + 2 nkv) hd] rotated q/k/v, fp32
+    bf16_t* attn_s = nullptr;  // [Tm, n_seg * nh hd]
+    bf16_t* act_s = nullptr;   // [Tm, n_seg * I]
     float* norm_w = nullptr;   // [H]
     std::vector<LayerW> layers;
     bool have_embed = false, have_norm = false, have_lm_head = false, finalized = false;
@@ -381,7 +443,8 @@ struct sr_model {
 static void model_free(sr_model* m) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(m->embed); F(m->lm_head); F(m->norm_w); F(m->rope_cos); F(m->rope_sin);
-    for (auto& l : m->layers) { F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); }
+    F(m->lm_head_s); F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s);
+    for (auto& l : m->layers) { F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); F(l.wqkv_s); F(l.wo_s); F(l.wgu_s); F(l.wdown_s); }
     F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act); F(m->delta);
     F(m->span_start); F(m->span_len); F(m->pool_start); F(m->row_len); F(m->cu);
     F(m->tok_id); F(m->pos); F(m->seq_of); F(m->key_valid);
@@ -441,6 +504,7 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
                "sr_model_create: hidden_size and intermediate_size must be multiples of 64");
     SR_REQUIRE(c.vocab_size % 16 == 0 || !c.has_lm_head, "sr_model_create: vocab_size must be a multiple of 16 for the sparse head");
     SR_REQUIRE(c.max_batch_tokens > 0 && c.max_batch_seqs > 0 && c.max_batch_seqs <= 65536, "sr_model_create: bad workspace sizes");
+    SR_REQUIRE(c.fp32_planes == 0 || c.fp32_planes == 2 || c.fp32_planes == 3, "sr_model_create: fp32_planes must be 0, 2 or 3");
     sr_model* m = new sr_model();
     m->cfg = c;
     m->Tm = (int)(ceil_div64(c.max_batch_tokens, 128) * 128);
@@ -451,12 +515,20 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
     const int64_t nq = (int64_t)c.num_heads * c.head_dim, nkv = (int64_t)c.num_kv_heads * c.head_dim;
     SR_ALLOC(m->embed, V * H * 4);
     if (c.has_lm_head) SR_ALLOC(m->lm_head, V * H * 2);
+    const int64_t nsg = c.fp32_planes ? split_map_w(c.fp32_planes).n_seg : 0;
+    if (c.has_lm_head && nsg) SR_ALLOC(m->lm_head_s, V * H * 2 * nsg);
     SR_ALLOC(m->norm_w, H * 4);
     for (auto& l : m->layers) {
         SR_ALLOC(l.wqkv, (nq + 2 * nkv) * H * 2);
         SR_ALLOC(l.wo, H * nq * 2);
         SR_ALLOC(l.wgu, 2 * I * H * 2);
         SR_ALLOC(l.wdown, H * I * 2);
+        if (nsg) {
+            SR_ALLOC(l.wqkv_s, (nq + 2 * nkv) * H * 2 * nsg);
+            SR_ALLOC(l.wo_s, H * nq * 2 * nsg);
+            SR_ALLOC(l.wgu_s, 2 * I * H * 2 * nsg);
+            SR_ALLOC(l.wdown_s, H * I * 2 * nsg);
+        }
         SR_ALLOC(l.ln1, H * 4);
         SR_ALLOC(l.ln2, H * 4);
     }
@@ -510,9 +582,12 @@ extern "C" int sr_model_destroy(sr_model* m) {
 }
 
 static int convert_rows(const void* src, int dtype, int64_t rows, int64_t cols, bf16_t* dbf, float* df32, int64_t base,
-                        int interleave, hipStream_t s) {
+                        int interleave, hipStream_t s, bf16_t* dsplit = nullptr, int planes = 0) {
     hipLaunchKernelGGL(convert_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dbf, df32, base,
                        interleave);
+    if (dsplit && planes)
+        hipLaunchKernelGGL(convert_rows_split_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dsplit, base,
+                           interleave, split_map_w(planes));
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -531,7 +606,8 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
 #define SHAPE_REQ(r, cc) SR_REQUIRE(shape_is((r), (cc)), "sr_model_set_weight: %s has shape [%lld, %lld], expected [%lld, %lld]", name, (long long)rows, (long long)cols, (long long)(r), (long long)(cc))
     if (n == "model.embed_tokens.weight") {
         SHAPE_REQ(V, H);
-        SR_TRY(convert_rows(d_ptr, dtype, V, H, (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head : nullptr, m->embed, 0, 0, s));
+        SR_TRY(convert_rows(d_ptr, dtype, V, H, (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head : nullptr, m->embed, 0, 0, s,
+                            (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head_s : nullptr, c.fp32_planes));
         m->have_embed = true;
         if (c.has_lm_head && c.tie_word_embeddings) m->have_lm_head = true;
         return SR_OK;
@@ -539,7 +615,7 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
     if (n == "lm_head.weight") {
         SR_REQUIRE(c.has_lm_head, "sr_model_set_weight: model was created without an lm_head");
         SHAPE_REQ(V, H);
-        SR_TRY(convert_rows(d_ptr, dtype, V, H, m->lm_head, nullptr, 0, 0, s));
+        SR_TRY(convert_rows(d_ptr, dtype, V, H, m->lm_head, nullptr, 0, 0, s, m->lm_head_s, c.fp32_planes));
         m->have_lm_head = true;
         return SR_OK;
     }
@@ -554,13 +630,13 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
     if (sscanf(name, "model.layers.%d.%127s", &li, rest) == 2 && li >= 0 && li < c.num_layers) {
         LayerW& l = m->layers[li];
         std::string r(rest);
-        if (r == "self_attn.q_proj.weight") { SHAPE_REQ(nq, H); SR_TRY(convert_rows(d_ptr, dtype, nq, H, l.wqkv, nullptr, 0, 0, s)); l.have |= 1; return SR_OK; }
-        if (r == "self_attn.k_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq, 0, s)); l.have |= 2; return SR_OK; }
-        if (r == "self_attn.v_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq + nkv, 0, s)); l.have |= 4; return SR_OK; }
-        if (r == "self_attn.o_proj.weight") { SHAPE_REQ(H, nq); SR_TRY(convert_rows(d_ptr, dtype, H, nq, l.wo, nullptr, 0, 0, s)); l.have |= 8; return SR_OK; }
-        if (r == "mlp.gate_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 1, s)); l.have |= 16; return SR_OK; }
-        if (r == "mlp.up_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 2, s)); l.have |= 32; return SR_OK; }
-        if (r == "mlp.down_proj.weight") { SHAPE_REQ(H, I); SR_TRY(convert_rows(d_ptr, dtype, H, I, l.wdown, nullptr, 0, 0, s)); l.have |= 64; return SR_OK; }
+        if (r == "self_attn.q_proj.weight") { SHAPE_REQ(nq, H); SR_TRY(convert_rows(d_ptr, dtype, nq, H, l.wqkv, nullptr, 0, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 1; return SR_OK; }
+        if (r == "self_attn.k_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 2; return SR_OK; }
+        if (r == "self_attn.v_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq + nkv, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 4; return SR_OK; }
+        if (r == "self_attn.o_proj.weight") { SHAPE_REQ(H, nq); SR_TRY(convert_rows(d_ptr, dtype, H, nq, l.wo, nullptr, 0, 0, s, l.wo_s, c.fp32_planes)); l.have |= 8; return SR_OK; }
+        if (r == "mlp.gate_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 1, s, l.wgu_s, c.fp32_planes)); l.have |= 16; return SR_OK; }
+        if (r == "mlp.up_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 2, s, l.wgu_s, c.fp32_planes)); l.have |= 32; return SR_OK; }
+        if (r == "mlp.down_proj.weight") { SHAPE_REQ(H, I); SR_TRY(convert_rows(d_ptr, dtype, H, I, l.wdown, nullptr, 0, 0, s, l.wdown_s, c.fp32_planes)); l.have |= 64; return SR_OK; }
         if (r == "input_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln1, 0, 0, s)); l.have |= 128; return SR_OK; }
         if (r == "post_attention_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln2, 0, 0, s)); l.have |= 256; return SR_OK; }
     }
@@ -581,14 +657,55 @@ extern "C" int sr_model_finalize(sr_model* m) {
 }
 
 // --------------------------------------------------------------- forward ------
-static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mask, int B, int L, int mode, hipStream_t s,
-                         int* T_out) {
+// Precision regimes:
+//   PREC_BF16  torch.autocast(bf16): documents (indexer.py:46-52, :255-256) and sparse queries (:390-391)
+//   PREC_FP32  no autocast: dense queries (eval_dense.py:94-106) and examples/quick_start.py - every nn.Linear is an fp32
+//              GEMM there.  Here each GEMM runs on the bf16 MFMA pipe over split-bf16 planes of BOTH operands
+//              (kernels.h: SplitMap; 3 planes / 6 products carry the full 24-bit significands, fp32 accumulate), the
+//              activations between GEMMs stay fp32 (residual stream, rotated q/k/v, softmax, SwiGLU) and are split into
+//              planes by the kernel that produces them.
+enum { PREC_BF16 = 0, PREC_FP32 = 1 };
+
+static int ensure_fp32_workspace(sr_model* m) {
+    if (m->xs) return SR_OK;
+    const sr_model_config& c = m->cfg;
+    SR_REQUIRE(c.fp32_planes > 0, "encode(fp32): the model was created with fp32_planes = 0 (bf16 regime only)");
+    const int64_t Tm = m->Tm, H = c.hidden_size, I = c.intermediate_size;
+    const int64_t nq = (int64_t)c.num_heads * c.head_dim, nkv = (int64_t)c.num_kv_heads * c.head_dim;
+    const int64_t nsg = split_map_a(c.fp32_planes).n_seg;
+    auto A = [&](void** p, int64_t bytes) {
+        if (hipMalloc(p, (size_t)bytes) != hipSuccess) { *p = nullptr; return false; }
+        return hipMemset(*p, 0, (size_t)bytes) == hipSuccess;
+    };
+    if (!A((void**)&m->xs, Tm * H * 2 * nsg) || !A((void**)&m->qkv_f, Tm * (nq + 2 * nkv) * 4) ||
+        !A((void**)&m->attn_s, Tm * nq * 2 * nsg) || !A((void**)&m->act_s, Tm * I * 2 * nsg)) {
+        auto F = [](void* p) { if (p) (void)hipFree(p); };
+        F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s);
+        m->xs = nullptr; m->qkv_f = nullptr; m->attn_s = nullptr; m->act_s = nullptr;
+        sr_set_error("encode(fp32): hipMalloc of the fp32-regime workspace failed (%lld tokens)", (long long)Tm);
+        return SR_ERR_NOMEM;
+    }
+    return SR_OK;
+}
+
+static int launch_rmsnorm_split(float* x, const float* embed, const int* tok_id, const float* w, bf16_t* xs, int T, int H,
+                                float eps, const SplitMap& map, hipStream_t s) {
+    if (T == 0) return SR_OK;
+    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, x, embed, tok_id, w, xs, T, H, eps,
+                       map);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mask, int B, int L, int mode, int prec,
+                         hipStream_t s, int* T_out) {
     const sr_model_config& c = m->cfg;
     SR_REQUIRE(m->finalized, "encode: sr_model_finalize was not called");
     SR_REQUIRE(B >= 1 && L >= 1, "encode: bad batch shape [%d, %d]", B, L);
     SR_REQUIRE(B <= m->Bm, "encode: batch of %d sequences exceeds max_batch_seqs %d", B, m->Bm);
     SR_REQUIRE(L <= m->max_pos, "encode: sequence length %d exceeds %d", L, m->max_pos);
     SR_REQUIRE(d_ids && d_mask, "encode: null input");
+    if (prec == PREC_FP32) SR_TRY(ensure_fp32_workspace(m));
     const int H = c.hidden_size, I = c.intermediate_size;
     const int nq = c.num_heads * c.head_dim, nkv = c.num_kv_heads * c.head_dim;
 
@@ -597,19 +714,50 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(256), 0, s, m->span_len, B, m->cu);
     SR_CHECK_LAUNCH();
     SR_CHECK_HIP(hipMemcpyAsync(m->h_cu, m->cu, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
-    SR_CHECK_HIP(hipMemcpyAsync(m->h_cu + m->Bm + 1, m->row_len, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     SR_CHECK_HIP(hipStreamSynchronize(s));
     const int T = m->h_cu[B];
     int max_len = 0;
+    // a row whose attention_mask is all zero packs to zero tokens: every kernel skips it and both heads return the
+    // zero vector for it (the reference's sparse head gives exactly that; its dense head would average garbage)
     for (int b = 0; b < B; ++b) max_len = (m->h_cu[b + 1] - m->h_cu[b]) > max_len ? (m->h_cu[b + 1] - m->h_cu[b]) : max_len;
-    for (int b = 0; b < B; ++b)
-        SR_REQUIRE(m->h_cu[m->Bm + 1 + b] > 0, "encode: row %d has an all-zero attention_mask (empty sequence)", b);
     SR_REQUIRE(T <= m->Tm, "encode: batch packs to %d tokens, workspace holds %d (raise max_batch_tokens or split the batch)", T, m->Tm);
     *T_out = T;
     m->last_T = T;
+    if (T == 0) return SR_OK;
     hipLaunchKernelGGL(plan_tokens_kernel, dim3(B), dim3(128), 0, s, d_ids, d_mask, L, m->span_start, m->cu, m->tok_id,
                        m->pos, m->key_valid, m->seq_of, c.vocab_size, mode);
     SR_CHECK_LAUNCH();
+
+    if (prec == PREC_FP32) {
+        const SplitMap ma = split_map_a(c.fp32_planes);
+        const int nsg = ma.n_seg;
+        for (int li = 0; li < c.num_layers; ++li) {
+            LayerW& l = m->layers[li];
+            // input_layernorm (the embedding gather is fused into the first one); o_proj / down_proj add straight into x
+            SR_TRY(launch_rmsnorm_split(m->x, li == 0 ? m->embed : (const float*)nullptr, li == 0 ? m->tok_id : (const int*)nullptr,
+                                        l.ln1, m->xs, T, H, c.rms_norm_eps, ma, s));
+            GemmArgs g{};
+            g.A = m->xs; g.W = l.wqkv_s; g.M = T; g.N = nq + 2 * nkv; g.K = nsg * H; g.C = m->qkv_f;
+            g.pos = m->pos; g.rope_cos = m->rope_cos; g.rope_sin = m->rope_sin; g.n_rope = nq + nkv; g.head_dim = c.head_dim;
+            SR_TRY(launch_gemm_bf16(EPI_QKV_ROPE_F32, g, s));
+            AttnF32Args a{};
+            a.qkv = m->qkv_f; a.out = m->attn_s; a.cu_seqlens = m->cu; a.key_valid = m->key_valid;
+            a.B = B; a.nh = c.num_heads; a.nkv = c.num_kv_heads; a.hd = c.head_dim;
+            a.scale = 1.0f / sqrtf((float)c.head_dim); a.max_seqlen = max_len; a.out_map = ma;
+            SR_TRY(launch_attention_f32(a, s));
+            g = GemmArgs{};
+            g.A = m->attn_s; g.W = l.wo_s; g.M = T; g.N = H; g.K = nsg * nq; g.C = m->x;
+            SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
+            SR_TRY(launch_rmsnorm_split(m->x, (const float*)nullptr, (const int*)nullptr, l.ln2, m->xs, T, H, c.rms_norm_eps, ma, s));
+            g = GemmArgs{};
+            g.A = m->xs; g.W = l.wgu_s; g.M = T; g.N = 2 * I; g.K = nsg * H; g.C = m->act_s; g.out_map = ma;
+            SR_TRY(launch_gemm_bf16(EPI_SWIGLU_SPLIT, g, s));
+            g = GemmArgs{};
+            g.A = m->act_s; g.W = l.wdown_s; g.M = T; g.N = H; g.K = nsg * I; g.C = m->x;
+            SR_TRY(launch_gemm_bf16(EPI_RESID_F32, g, s));
+        }
+        return SR_OK;
+    }
 
     // embedding gather fused with the first input_layernorm
     SR_TRY(launch_rmsnorm(m->x, m->embed, m->tok_id, (const bf16_t*)nullptr, m->layers[0].ln1, m->xn,
@@ -650,16 +798,19 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     return SR_OK;
 }
 
-extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
-                               float* d_out, sr_stream stream) {
-    SR_REQUIRE(m && d_out, "sr_encode_dense: null argument");
-    hipStream_t s = (hipStream_t)stream;
+static int encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
+                        float* d_out, hipStream_t s) {
     std::lock_guard<std::mutex> lock(m->mu);
     StreamOrder::Scope in_order(m->order, s);
     int T = 0;
-    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, s, &T));
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, prec, s, &T));
     const int H = m->cfg.hidden_size;
-    float2* stats = reinterpret_cast<float2*>(m->xn);   // xn (bf16 [Tm, H]) is free after the last layer: reuse as [T] float2
+    if (T == 0) {
+        SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * H * 4, s));
+        return SR_OK;
+    }
+    // a [T] float2 scratch: xn (bf16 [Tm, H]) is free after the last layer in the bf16 regime, xs in the fp32 regime
+    float2* stats = reinterpret_cast<float2*>(prec == PREC_FP32 ? (void*)m->xs : (void*)m->xn);
     hipLaunchKernelGGL(dense_head_stats_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, m->norm_w, stats, T, H,
                        m->cfg.rms_norm_eps);
     hipLaunchKernelGGL(dense_head_pool_kernel, dim3((unsigned)B, (unsigned)ceil_div64(H, 256)), dim3(256), 0, s, m->x, m->norm_w,
@@ -668,29 +819,62 @@ extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const in
     return SR_OK;
 }
 
+static int encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
+                         float* d_out, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    StreamOrder::Scope in_order(m->order, s);
+    int T = 0;
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, prec, s, &T));
+    const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
+    SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
+    if (T == 0) return SR_OK;       // log(1 + relu(max over no tokens)) = 0
+    GemmArgs g{};
+    if (prec == PREC_FP32) {
+        const SplitMap ma = split_map_a(m->cfg.fp32_planes);
+        SR_TRY(launch_rmsnorm_split(m->x, (const float*)nullptr, (const int*)nullptr, m->norm_w, m->xs, T, H, m->cfg.rms_norm_eps,
+                                    ma, s));
+        g.A = m->xs; g.W = m->lm_head_s; g.K = ma.n_seg * H;
+    } else {
+        // final norm -> bf16 GEMM input
+        SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr,
+                           (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps, s));
+        g.A = m->xn; g.W = m->lm_head; g.K = H;
+    }
+    g.M = T; g.N = V; g.C = d_out; g.seq_of = m->seq_of; g.out_ld = V;
+    // rows with seq_of == -2 (mask == 0 inside the span) are skipped by the segmented max
+    SR_TRY(launch_gemm_bf16(EPI_SEGMAX, g, s));
+    const int64_t n = (int64_t)B * V;
+    // under autocast the lm_head output is bf16 (rounded before the fp32 upcast, llm_encoder.py:187-188); in fp32 it is not
+    hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, d_out, n,
+                       powf((float)H, -0.25f), prec == PREC_FP32 ? 0 : 1);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                               float* d_out, sr_stream stream) {
+    SR_REQUIRE(m && d_out, "sr_encode_dense: null argument");
+    return encode_dense(m, d_input_ids, d_attention_mask, B, L, PREC_BF16, d_out, (hipStream_t)stream);
+}
+
+extern "C" int sr_encode_dense_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                                    float* d_out, sr_stream stream) {
+    SR_REQUIRE(m && d_out, "sr_encode_dense_fp32: null argument");
+    return encode_dense(m, d_input_ids, d_attention_mask, B, L, PREC_FP32, d_out, (hipStream_t)stream);
+}
+
 extern "C" int sr_encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
                                 float* d_out, sr_stream stream) {
     SR_REQUIRE(m && d_out, "sr_encode_sparse: null argument");
     SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_sparse: model was created without an lm_head (LlamaBiModel)");
-    hipStream_t s = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(m->mu);
-    StreamOrder::Scope in_order(m->order, s);
-    int T = 0;
-    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, s, &T));
-    const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
-    // final norm -> bf16 GEMM input
-    SR_TRY(launch_rmsnorm(m->x, (const float*)nullptr,
-                       (const int*)nullptr, (const bf16_t*)nullptr, m->norm_w, m->xn, (float*)nullptr, T, H, m->cfg.rms_norm_eps, s));
-    SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
-    GemmArgs g{};
-    g.A = m->xn; g.W = m->lm_head; g.M = T; g.N = V; g.K = H; g.C = d_out; g.seq_of = m->seq_of; g.out_ld = V;
-    // rows with seq_of == -2 (mask == 0 inside the span) are skipped by the segmented max
-    SR_TRY(launch_gemm_bf16(EPI_SEGMAX, g, s));
-    const int64_t n = (int64_t)B * V;
-    hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, d_out, n,
-                       powf((float)H, -0.25f), 1);
-    SR_CHECK_LAUNCH();
-    return SR_OK;
+    return encode_sparse(m, d_input_ids, d_attention_mask, B, L, PREC_BF16, d_out, (hipStream_t)stream);
+}
+
+extern "C" int sr_encode_sparse_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                                     float* d_out, sr_stream stream) {
+    SR_REQUIRE(m && d_out, "sr_encode_sparse_fp32: null argument");
+    SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_sparse_fp32: model was created without an lm_head (LlamaBiModel)");
+    return encode_sparse(m, d_input_ids, d_attention_mask, B, L, PREC_FP32, d_out, (hipStream_t)stream);
 }
 
 extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_rows, int64_t* n_tokens, sr_stream stream) {

@@ -361,22 +361,33 @@ void gemm_bf16_kernel(GemmArgs g) {
                 }
             }
         }
-    } else if constexpr (EPI == EPI_QKV_ROPE) {
+    } else if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
         // q/k heads: out[d] = x[d] cos - x[d + hd/2] sin, out[d + hd/2] = x[d + hd/2] cos + x[d] sin (HF rotate_half),
         // in fp32 on the accumulators; both halves of a head live in this lane (blocks i and i + hd/32).
         // A wave's feature range (16 * NB) covers whole heads: NB * 16 % head_dim == 0 is checked at launch.
+        // EPI_QKV_ROPE_F32 (fp32 regime) stores the rotated fp32 values as they are.
+        constexpr bool F32OUT = EPI == EPI_QKV_ROPE_F32;
         const int hd = g.head_dim, hb = hd / 32;   // hb = block distance between rotation partners
+        auto put = [&](int64_t off, const f32x4& v) {
+            if constexpr (F32OUT) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + off) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(v[r]);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
+            }
+        };
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int m = m0 + wm * MB * 16 + j * 16 + frow;
             if (m >= g.M) continue;
             const int p = g.pos[m];
-            bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.N;
+            const int64_t crow = (int64_t)m * g.N;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
                 if (n >= g.N) continue;
-                bf16x4 o;
                 if (n < g.n_rope) {
                     const int d = n % hd;
                     if (d >= hd / 2) continue;                 // written together with its first-half partner
@@ -384,20 +395,17 @@ void gemm_bf16_kernel(GemmArgs g) {
                     f32x4 x1 = acc[i][j], x2;
                     if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
                     const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
-                    bf16x4 o2;
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
+                    f32x4 y1, y2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        o[r] = (short)f32_to_bf16(x1[r] * c[r] - x2[r] * s[r]);
-                        o2[r] = (short)f32_to_bf16(x2[r] * c[r] + x1[r] * s[r]);
+                        y1[r] = x1[r] * c[r] - x2[r] * sn[r];
+                        y2[r] = x2[r] * c[r] + x1[r] * sn[r];
                     }
-                    *reinterpret_cast<bf16x4*>(crow + n) = o;
-                    *reinterpret_cast<bf16x4*>(crow + n + hd / 2) = o2;
+                    put(crow + n, y1);
+                    put(crow + n + hd / 2, y2);
                 } else {
-                    const f32x4 v = acc[i][j];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(v[r]);
-                    *reinterpret_cast<bf16x4*>(crow + n) = o;
+                    put(crow + n, acc[i][j]);
                 }
             }
         }
@@ -419,6 +427,36 @@ void gemm_bf16_kernel(GemmArgs g) {
                     o[r] = (short)f32_to_bf16(sg * up[r]);
                 }
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * half_n + n) = o;
+            }
+        }
+    } else if constexpr (EPI == EPI_SWIGLU_SPLIT) {
+        // fp32 regime: silu(gate) * up with an accurate exp and a true division, then stored as the split-bf16 plane
+        // segments the down_proj GEMM consumes: C [M, n_seg * N/2], segment sg holds plane out_map.plane[sg]
+        const int half_n = g.N >> 1;
+        const int nsg = g.out_map.n_seg;
+        const int64_t ldc = (int64_t)nsg * half_n;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int i = 0; i < NB; i += 2) {
+                const int n = (n0 >> 1) + wn * NB * 8 + (i >> 1) * 16 + fg * 4;
+                if (n >= half_n) continue;
+                const f32x4 gt = acc[i][j], up = acc[i + 1][j];
+                bf16x4 pl0, pl1, pl2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = (gt[r] / (1.f + expf(-gt[r]))) * up[r];
+                    unsigned short a0, a1, a2;
+                    split_bf16x3(y, a0, a1, a2);
+                    pl0[r] = (short)a0; pl1[r] = (short)a1; pl2[r] = (short)a2;
+                }
+                bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n;
+                for (int sg = 0; sg < nsg; ++sg) {
+                    const int pi = g.out_map.plane[sg];
+                    *reinterpret_cast<bf16x4*>(crow + (int64_t)sg * half_n) = pi == 0 ? pl0 : (pi == 1 ? pl1 : pl2);
+                }
             }
         }
     } else {  // EPI_SEGMAX: per-sequence max over this tile's token rows, straight from the accumulators
@@ -582,10 +620,10 @@ static bool env_off(const char* name) {
 template <int EPI>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
     const bool pipe = g.K / G_BK >= 4 && !env_off("SR_GEMM_PIPE");      // the pipelined k-loop needs >= 4 k-steps
-    if constexpr (EPI == EPI_QKV_ROPE) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
     }
-    if constexpr (EPI != EPI_QKV_ROPE) {
+    if constexpr (EPI != EPI_QKV_ROPE && EPI != EPI_QKV_ROPE_F32) {
         // few 128^2 tiles (a short tail behind the 256^2 rounds, or a small problem): halve the token tile so that two or
         // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
         const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
@@ -602,8 +640,8 @@ static GemmArgs rows_from(const GemmArgs& g, int row0) {
     GemmArgs t = g;
     t.A = g.A + (int64_t)row0 * g.K;
     t.M = g.M - row0;
-    const int64_t ldc = (EPI == EPI_SWIGLU) ? g.N / 2 : g.N;
-    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) ? 4 : 2;
+    const int64_t ldc = (EPI == EPI_SWIGLU) ? g.N / 2 : (EPI == EPI_SWIGLU_SPLIT ? (int64_t)g.out_map.n_seg * (g.N / 2) : g.N);
+    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE_F32) ? 4 : 2;
     if constexpr (EPI != EPI_SEGMAX) t.C = reinterpret_cast<unsigned char*>(g.C) + (int64_t)row0 * ldc * esz;
     if (g.seq_of) t.seq_of = g.seq_of + row0;
     if (g.pos) t.pos = g.pos + row0;
@@ -620,20 +658,20 @@ static int skinny_max_rows() {
 
 template <int EPI>
 static int launch_one(const GemmArgs& g, hipStream_t s) {
-    if constexpr (EPI == EPI_QKV_ROPE) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
         SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
     }
     if (g.M <= skinny_max_rows() && g.K / G_BK >= 4) {
         if (g.M > 32) {
-            if constexpr (EPI == EPI_QKV_ROPE) {
+            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
                 if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 4, true, 3>(g, s);
             }
             return launch_cfg<EPI, 1, 1, 4, 4, true, 4>(g, s);
         }
         if (g.M > 16) {
-            if constexpr (EPI == EPI_QKV_ROPE) {
+            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
                 if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 2, true, 4>(g, s);
             }
             return launch_cfg<EPI, 1, 1, 4, 2, true, 4>(g, s);
@@ -641,7 +679,7 @@ static int launch_one(const GemmArgs& g, hipStream_t s) {
         // A handful of tokens (online queries): the work is streaming W once.  One WAVE per workgroup owns 64 features x 16
         // tokens (N / 64 independent workgroups instead of N / 128 four-wave ones idling on a 16-token tile), four 10 KB LDS
         // stages keep three k-steps of weights in flight per wave.  Same MFMA chain per output element as every other tile.
-        if constexpr (EPI == EPI_QKV_ROPE) {
+        if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
             if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 1, true, 4>(g, s);
         }
         return launch_cfg<EPI, 1, 1, 4, 1, true, 4>(g, s);
@@ -661,7 +699,8 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
     SR_REQUIRE(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0) return SR_OK;
     SR_REQUIRE(g.K % G_BK == 0, "gemm: K=%d must be a multiple of %d", g.K, G_BK);
-    SR_REQUIRE(g.N % 16 == 0 && (epi != EPI_SWIGLU || g.N % 32 == 0), "gemm: N=%d must be a multiple of 16 (32 for SwiGLU)", g.N);
+    SR_REQUIRE(g.N % 16 == 0 && ((epi != EPI_SWIGLU && epi != EPI_SWIGLU_SPLIT) || g.N % 32 == 0), "gemm: N=%d must be a multiple of 16 (32 for SwiGLU)", g.N);
+    SR_REQUIRE(epi != EPI_SWIGLU_SPLIT || (g.out_map.n_seg >= 1 && g.out_map.n_seg <= SR_MAX_SEG), "gemm(swiglu split): bad segment map");
     switch (epi) {
         case EPI_STORE_BF16: return launch_one<EPI_STORE_BF16>(g, s);
         case EPI_RESID_F32: return launch_one<EPI_RESID_F32>(g, s);
@@ -669,6 +708,8 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
         case EPI_SEGMAX: return launch_one<EPI_SEGMAX>(g, s);
         case EPI_STORE_F32: return launch_one<EPI_STORE_F32>(g, s);
         case EPI_QKV_ROPE: return launch_one<EPI_QKV_ROPE>(g, s);
+        case EPI_QKV_ROPE_F32: return launch_one<EPI_QKV_ROPE_F32>(g, s);
+        case EPI_SWIGLU_SPLIT: return launch_one<EPI_SWIGLU_SPLIT>(g, s);
     }
     sr_set_error("gemm: unknown epilogue %d", (int)epi);
     return SR_ERR_INVALID;

@@ -11,7 +11,30 @@ enum GemmEpilogue {
     EPI_SEGMAX = 3,      // out[seq_of[m], n] = max(out, acc) over the tokens of each sequence (sparse head)
     EPI_STORE_F32 = 4,   // C[M,N] fp32 = acc (tests)
     EPI_QKV_ROPE = 5,    // C[M,N] bf16 = acc with RoPE applied (fp32) to features n < n_rope (q and k heads)
+    EPI_QKV_ROPE_F32 = 6,   // same, C[M,N] fp32 (fp32 regime: the attention reads fp32 operands)
+    EPI_SWIGLU_SPLIT = 7,   // fp32 regime: silu(gate) * up in fp32, stored as split-bf16 plane segments (out_map)
 };
+
+// ---- fp32 regime: fp32 operands as sums of bf16 planes ---------------------------------------------------
+// x = p0 + p1 + p2, each plane the bf16 rounding of what the previous ones left (the subtractions are exact in fp32),
+// so three planes carry the whole 24-bit significand.  A fp32-class product a.w is the sum of plane products
+// a_i . w_j; laid out along K as segments it is ONE bf16 GEMM with K' = n_seg * K (fp32 accumulate in the MFMA):
+//   A' = [a_{pa[0]} | a_{pa[1]} | ...]   W' = [w_{pw[0]} | w_{pw[1]} | ...]      (smallest terms first)
+//   3 planes, 6 products (error below fp32 epsilon):  pa = 2 0 1 1 0 0   pw = 0 2 1 0 1 0
+//   2 planes, 3 products (~2^-17 relative):           pa = 1 0 0         pw = 0 1 0
+#define SR_MAX_SEG 6
+struct SplitMap {
+    int n_seg;
+    int plane[SR_MAX_SEG];
+};
+inline SplitMap split_map_a(int planes) {
+    if (planes >= 3) return SplitMap{6, {2, 0, 1, 1, 0, 0}};
+    return SplitMap{3, {1, 0, 0, 0, 0, 0}};
+}
+inline SplitMap split_map_w(int planes) {
+    if (planes >= 3) return SplitMap{6, {0, 2, 1, 0, 1, 0}};
+    return SplitMap{3, {0, 1, 0, 0, 0, 0}};
+}
 
 struct GemmArgs {
     const bf16_t* A;   // activations [M, K] row-major
@@ -27,6 +50,7 @@ struct GemmArgs {
     int n_rope;             // features [0, n_rope) are rotated (q heads then k heads), the rest (v) stored as is
     int head_dim;           // 64 or 128
     unsigned long long* stamps;  // diagnostics only (tools/micro): 4 s_memrealtime stamps (100 MHz) per workgroup-tile, else null
+    SplitMap out_map;  // EPI_SWIGLU_SPLIT: plane of each output segment; C is [M, n_seg * N/2] bf16
     int m_fastest;     // tile order, chosen by launch_gemm_bf16: 1 = token tiles fastest (W far larger than the caches)
 };
 
@@ -49,3 +73,17 @@ struct AttnArgs {
 };
 // Bidirectional (non-causal) GQA attention over packed var-len sequences.
 int launch_attention(const AttnArgs& a, hipStream_t s);
+
+// fp32 regime (the reference encodes dense queries without autocast, eval_dense.py:94-106): fp32 q/k/v (already
+// rotated), fp32 scores, softmax and P.V; the output is written as split-bf16 plane segments for the o_proj GEMM.
+struct AttnF32Args {
+    const float* qkv;       // [T, (nh + 2*nkv) * hd]
+    bf16_t* out;            // [T, n_seg * nh * hd]
+    const int* cu_seqlens;  // [B + 1]
+    const unsigned char* key_valid;  // [T]
+    int B, nh, nkv, hd;
+    float scale;
+    int max_seqlen;         // longest sequence of the batch (grid sizing)
+    SplitMap out_map;
+};
+int launch_attention_f32(const AttnF32Args& a, hipStream_t s);

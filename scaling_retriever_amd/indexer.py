@@ -67,7 +67,8 @@ def store_embs(model, collection_loader, local_rank, index_dir, device, chunk_si
     for idx, batch in tqdm(enumerate(collection_loader), disable=not is_first_worker(),
                            desc=f"encode # {len(collection_loader)} seqs", total=len(collection_loader)):
         inputs = {k: v.to(device) for k, v in batch.items() if k != "ids"}
-        reps = enc.doc_encode(**inputs)
+        with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):      # indexer.py:46-52
+            reps = enc.doc_encode(**inputs)
         text_ids = batch["ids"]
         assert isinstance(text_ids, list)
         embeddings.append(reps)
@@ -246,7 +247,8 @@ class SparseIndexer:
         dev_rows, dev_cols, dev_vals = [], [], []
         for t, batch in enumerate(tqdm(collection_loader, disable=not is_first_worker())):
             inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
-            batch_documents = self.model.encode(**inputs)      # [bz, vocab_size] fp32 on device
+            with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:255-256
+                batch_documents = self.model.encode(**inputs)      # [bz, vocab_size] fp32 on device
             if self.compute_stats:
                 stats["L0_d"] += self.l0(batch_documents).item()
             row_ptr, col, data = sparse_reps_to_csr(batch_documents)
@@ -382,7 +384,8 @@ class SparseRetrieval:
         for t, batch in enumerate(tqdm(q_loader, total=len(q_loader), desc="generate query vecs",
                                        disable=not is_first_worker())):
             inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
-            batch_sparse_reps = self.model.encode(**inputs)
+            with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:390-391
+                batch_sparse_reps = self.model.encode(**inputs)
             qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
             row_ptr, cols, vals = sparse_reps_to_csr(batch_sparse_reps)
             row_ptr, cols, vals = row_ptr.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()

@@ -121,8 +121,24 @@ class HipLlamaBackbone(torch.nn.Module):
     """Stands where the reference keeps `base_model` (LlamaBiModel / LlamaBiForMNTP): owns the
     checkpoint tensors until the model is moved to a ROCm device, then the sr_model handle."""
 
-    def __init__(self, config, weights, has_lm_head, lora=None, max_batch_tokens=32768, max_batch_seqs=1024):
+    def __init__(self, config, weights, has_lm_head, lora=None, max_batch_tokens=32768, max_batch_seqs=1024,
+                 precision="auto", fp32_planes=None):
         super().__init__()
+        # Precision regime per call, as in the reference, where the CALLER decides it with torch.autocast:
+        #   "auto" (default)  bf16 regime inside torch.autocast("cuda", dtype=torch.bfloat16) - documents and sparse
+        #                     queries (indexer.py:46-52, :255-256, :390-391) - fp32 regime otherwise - dense queries
+        #                     (eval_dense.py:94-106) and examples/quick_start.py;
+        #   "bf16" / "fp32"   force one regime.
+        # fp32_planes: bf16 planes per fp32 operand in the fp32 regime (3 = full significand, 2 = faster, 0 = no fp32
+        # regime and no extra weight copies); default 3, or the SR_FP32_PLANES environment variable.
+        if precision not in ("auto", "bf16", "fp32"):
+            raise ValueError(f"precision must be 'auto', 'bf16' or 'fp32', got {precision!r}")
+        self.precision = precision
+        if fp32_planes is None:
+            fp32_planes = int(os.environ.get("SR_FP32_PLANES", "3"))
+        if fp32_planes not in (0, 2, 3):
+            raise ValueError(f"fp32_planes must be 0, 2 or 3, got {fp32_planes}")
+        self.fp32_planes = int(fp32_planes)
         self.config = config if isinstance(config, LlamaConfigLite) else LlamaConfigLite.from_dict(config)
         self._weights = weights            # name -> tensor (host or device), dropped after upload
         self._lora = lora                  # {"scale": float, "A": {name: t}, "B": {name: t}} or None
@@ -155,7 +171,7 @@ class HipLlamaBackbone(torch.nn.Module):
             head_dim=c.head_dim, rms_norm_eps=float(c.rms_norm_eps), rope_theta=theta, rope_llama3=llama3,
             rope_factor=fac, rope_low_freq_factor=lo, rope_high_freq_factor=hi, rope_original_max_pos=old,
             tie_word_embeddings=int(bool(c.tie_word_embeddings)), has_lm_head=int(self.has_lm_head),
-            max_batch_tokens=self.max_batch_tokens, max_batch_seqs=self.max_batch_seqs)
+            max_batch_tokens=self.max_batch_tokens, max_batch_seqs=self.max_batch_seqs, fp32_planes=self.fp32_planes)
 
     def build_engine(self, device):
         _lib.require_gpu()
@@ -237,9 +253,25 @@ class HipLlamaBackbone(torch.nn.Module):
             else:
                 raise _lib.SrHipError("no ROCm device: LlamaBi* encode runs on MI355X only (no CPU fallback)")
 
+    def resolve_precision(self):
+        """'bf16' or 'fp32' for a call made right now (see __init__)."""
+        if self.precision != "auto":
+            return self.precision
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            if dt != torch.bfloat16:
+                raise NotImplementedError(f"autocast dtype {dt} is not supported (the reference uses torch.bfloat16)")
+            return "bf16"
+        return "fp32"
+
     def _encode(self, input_ids, attention_mask, sparse):
         if input_ids.dim() != 2 or attention_mask.shape != input_ids.shape:
             raise ValueError("input_ids and attention_mask must both be [batch, length]")
+        prec = self.resolve_precision()
+        if prec == "fp32" and self.fp32_planes == 0:
+            raise _lib.SrHipError("fp32-regime encode requested (no torch.autocast(bf16) active) but the model was built "
+                                  "with fp32_planes=0; wrap the call in torch.autocast('cuda', dtype=torch.bfloat16) or "
+                                  "build the model with fp32_planes=3")
         self._ensure_engine(input_ids)
         src_device = input_ids.device
         ids = input_ids.to(device=self._device, dtype=torch.int64).contiguous()
@@ -247,7 +279,8 @@ class HipLlamaBackbone(torch.nn.Module):
         B, L = ids.shape
         width = self.config.vocab_size if sparse else self.config.hidden_size
         out = torch.empty((B, width), dtype=torch.float32, device=self._device)
-        fn = self._lib.sr_encode_sparse if sparse else self._lib.sr_encode_dense
+        what = ("sr_encode_sparse" if sparse else "sr_encode_dense") + ("_fp32" if prec == "fp32" else "")
+        fn = getattr(self._lib, what)
         rows_per_call = max(1, min(self.max_batch_seqs, self.max_batch_tokens // max(L, 1)))
         if rows_per_call * L > self.max_batch_tokens and L > self.max_batch_tokens:
             raise ValueError(f"sequence length {L} exceeds the workspace ({self.max_batch_tokens} tokens)")
@@ -256,7 +289,7 @@ class HipLlamaBackbone(torch.nn.Module):
             for b0 in range(0, B, rows_per_call):
                 b1 = min(B, b0 + rows_per_call)
                 _lib.check(fn(self._h, ids[b0:b1].data_ptr(), mask[b0:b1].data_ptr(), b1 - b0, L,
-                              out[b0:b1].data_ptr(), stream), "sr_encode_sparse" if sparse else "sr_encode_dense")
+                              out[b0:b1].data_ptr(), stream), what)
         return out if src_device == self._device else out.to(src_device)
 
     def last_hidden_state_packed(self):
@@ -381,11 +414,12 @@ class LLM2Retriever(torch.nn.Module):
                         merge_peft=merge_peft, is_trainable=is_trainable, access_token=access_token)
 
     @classmethod
-    def from_weights(cls, config, weights, max_batch_tokens=32768, max_batch_seqs=1024, **make_kw):
+    def from_weights(cls, config, weights, max_batch_tokens=32768, max_batch_seqs=1024, precision="auto", fp32_planes=None,
+                     **make_kw):
         """Build from an in-memory state dict (HF Llama names -> numpy/torch tensors)."""
         weights = {_canonical_name(k): v for k, v in weights.items()}
-        backbone = HipLlamaBackbone(config, weights, has_lm_head=cls.HAS_LM_HEAD,
-                                    max_batch_tokens=max_batch_tokens, max_batch_seqs=max_batch_seqs)
+        backbone = HipLlamaBackbone(config, weights, has_lm_head=cls.HAS_LM_HEAD, max_batch_tokens=max_batch_tokens,
+                                    max_batch_seqs=max_batch_seqs, precision=precision, fp32_planes=fp32_planes)
         return cls._make(backbone, **make_kw)
 
     def save_pretrained(self, save_dir):

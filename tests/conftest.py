@@ -13,6 +13,8 @@ if GOLDEN not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fp32_regime: GPU test of the encoder's no-autocast regime (the reference's dense-query "
+                                       "regime, eval_dense.py:94-106)")
 
 
 @pytest.fixture(scope="session")

@@ -194,7 +194,7 @@ def _load_case(golden_dir, name):
 def test_dense_encode_matches_reference_golden(golden_dir, name, side):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     z, cfg, w = _load_case(golden_dir, name)
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     ids = torch.from_numpy(z[f"{side}:input_ids"]).cuda()
     mask = torch.from_numpy(z[f"{side}:attention_mask"]).cuda()
     out = model.doc_encode(input_ids=ids, attention_mask=mask)
@@ -213,7 +213,7 @@ def test_dense_encode_matches_reference_golden(golden_dir, name, side):
 def test_sparse_encode_matches_reference_golden(golden_dir, name, side):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiSparse
     z, cfg, w = _load_case(golden_dir, name)
-    model = LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     ids = torch.from_numpy(z[f"{side}:input_ids"]).cuda()
     mask = torch.from_numpy(z[f"{side}:attention_mask"]).cuda()
     out = model.encode(input_ids=ids, attention_mask=mask)
@@ -232,7 +232,7 @@ def test_hidden_states_match_oracle(golden_dir):
     """last_hidden_state of the packed real tokens vs the fp32 oracle (per-token check)."""
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     z, cfg, w = _load_case(golden_dir, "enc_hd64")
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda")
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda")
     ids, mask = z["left:input_ids"], z["left:attention_mask"]
     model.encode(input_ids=torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda())
     hs = model.base_model.last_hidden_state_packed().cpu().numpy()
@@ -247,7 +247,7 @@ def test_toy_config_scores(golden_dir):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     zq, cfg, w = _load_case(golden_dir, "enc_toy_q")
     zd = np.load(os.path.join(golden_dir, "enc_toy_d.npz"))
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda")
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda")
     q = model.query_encode(input_ids=torch.from_numpy(zq["left:input_ids"]).cuda(),
                            attention_mask=torch.from_numpy(zq["left:attention_mask"]).cuda())
     d = model.doc_encode(input_ids=torch.from_numpy(zd["left:input_ids"]).cuda(),
@@ -261,7 +261,7 @@ def test_batch_composition_invariance(golden_dir):
     """Encoding a row alone or inside a padded batch gives the same vector (packing drops the pads)."""
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     z, cfg, w = _load_case(golden_dir, "enc_hd64")
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda")
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda")
     ids, mask = torch.from_numpy(z["left:input_ids"]).cuda(), torch.from_numpy(z["left:attention_mask"]).cuda()
     full = model.encode(input_ids=ids, attention_mask=mask)
     n = int(mask[3].sum())
@@ -272,17 +272,27 @@ def test_batch_composition_invariance(golden_dir):
 def test_encode_argument_errors(golden_dir):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense, LlamaBiSparse
     z, cfg, w = _load_case(golden_dir, "enc_tiny_a")
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda")
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda")
     ids = torch.from_numpy(z["left:input_ids"]).cuda()
     mask = torch.from_numpy(z["left:attention_mask"]).cuda().clone()
     mask[2] = 0
-    with pytest.raises(ValueError):
-        model.encode(input_ids=ids, attention_mask=mask)        # empty sequence
+    # A row with an all-zero attention_mask does not abort the batch: it gets the zero vector (the reference's sparse
+    # head returns exactly that, log(1 + relu(max(logits - 1e6))) = 0, llm_encoder.py:189-193) and the other rows are
+    # what they are without it.
+    full = model.encode(input_ids=ids, attention_mask=torch.from_numpy(z["left:attention_mask"]).cuda())
+    holed = model.encode(input_ids=ids, attention_mask=mask)
+    assert torch.equal(holed[2], torch.zeros_like(holed[2]))
+    keep = [0, 1, 3, 4]
+    assert rel(holed[keep].cpu().numpy(), full[keep].cpu().numpy()) < 1e-6
+    sp = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda")
+    sp_holed = sp.encode(input_ids=ids, attention_mask=mask)
+    assert torch.equal(sp_holed[2], torch.zeros_like(sp_holed[2])) and sp_holed[keep].abs().sum() > 0
+    assert torch.equal(model.encode(input_ids=ids, attention_mask=torch.zeros_like(mask)), torch.zeros_like(full))
     with pytest.raises(ValueError):
         model.encode(input_ids=ids, attention_mask=mask[:, :3])
     bad = dict(cfg, num_attention_heads=8)                      # head_dim 16: unsupported
     with pytest.raises(ValueError):
-        LlamaBiSparse.from_weights(bad, w).to("cuda")
+        LlamaBiSparse.from_weights(bad, w, precision="bf16").to("cuda")
 
 
 # ------------------------------------------------------------------ loaders / LoRA

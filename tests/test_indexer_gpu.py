@@ -66,7 +66,7 @@ def test_store_embs_then_dense_retrieval(tiny, tmp_path):
     rng = np.random.default_rng(0)
     docs, queries = _corpus(rng, 70, V, 3, 30), _corpus(rng, 9, V, 2, 8)
     pids = [f"p{i}" for i in range(len(docs))]
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     loader = FakeLoader(docs, pids, batch_size=16, pad_id=V - 1)
     out_dir = str(tmp_path / "embs")
     store_embs(model, loader, local_rank=0, index_dir=out_dir, device="cuda", chunk_size=32)   # 2 batches per chunk
@@ -106,7 +106,7 @@ def test_sparse_index_then_retrieval(tiny, tmp_path):
     rng = np.random.default_rng(1)
     docs, queries = _corpus(rng, 50, V, 1, 6), _corpus(rng, 7, V, 1, 3)
     pids, qids = [f"p{i}" for i in range(len(docs))], [f"q{i}" for i in range(len(queries))]
-    model = LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     index_dir = str(tmp_path / "index")
     indexer = SparseIndexer(model, index_dir=index_dir, compute_stats=True, dim_voc=model.vocab_size, device="cuda")
     indexer.index(FakeLoader(docs, pids, batch_size=8, pad_id=V - 1))

@@ -92,7 +92,7 @@ def test_dense_pipeline_reproduces_mrr_and_ndcg(setup):
         q = _oracle_encode(LB.dense_encode, w, cfg, queries, "left", hooks)
         s, i = SC.flat_ip_search(q, d, K)
         ref[name] = _metrics(i, s, src)
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     index = DenseIndexHIP(cfg["hidden_size"])
     index.add_device_rows(_hip_encode(model, docs, "left", False))
     s, i = index.search(_hip_encode(model, queries, "left", True), K)
@@ -119,7 +119,7 @@ def test_sparse_pipeline_reproduces_mrr_and_ndcg(setup):
         sc = q @ d.T
         i = np.argsort(-sc, axis=1, kind="stable")[:, :K]
         ref[name] = _metrics(i, np.take_along_axis(sc, i, 1), src)
-    model = LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
     d_reps = _hip_encode(model, docs, "right", False)
     q_reps = _hip_encode(model, queries, "right", True)
     from scaling_retriever_amd.scoring import SparseIndexHIP

@@ -68,7 +68,7 @@ def tiny_models(golden_dir):
     z = np.load(os.path.join(golden_dir, "enc_tiny_a.npz"))
     cfg = json.loads(str(z["config_json"]))
     w = make_weights(cfg, 99)
-    return cfg, w, LlamaBiDense.from_weights(cfg, w).to("cuda").eval(), LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()
+    return cfg, w, LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda").eval(), LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
 
 
 @settings(max_examples=12, deadline=None)
