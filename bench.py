@@ -7,21 +7,34 @@ the HIP LlamaBiDense encoder (1B dims, random weights), score them against the d
 embedding matrix resident in HBM (8 841 823 x 2048, synthetic), fused top-1000, and - for N > 1 - one
 RCCL gather of the per-shard top-k + merge on rank 0.  value = queries / s over the whole job.
 
+Precision: queries are encoded in the encoder's fp32 regime, as the reference does (eval_dense.py:94-106: no
+autocast) - split-bf16 GEMMs carrying the full fp32 significands - documents in the bf16-autocast regime
+(indexer.py:46-52); scores are exact fp32.
+
 Also reported on the same JSON line: `roofline` for the dominant kernel (dense_score_kernel, fp32 MFMA
-bound; durations from HIP events recorded around every launch inside the timed region), `encode`
-(passages/s of doc_encode on a sample, MFMA bf16 bound), `cpu_baseline` (the oracle's faiss-style
-flat IP search on the host cores, bounded sample, rank 0 at N = 1 only).
+bound; durations from HIP events recorded around every launch inside the timed region), `cpu_baseline` (the
+oracle's faiss-style flat IP search on the host cores, bounded sample, rank 0 at N = 1 only), and the two other
+stages of the headline metric:
+  `encode`  passages/s of the corpus-encode task: >= 100 000 synthetic passages through store_embs (token-budget
+            batches -> doc_encode under autocast -> D2H -> embs_*.npy / ids_*.npy / plan.json), with its MFMA roofline;
+  `sparse`  BASELINE.json configs[2] (N = 1 only): queries/s of sr_sparse_search on the MSMARCO-shaped synthetic
+            inverted index, full-size bit-exact check against the oracle, the 32-thread CPU baseline, and the two
+            bounds that describe the kernel (unique index bytes over HBM; LDS read-modify-writes against the
+            microbenchmark tools/micro/lds_rmw.hip).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus 8 --steps 3 --warmup 1
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("TQDM_DISABLE", "1")      # stdout carries ONE JSON line; progress bars would drown stderr
 
 import numpy as np
 import torch
@@ -29,6 +42,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 LION_1B = dict(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
                num_attention_heads=32, num_key_value_heads=8, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0,
@@ -89,6 +103,191 @@ def synth_batches(n, batch, mu, sigma, lo, hi, vocab, seed, device, rows=None):
     return out, lens
 
 
+class _TimedEncoder:
+    """Stands where store_embs expects the model: forwards doc_encode and brackets every call with events on torch's
+    current stream (the stream the C ABI launches on), so the GPU share of the pass is measured, not guessed."""
+
+    def __init__(self, model):
+        self.model = model
+        self.events = []
+        self.tokens = 0
+        self.sq_tokens = 0.0
+
+    def doc_encode(self, **inputs):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = self.model.doc_encode(**inputs)
+        b.record()
+        self.events.append((a, b))
+        return out
+
+    def gpu_seconds(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events) * 1e-3
+
+
+def synth_token_chunks(n, mu, sigma, lo, hi, vocab, seed, rows, chunk=8192):
+    """Already tokenised passages for TokenBudgetCollectionLoader (no tokenizer offline): (ids, flat int32 tokens, lengths)
+    chunks; lengths ~ clip(lognormal(mu, sigma)), ids uniform."""
+    lens = np.clip(np.round(np.random.default_rng(seed).lognormal(mu, sigma, size=n)), lo, hi).astype(np.int32)
+    r0, r1 = rows
+    chunks = []
+    for c0 in range(r0, r1, chunk):
+        ls = lens[c0:min(c0 + chunk, r1)]
+        flat = np.random.default_rng((seed, c0)).integers(0, vocab - 1, size=int(ls.sum()), dtype=np.int32)
+        chunks.append((list(range(c0, c0 + len(ls))), flat, ls))
+    return chunks, lens[r0:r1]
+
+
+def encode_leg(args, cfg, model, device, rank, world, share_gpu):
+    import shutil
+    import tempfile
+    from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
+    from scaling_retriever_amd.distributed import query_slice
+    from scaling_retriever_amd.indexer import store_embs
+    H, L = cfg["hidden_size"], cfg["num_hidden_layers"]
+    rows = query_slice(args.encode_passages, rank, world)           # contiguous block per rank
+    chunks, lens = synth_token_chunks(args.encode_passages, 4.25, 0.35, 8, 192, cfg["vocab_size"], 3, rows)
+    tmp = tempfile.mkdtemp(prefix="sr_bench_embs_")
+    try:
+        def loader():
+            return TokenBudgetCollectionLoader(tokenized=chunks, max_length=192, max_tokens=args.token_budget, max_seqs=1024,
+                                               window=32768, pad_token_id=cfg["vocab_size"] - 1, padding_side="left")
+        warm = TokenBudgetCollectionLoader(tokenized=chunks[:1], max_length=192, max_tokens=args.token_budget, max_seqs=1024,
+                                           pad_token_id=cfg["vocab_size"] - 1, padding_side="left")
+        for i_, b_ in enumerate(warm):                              # warm-up: two batches
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                model.doc_encode(input_ids=b_["input_ids"].to(device), attention_mask=b_["attention_mask"].to(device))
+            if i_ >= 1:
+                break
+        timed = _TimedEncoder(model)
+        n_batches = sum(1 for _ in loader())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        te = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):              # store_embs prints its plan like the reference does
+            store_embs(timed, loader(), rank, tmp, device, chunk_size=65536)
+        torch.cuda.synchronize()
+        te = time.perf_counter() - te
+        gpu_s = timed.gpu_seconds()
+        if world > 1:
+            t = torch.tensor([te, gpu_s], dtype=torch.float64, device="cpu" if share_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te, gpu_s = float(t[0].item()), float(t[1].item())
+        written = sum(np.load(os.path.join(tmp, f), mmap_mode="r").shape[0] for f in os.listdir(tmp) if f.startswith("embs_"))
+        assert written == len(lens), (written, len(lens))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # whole-job figures: every rank encoded 1/W of the sample, times are the max over ranks
+    all_lens = np.clip(np.round(np.random.default_rng(3).lognormal(4.25, 0.35, size=args.encode_passages)), 8, 192)
+    tokens = float(all_lens.sum())
+    flop = tokens * FLOP_PER_TOKEN_1B * L / 16 + 4.0 * float((all_lens.astype(np.float64) ** 2).sum()) * H * L
+    ach, ach_gpu = flop / te / 1e12 / world, flop / gpu_s / 1e12 / world
+    return {"value": round(args.encode_passages / te, 1), "unit": "passages/s (whole job, through store_embs: encode + D2H + .npy files)",
+            "passages_per_s_per_gpu": round(args.encode_passages / te / world, 1), "sample_passages": int(args.encode_passages),
+            "mean_tokens_per_passage": round(float(all_lens.mean()), 1), "token_budget": args.token_budget, "batches_per_rank": n_batches,
+            "dtype": "bf16 GEMM inputs / fp32 accumulate (autocast regime, indexer.py:46-52)",
+            "wall_s": round(te, 3), "gpu_encode_s": round(gpu_s, 3),
+            "roofline": {"kernel": "gemm_bf16_kernel (bf16 MFMA 16x16x32, 256 x 256 tiles) - the layer GEMMs are 88 % of the pass",
+                         "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TF, 4),
+                         "achieved_gpu_time_only": round(ach_gpu, 1), "frac_gpu_time_only": round(ach_gpu / PEAK_BF16_MFMA_TF, 4),
+                         "traffic": None,
+                         "note": "achieved = algorithmic FLOP of the real (non-pad) tokens (2 x linear params + attention 4 S H per layer) / wall time "
+                                 "of the whole store_embs pass per GPU; gpu_time_only divides by the summed doc_encode durations (HIP events)"}}
+
+
+def sparse_leg(args, device):
+    """BASELINE.json configs[2]: one MI355X vs the 32-thread CPU shape the reference names (README.md:89-94)."""
+    import synth
+    from scaling_retriever_amd import _lib
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    lib = _lib.load()
+    V, N, L0_d, L0_q, nq, k = 128256, 8_841_823, 128, 32, 6980, 1000
+    t0 = time.time()
+    indptr, doc_ids, vals, _ = synth.build_index(V, N, L0_d, device, 3)
+    q_indptr, q_cols, q_vals = synth.build_queries(V, nq, L0_q, device, 4)
+    idx = SparseIndexHIP(indptr, doc_ids, vals, N, device=device)
+    torch.cuda.synchronize()
+    nnz = int(doc_ids.numel())
+    log(f"[sparse] {nnz} postings ({nnz * 8 / 1e9:.2f} GB) built in {time.time() - t0:.1f}s")
+    lens = indptr[1:] - indptr[:-1]
+    touched = lens[q_cols.long()].reshape(nq, L0_q).sum(1).double()
+    # bytes of index a batch of queries needs at least once: the posting lists of its DISTINCT terms (sr_sparse_search
+    # walks the query set in batches of 1024)
+    unique_bytes = 0.0
+    for qb in range(0, nq, 1024):
+        terms = torch.unique(q_cols[qb * L0_q:min(nq, qb + 1024) * L0_q].long())
+        unique_bytes += 8.0 * float(lens[terms].sum().item())
+    idx.search(q_indptr, q_cols, q_vals, k)
+    torch.cuda.synchronize()
+    steps = 3
+    _lib.check(lib.sr_sparse_index_profile(idx._h, 1))
+    ts = time.perf_counter()
+    for _ in range(steps):
+        s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - ts) / steps
+    n_l, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    _lib.check(lib.sr_sparse_index_profile_read(idx._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by)))
+    _lib.check(lib.sr_sparse_index_profile(idx._h, 0))
+    kernel_s = ms.value * 1e-3 / steps
+    rmw = by.value / 8.0 / steps                                    # one LDS read-modify-write per touched posting
+    rmw_rate = rmw / kernel_s
+    lds_peak, lds_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_lds_rmw.json")) as f:
+            mb = json.load(f)
+        lds_peak = max(v for kk, v in mb.items() if kk.startswith("random_b32_wg"))
+        lds_src = "profiles/r02_lds_rmw.json (tools/micro/lds_rmw.hip: random ds_read_b32 + ds_write_b32 on a 32 KB tile, no global traffic)"
+    except Exception:
+        pass
+    hbm_gbps = unique_bytes / kernel_s / 1e9
+    out = {"metric": "sparse inverted-index queries/s (index resident in HBM, top-%d)" % k, "value": round(nq / dt, 1), "unit": "queries/s",
+           "ms_per_pass": round(dt * 1e3, 1), "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "Lion-SP-1B sparse scoring (BASELINE.json configs[2]), synthetic Zipf(1.0) index", "V": V, "N": N, "L0_d": L0_d,
+                      "L0_q": L0_q, "nq": nq, "k": k, "postings": nnz, "mean_postings_touched_per_query": float(touched.mean().item())},
+           "roofline": {"kernel": "sparse_score_kernel", "bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(hbm_gbps / PEAK_HBM_GBPS, 4), "traffic": None, "launches": int(n_l.value),
+                        "kernel_ms_per_pass": round(kernel_s * 1e3, 1), "unique_index_bytes_per_pass": unique_bytes,
+                        "hbm_floor_ms_per_pass": round(unique_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3, 2),
+                        "note": "achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per posting) / "
+                                "kernel time: the HBM floor is a small fraction of the kernel time, i.e. this kernel is NOT HBM-bound - the posting "
+                                "lists are re-read per (query, doc tile) from L2 / Infinity Cache and every touched posting costs one LDS "
+                                "read-modify-write, which is what `lds_rmw` prices"},
+           "lds_rmw": {"bound": "lds", "achieved": rmw_rate, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",
+                       "frac": round(rmw_rate / lds_peak, 4) if lds_peak else None, "rmw_per_pass": rmw, "peak_source": lds_src}}
+    from oracle import scoring as SC
+    h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
+    check = 4
+    nqc = max(args.sparse_cpu_queries, check)
+    hq_indptr = q_indptr[:nqc + 1].cpu().numpy()
+    hq_cols, hq_vals = q_cols[:nqc * L0_q].cpu().numpy(), q_vals[:nqc * L0_q].cpu().numpy()
+    cores = os.cpu_count()
+    runs = []
+    for qt, it in ((4, 8), (4, max(1, cores // 4))):   # first = the 32-thread shape BASELINE.json names; then all cores
+        if (qt, it) in [(r["q_threads"], r["inner_threads"]) for r in runs]:
+            continue
+        tc = time.perf_counter()
+        oi, os_, oc = SC.sparse_retrieve_c(h_indptr, h_ids, h_vals, hq_indptr, hq_cols, hq_vals, k, 0.0, N, q_threads=qt, inner_threads=it)
+        tc = time.perf_counter() - tc
+        runs.append({"q_threads": qt, "inner_threads": it, "qps": nqc / tc, "seconds": tc})
+        log("[sparse] cpu:", runs[-1])
+    gi, gs, gc = i[:check].cpu().numpy(), s[:check].cpu().numpy(), c[:check].cpu().numpy()
+    for q in range(check):
+        assert gc[q] == oc[q], (q, gc[q], oc[q])
+        assert np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), q
+    out["parity"] = f"{check} queries bit-exact (ids and fp32 scores) vs the oracle's C port of numba_score_float + select_topk at full size"
+    best = max(runs, key=lambda r: r["qps"])
+    out["cpu_baseline"] = {"value": round(runs[0]["qps"], 3), "unit": "queries/s", "cores": 32, "kind": "port",
+                           "sample": f"{nqc} queries on the full index, oracle_sparse_retrieve (C/OpenMP port of numba_score_float + select_topk), "
+                                     f"4 query threads x 8 posting threads = the 32-thread shape of README.md:89-94 / indexer.py:459, {runs[0]['seconds']:.1f}s",
+                           "best_shape_on_this_host": {"value": round(best["qps"], 3), "threads": best["q_threads"] * best["inner_threads"],
+                                                       "host_cores": cores}}
+    idx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +297,11 @@ def main():
     ap.add_argument("--n-queries", type=int, default=6980)
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--query-batch", type=int, default=2048, help="queries per query_encode call (eval_batch_size; the reference script uses 128)")
-    ap.add_argument("--encode-batches", type=int, default=16, help="passage batches (x128) for the encode figure")
+    ap.add_argument("--encode-passages", type=int, default=131072, help="synthetic passages pushed through store_embs for the encode figure")
+    ap.add_argument("--token-budget", type=int, default=16384, help="real tokens per doc_encode batch of the encode leg")
+    ap.add_argument("--no-encode", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true")
+    ap.add_argument("--sparse-cpu-queries", type=int, default=768, help="bounded CPU sample of the sparse baseline (~10 s per threading shape)")
     ap.add_argument("--layers", type=int, default=None, help="override num layers (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 / bf16x6 precision-mode measurements")
@@ -133,7 +336,8 @@ def main():
         cfg["num_hidden_layers"] = args.layers
     H = cfg["hidden_size"]
     t_setup = time.time()
-    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=4096).to(device).eval()
+    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=0), max_batch_tokens=65536, max_batch_seqs=8192).to(device).eval()
+    assert model.base_model.resolve_precision() == "fp32"      # no autocast here: the reference's dense-query regime
     # every rank encodes only its block of the queries; the embeddings are all-gathered (second, 57 MB collective)
     q_rows = query_slice(args.n_queries, rank, world)
     q_batches, q_lens = synth_batches(args.n_queries, args.query_batch, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device, rows=q_rows)
@@ -149,7 +353,8 @@ def main():
         f"{args.n_queries} queries, mean {q_lens.mean():.1f} tokens")
 
     def encode_queries():
-        local = [model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches]
+        with torch.no_grad():                                   # eval_dense.py:101 - and no autocast: fp32 regime
+            local = [model.query_encode(input_ids=i, attention_mask=m) for i, m in q_batches]
         local = torch.cat(local) if local else torch.zeros((0, H), dtype=torch.float32, device=device)
         return all_gather_query_reps(local, args.n_queries)
 
@@ -218,6 +423,8 @@ def main():
 
     # ---- the same step with the score kernel in split-bf16 arithmetic (opt-in precision modes of sr_dense_search;
     #      fp32 operands split into bf16 planes, 3 / 6 plane products on the bf16 MFMA pipe, fp32 accumulate) ----
+    mode_steps = min(args.steps, 3)     # secondary figures: a few steps are enough, the default run must stay short
+
     def timed_mode(mode, n_prod, note):
         try:
             index.set_precision(mode)
@@ -225,7 +432,7 @@ def main():
             _lib.check(lib.sr_dense_index_profile(index._h, 1))
             barrier()
             tf0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(mode_steps):
                 step()
             barrier()
             dtf = time.perf_counter() - tf0
@@ -236,8 +443,8 @@ def main():
                 dtf = float(t.item())
             _lib.check(lib.sr_dense_index_profile_read(index._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
             eq_tf = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-            return {"precision": mode, "value": round(args.n_queries * args.steps / dtf, 2), "unit": "queries/s",
-                    "ms_per_step": round(dtf / args.steps * 1e3, 2),
+            return {"precision": mode, "value": round(args.n_queries * mode_steps / dtf, 2), "unit": "queries/s",
+                    "ms_per_step": round(dtf / mode_steps * 1e3, 2), "steps": mode_steps,
                     "roofline": {"kernel": f"dense_split_kernel (bf16 MFMA 16x16x32, {n_prod} products per fp32-equivalent FMA)", "bound": "mfma",
                                  "achieved": round(n_prod * eq_tf, 1), "peak": PEAK_BF16_MFMA_TF,
                                  "unit": f"TFLOP/s (bf16 MFMA work = {n_prod} x algorithmic)",
@@ -272,26 +479,6 @@ def main():
         small.append({"nq": nq_s, "ms_per_search": round(t_s * 1e3, 2), "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                       "frac": round(gbps / PEAK_HBM_GBPS, 4), "bound": "hbm", "kernel": "dense_stream_kernel (exact fp32, D read once)"})
 
-    # ---- secondary figure: passages/s of doc_encode (same engine, doc-length batches) ----
-    def encode_rate(batch):
-        d_batches, d_lens = synth_batches(args.encode_batches * 128, batch, 4.25, 0.35, 8, 192, cfg["vocab_size"], 3, device)
-        model.doc_encode(input_ids=d_batches[0][0], attention_mask=d_batches[0][1])
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        for i_, m_ in d_batches:
-            model.doc_encode(input_ids=i_, attention_mask=m_)
-        torch.cuda.synchronize()
-        te = time.perf_counter() - te
-        tokens = int(d_lens.sum())
-        L = cfg["num_hidden_layers"]
-        flop = tokens * FLOP_PER_TOKEN_1B * L / 16 + 4.0 * float((d_lens.astype(np.float64) ** 2).sum()) * H * L
-        return {"batch": batch, "passages_per_s_per_gpu": round(len(d_lens) / te, 1), "tokens_per_s_per_gpu": round(tokens / te, 1),
-                "achieved_TFLOPs": round(flop / te / 1e12, 1), "frac_of_bf16_mfma_peak": round(flop / te / 1e12 / PEAK_BF16_MFMA_TF, 4),
-                "mean_tokens_per_passage": round(float(d_lens.mean()), 1), "sample_passages": int(len(d_lens))}
-    e128, e512 = encode_rate(128), encode_rate(512)
-    encode = {"passages_per_s_per_gpu": e512["passages_per_s_per_gpu"], "dtype": "bf16 GEMM / fp32 accumulate",
-              "reference_batch_128": e128, "batch_512": e512}
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import scoring as SC
@@ -308,6 +495,42 @@ def main():
                          f"the faiss IndexFlatIP algorithm): {nqs} queries x {ns} docs x {H} took {tc:.2f}s; "
                          f"extrapolated linearly to {args.n_docs} docs; query encoding not included"}
 
+
+    # ---- query-encode regimes side by side (one pass each, synchronised): the headline runs the fp32 regime ----
+    def timed_query_encode(prec):
+        model.base_model.precision = prec
+        try:
+            encode_queries()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            encode_queries()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - tq) * 1e3, 1)
+        finally:
+            model.base_model.precision = "auto"
+    breakdown["query_encode_ms_bf16_regime"] = timed_query_encode("bf16")
+    breakdown["query_encode_regime"] = ("fp32 (reference: no autocast, eval_dense.py:94-106): every GEMM on 3 bf16 planes per operand, "
+                                        "6 plane products, fp32 accumulate; fp32 attention")
+    q_tokens = int(q_lens.sum())
+    breakdown["query_encode_bf16_mfma_TFLOPs"] = round(q_tokens * FLOP_PER_TOKEN_1B * cfg["num_hidden_layers"] / 16 * 6 / t_enc / 1e12, 1)
+
+    # everything below needs the HBM the corpus matrix holds
+    index.close()
+    del index, D, reps_b
+    torch.cuda.empty_cache()
+
+    # ---- stage 2 of the metric: passages/s of the corpus-encode task, through store_embs ----
+    encode = None
+    if not args.no_encode:
+        encode = encode_leg(args, cfg, model, device, rank, world, share_gpu)
+
+    # ---- BASELINE.json configs[2]: sparse inverted-index scoring (single GPU) ----
+    sparse = None
+    if rank == 0 and world == 1 and not args.no_sparse:
+        del model
+        torch.cuda.empty_cache()
+        sparse = sparse_leg(args, device)
+
     if rank == 0:
         res = {
             "metric": "MSMARCO-Dev queries/sec end-to-end (query encode + dense brute-force top-1000)",
@@ -315,13 +538,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Lion-DS-1B dense: 6980 Dev queries encoded (HIP LlamaBiDense, 1B dims, random init, bf16 GEMMs) "
+            "config": {"workload": "Lion-DS-1B dense: 6980 Dev queries encoded (HIP LlamaBiDense, 1B dims, random init, fp32 regime as the reference: "
+                                   "split-bf16 GEMMs with the full fp32 significands, fp32 attention) "
                                    f"+ brute-force fp32 top-{args.topk} over {args.n_docs} x {H} passage embeddings resident in HBM",
                        "n_docs": args.n_docs, "n_queries": args.n_queries, "hidden": H, "topk": args.topk,
                        "query_batch": args.query_batch, "layers": cfg["num_hidden_layers"],
+                       "query_encode_precision": "fp32 regime (3 bf16 planes per operand, 6 products, fp32 accumulate)",
+                       "doc_encode_precision": "bf16 autocast regime", "score_precision": "exact fp32 (k-ordered fmaf chain)",
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
-            "roofline": roofline, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast, "encode": encode, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,
+            "encode": encode, "sparse": sparse,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -43,6 +43,10 @@ def parse_args(argv=None):
     ap.add_argument("--local_rank", type=int, default=-1)
     ap.add_argument("--world_size", type=int, default=1)
     ap.add_argument("--chunk_size", type=int, default=2_000_000)
+    ap.add_argument("--token_budget", type=int, default=16384,
+                    help="real tokens per doc_encode batch (length-bucketed, multi-worker tokenisation); 0 = the reference's "
+                         "loader: eval_batch_size passages padded to the longest, one worker (eval_dense.py:171-179)")
+    ap.add_argument("--tokenize_workers", type=int, default=4)
     args = ap.parse_args(argv)
     if args.eval_metric:
         args.eval_metric = ast.literal_eval(args.eval_metric)     # the reference uses eval() (eval_dense.py:70)
@@ -83,9 +87,16 @@ def write_doc_embeds(args):
     tokenizer = _tokenizer(args.model_name_or_path, args.access_token)
     source = args.data_source or CORPUS_DATASOURCE.get(args.corpus_path, "msmarco")
     dataset = CollectionDataset(corpus_path=args.corpus_path, data_source=source)
-    sampler = DistributedSampler(dataset, shuffle=False) if args.world_size > 1 else None
-    loader = DataLoader(dataset, batch_size=args.eval_batch_size, shuffle=False, num_workers=1, sampler=sampler,
-                        collate_fn=LlamaDenseCollectionCollator(tokenizer=tokenizer, max_length=args.doc_max_length))
+    if args.token_budget > 0:
+        from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
+        rank = dist.get_rank() if args.world_size > 1 else 0
+        loader = TokenBudgetCollectionLoader(dataset, tokenizer, max_length=args.doc_max_length, max_tokens=args.token_budget,
+                                             max_seqs=1024, num_workers=args.tokenize_workers, rank=rank,
+                                             world_size=args.world_size)
+    else:
+        sampler = DistributedSampler(dataset, shuffle=False) if args.world_size > 1 else None
+        loader = DataLoader(dataset, batch_size=args.eval_batch_size, shuffle=False, num_workers=1, sampler=sampler,
+                            collate_fn=LlamaDenseCollectionCollator(tokenizer=tokenizer, max_length=args.doc_max_length))
     model = LlamaBiDense.load_from_lora(args.model_name_or_path, access_token=args.access_token)
     model.to(args.local_rank)
     model.eval()

@@ -36,6 +36,10 @@ def parse_args(argv=None):
     ap.add_argument("--top_k", type=int, default=1000)
     ap.add_argument("--local_rank", type=int, default=-1)
     ap.add_argument("--world_size", type=int, default=1)
+    ap.add_argument("--token_budget", type=int, default=16384,
+                    help="real tokens per encode batch of the indexing task (length-bucketed, multi-worker tokenisation); "
+                         "0 = the reference's loader (eval_sparse.py:94-97)")
+    ap.add_argument("--tokenize_workers", type=int, default=4)
     args = ap.parse_args(argv)
     if args.eval_metric:
         args.eval_metric = ast.literal_eval(args.eval_metric)
@@ -71,9 +75,15 @@ def sparse_index(args):
     source = args.data_source or CORPUS_DATASOURCE.get(args.corpus_path, "msmarco")
     collection = CollectionDataset(corpus_path=args.corpus_path, data_source=source)
     model = LlamaBiSparse.load_from_lora(args.model_name_or_path)
-    sampler = DistributedSampler(collection, shuffle=False) if args.world_size > 1 else None
-    loader = DataLoader(collection, batch_size=args.eval_batch_size, shuffle=False, num_workers=2, sampler=sampler,
-                        collate_fn=LlamaSparseCollectionCollator(tokenizer=tokenizer, max_length=args.doc_max_length))
+    if args.token_budget > 0:
+        from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
+        loader = TokenBudgetCollectionLoader(collection, tokenizer, max_length=args.doc_max_length, max_tokens=args.token_budget,
+                                             max_seqs=256, num_workers=args.tokenize_workers,
+                                             rank=dist.get_rank() if args.world_size > 1 else 0, world_size=args.world_size)
+    else:
+        sampler = DistributedSampler(collection, shuffle=False) if args.world_size > 1 else None
+        loader = DataLoader(collection, batch_size=args.eval_batch_size, shuffle=False, num_workers=2, sampler=sampler,
+                            collate_fn=LlamaSparseCollectionCollator(tokenizer=tokenizer, max_length=args.doc_max_length))
     index_dir = args.index_dir[:-1] if args.index_dir.endswith("/") else args.index_dir
     if args.world_size > 1:
         index_dir = f"{index_dir}_{dist.get_rank()}"               # eval_sparse.py:98-100

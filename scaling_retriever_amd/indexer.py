@@ -44,13 +44,16 @@ def store_embs(model, collection_loader, local_rank, index_dir, device, chunk_si
     so there is one D2H copy per chunk instead of one per batch (indexer.py:56)."""
     if is_query:
         raise NotImplementedError
-    write_freq = max(1, chunk_size // collection_loader.batch_size)
+    batch_size = getattr(collection_loader, "batch_size", None)
     if is_first_worker():
-        print("write_freq: {}, batch_size: {}, chunk_size: {}".format(write_freq, collection_loader.batch_size, chunk_size))
+        print("batch_size: {}, chunk_size: {}".format(batch_size if batch_size else "token budget", chunk_size))
     os.makedirs(index_dir, exist_ok=True)
     enc = _unwrap(model)
     embeddings, embeddings_ids = [], []
     chunk_idx = 0
+    # a chunk is closed after `chunk_size` passages; with fixed-size batches that is every chunk_size // batch_size
+    # batches, exactly the reference's write_freq (indexer.py:32-33, :60)
+    chunk_docs = max(1, chunk_size // batch_size) * batch_size if batch_size else chunk_size
 
     def flush():
         nonlocal embeddings, embeddings_ids, chunk_idx
@@ -64,16 +67,20 @@ def store_embs(model, collection_loader, local_rank, index_dir, device, chunk_si
         embeddings, embeddings_ids = [], []
         chunk_idx += 1
 
+    try:
+        total = len(collection_loader)
+    except TypeError:
+        total = None              # token-budget loaders do not know their batch count up front
     for idx, batch in tqdm(enumerate(collection_loader), disable=not is_first_worker(),
-                           desc=f"encode # {len(collection_loader)} seqs", total=len(collection_loader)):
-        inputs = {k: v.to(device) for k, v in batch.items() if k != "ids"}
+                           desc="encode # {} seqs".format(total if total is not None else "?"), total=total):
+        inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "ids"}
         with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):      # indexer.py:46-52
             reps = enc.doc_encode(**inputs)
         text_ids = batch["ids"]
         assert isinstance(text_ids, list)
         embeddings.append(reps)
         embeddings_ids.extend(text_ids)
-        if (idx + 1) % write_freq == 0:
+        if len(embeddings_ids) >= chunk_docs:
             flush()
     if len(embeddings) != 0:
         print("last embedddings shape = {}".format((sum(len(e) for e in embeddings), embeddings[0].shape[1])))

@@ -281,16 +281,41 @@ class HipLlamaBackbone(torch.nn.Module):
         out = torch.empty((B, width), dtype=torch.float32, device=self._device)
         what = ("sr_encode_sparse" if sparse else "sr_encode_dense") + ("_fp32" if prec == "fp32" else "")
         fn = getattr(self._lib, what)
-        rows_per_call = max(1, min(self.max_batch_seqs, self.max_batch_tokens // max(L, 1)))
-        if rows_per_call * L > self.max_batch_tokens and L > self.max_batch_tokens:
-            raise ValueError(f"sequence length {L} exceeds the workspace ({self.max_batch_tokens} tokens)")
         with torch.cuda.device(self._device):
             stream = _lib.stream_ptr()
-            for b0 in range(0, B, rows_per_call):
-                b1 = min(B, b0 + rows_per_call)
+            for b0, b1 in self._call_ranges(mask, sparse):
                 _lib.check(fn(self._h, ids[b0:b1].data_ptr(), mask[b0:b1].data_ptr(), b1 - b0, L,
                               out[b0:b1].data_ptr(), stream), what)
         return out if src_device == self._device else out.to(src_device)
+
+    def _call_ranges(self, mask, sparse):
+        """Row ranges [b0, b1) per C call.  The workspace holds max_batch_tokens PACKED tokens (pads are not computed), so
+        a batch whose padded size fits goes through in one call; otherwise the rows are cut by the tokens they really
+        pack to - the span plan_rows_kernel keeps per row (csrc/encoder.hip): for the dense head
+        [min(first unmasked, L - len), L), for the sparse head [first unmasked, last unmasked]."""
+        B, L = mask.shape
+        if B <= self.max_batch_seqs and B * L <= self.max_batch_tokens:
+            return [(0, B)]
+        m = mask != 0
+        n = m.sum(1)
+        pos = torch.arange(L, device=mask.device)
+        first = torch.where(m, pos, L).min(1).values
+        if sparse:
+            last = torch.where(m, pos, -1).max(1).values
+            span = torch.where(n > 0, last + 1 - first, 0)
+        else:
+            span = torch.where(n > 0, L - torch.minimum(first, L - n), 0)
+        span = span.cpu().tolist()                    # one small D2H per oversized batch
+        out, b0, tok = [], 0, 0
+        for b, t in enumerate(span):
+            if t > self.max_batch_tokens:
+                raise ValueError(f"row {b} packs to {t} tokens, the workspace holds {self.max_batch_tokens} (raise max_batch_tokens)")
+            if b > b0 and (tok + t > self.max_batch_tokens or b - b0 >= self.max_batch_seqs):
+                out.append((b0, b))
+                b0, tok = b, 0
+            tok += t
+        out.append((b0, B))
+        return out
 
     def last_hidden_state_packed(self):
         """fp32 [n_tokens, H] final-norm hidden states of the last encode call (test hook)."""

@@ -122,8 +122,26 @@ def test_eval_dense_and_sparse_drivers_end_to_end(golden_dir, tmp_path):
     lora, merged = models["dense"]
     emb_dir, out_dir = str(tmp_path / "embs"), str(tmp_path / "out_dense")
     eval_dense.main(["--task_name", "write_doc_embeds", "--model_name_or_path", lora, "--corpus_path", str(tmp_path / "corpus.tsv"),
-                     "--doc_embed_dir", emb_dir, "--eval_batch_size", "16", "--doc_max_length", "16", "--chunk_size", "32"])
+                     "--doc_embed_dir", emb_dir, "--eval_batch_size", "16", "--doc_max_length", "16", "--chunk_size", "32",
+                     "--token_budget", "0"])                       # the reference's loader: 16 passages padded to the longest
     assert json.load(open(os.path.join(emb_dir, "plan.json")))["num_chunks"] == 2
+    # the token-budget pipeline (length-bucketed batches, 2 tokeniser workers) writes the same pid -> vector content
+    emb_dir2 = str(tmp_path / "embs_budget")
+    eval_dense.main(["--task_name", "write_doc_embeds", "--model_name_or_path", lora, "--corpus_path", str(tmp_path / "corpus.tsv"),
+                     "--doc_embed_dir", emb_dir2, "--doc_max_length", "16", "--chunk_size", "32", "--token_budget", "96",
+                     "--tokenize_workers", "2"])
+    from scaling_retriever_amd.utils.utils import obtain_doc_vec_dir_files as _files
+
+    def _by_pid(d):
+        vf, idf = _files(d)
+        return {str(p): v for f, g in zip(vf, idf) for p, v in zip(np.load(g), np.load(f))}
+    seq, bud = _by_pid(emb_dir), _by_pid(emb_dir2)
+    assert set(seq) == set(bud) == {f"d{i}" for i in range(60)}
+    # Same content per passage.  Not the same BITS: a left-padded row's RoPE positions start at its pad count (position_ids =
+    # arange(L), as in the reference), so the bf16 roundings of q / k depend on how long the batch's longest row is -
+    # the reference's own outputs move by the same amount when its batches are regrouped.
+    for p in seq:
+        assert np.linalg.norm(seq[p] - bud[p]) / np.linalg.norm(seq[p]) < 5e-3, p
     eval_dense.main(["--task_name", "retrieval", "--model_name_or_path", lora, "--query_path", str(tmp_path / "queries.tsv"),
                      "--doc_embed_dir", emb_dir, "--out_dir", out_dir, "--top_k", "10", "--query_max_length", "8"])
     run = json.load(open(os.path.join(out_dir, "run.json")))
@@ -171,11 +189,22 @@ def test_eval_dense_and_sparse_drivers_end_to_end(golden_dir, tmp_path):
     lora_s, merged_s = models["sparse"]
     index_dir, out_s = str(tmp_path / "sp_index"), str(tmp_path / "out_sparse")
     eval_sparse.main(["--task_name", "indexing", "--model_name_or_path", lora_s, "--corpus_path", str(tmp_path / "corpus.tsv"),
-                      "--index_dir", index_dir, "--eval_batch_size", "8", "--doc_max_length", "16"])
+                      "--index_dir", index_dir, "--eval_batch_size", "8", "--doc_max_length", "16", "--token_budget", "0"])
     assert os.path.exists(os.path.join(index_dir, "doc_ids.pkl")) and os.path.exists(os.path.join(index_dir, "index_stats.json"))
     eval_sparse.main(["--task_name", "retrieval", "--model_name_or_path", lora_s, "--query_path", str(tmp_path / "queries.tsv"),
                       "--index_dir", index_dir, "--out_dir", out_s, "--top_k", "10", "--query_max_length", "8"])
     run_s = json.load(open(os.path.join(out_s, "run.json")))
+    # same index content through the token-budget pipeline: identical run (pid -> score), whatever the internal doc order
+    index_dir2, out_s2 = str(tmp_path / "sp_index_budget"), str(tmp_path / "out_sparse_budget")
+    eval_sparse.main(["--task_name", "indexing", "--model_name_or_path", lora_s, "--corpus_path", str(tmp_path / "corpus.tsv"),
+                      "--index_dir", index_dir2, "--doc_max_length", "16", "--token_budget", "96", "--tokenize_workers", "2"])
+    eval_sparse.main(["--task_name", "retrieval", "--model_name_or_path", lora_s, "--query_path", str(tmp_path / "queries.tsv"),
+                      "--index_dir", index_dir2, "--out_dir", out_s2, "--top_k", "10", "--query_max_length", "8"])
+    run_s2 = json.load(open(os.path.join(out_s2, "run.json")))
+    for q in run_s:          # same ranking content (scores move by the bf16 / RoPE-offset noise described above)
+        assert len(set(run_s[q]) & set(run_s2[q])) >= 9, q
+        for pid in set(run_s[q]) & set(run_s2[q]):
+            assert abs(run_s[q][pid] - run_s2[q][pid]) < 2e-2 * max(1.0, abs(run_s[q][pid]))
     d_sp = _encode_oracle(LB.sparse_encode, merged_s, cfg, tok, docs, 16)
     q_sp = _encode_oracle(LB.sparse_encode, merged_s, cfg, tok, queries, 8)
     ref_s = q_sp @ d_sp.T
