@@ -57,8 +57,15 @@ def ddp_setup(args):
     """eval_dense.py:29-32.  Works without torchrun too (single process, no process group)."""
     if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.local_rank = int(os.environ["LOCAL_RANK"])
-        torch.cuda.set_device(args.local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", args.local_rank))
+        if os.environ.get("SR_SHARE_GPU") == "1":
+            # dry run of the multi-rank path on a ONE-GPU box (tests): every rank on cuda:0, gloo instead of RCCL, which refuses
+            # two ranks on one device; real runs leave it unset
+            args.local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(args.local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", args.local_rank))
         args.world_size = dist.get_world_size()
     else:
         args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,8 +92,14 @@ def write_doc_embeds(args):
     if is_first_worker():
         os.makedirs(args.doc_embed_dir, exist_ok=True)
     tokenizer = _tokenizer(args.model_name_or_path, args.access_token)
-    source = args.data_source or CORPUS_DATASOURCE.get(args.corpus_path, "msmarco")
-    dataset = CollectionDataset(corpus_path=args.corpus_path, data_source=source)
+    if args.is_beir and args.beir_dataset is not None:            # eval_dense.py:164-169
+        from scaling_retriever_amd.dataset.dataset import BeirDataset
+        from scaling_retriever_amd.utils.beir import load_beir
+        corpus, _, _ = load_beir(args.beir_dataset_dir, args.beir_dataset, split="test")
+        dataset = BeirDataset(corpus, information_type="document")
+    else:
+        source = args.data_source or CORPUS_DATASOURCE.get(args.corpus_path, "msmarco")
+        dataset = CollectionDataset(corpus_path=args.corpus_path, data_source=source)
     if args.token_budget > 0:
         from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
         rank = dist.get_rank() if args.world_size > 1 else 0
@@ -100,8 +113,9 @@ def write_doc_embeds(args):
     model = LlamaBiDense.load_from_lora(args.model_name_or_path, access_token=args.access_token)
     model.to(args.local_rank)
     model.eval()
-    store_embs(model=model, collection_loader=loader, local_rank=args.local_rank, index_dir=args.doc_embed_dir,
-               device=args.local_rank, chunk_size=args.chunk_size)
+    # file names carry the rank (= LOCAL_RANK on the single node the reference runs on, eval_dense.py:188)
+    store_embs(model=model, collection_loader=loader, local_rank=dist.get_rank() if args.world_size > 1 else args.local_rank,
+               index_dir=args.doc_embed_dir, device=args.local_rank, chunk_size=args.chunk_size)
     if args.world_size > 1:
         dist.barrier()
 
@@ -141,7 +155,7 @@ class LocalFaissDenseRetriever(DenseRetriever):
         # one HBM segment per shard file instead of one concatenated host copy (eval_dense.py:113-121)
         total = 0
         for doc_file, id_file in zip(doc_vec_files, doc_id_files):
-            total += self.index.index_data(np.load(doc_file), np.load(id_file).tolist())
+            total += self.index.index_data(np.load(doc_file, mmap_mode="r"), np.load(id_file).tolist())
         print("size of doc reps indexed: ", total)
 
     def get_top_docs(self, dataloader, top_docs):
@@ -166,7 +180,14 @@ def retrieval(args):
     model.to(device)
     model.eval()
     tokenizer = _tokenizer(args.model_name_or_path, args.access_token)
-    q_loader = DataLoader(MSMARCOQueryDataset(args.query_path), batch_size=args.eval_batch_size, shuffle=False, num_workers=0,
+    if args.is_beir and args.beir_dataset is not None:            # eval_dense.py:211-216
+        from scaling_retriever_amd.dataset.dataset import BeirDataset
+        from scaling_retriever_amd.utils.beir import load_beir
+        _, beir_queries, _ = load_beir(args.beir_dataset_dir, args.beir_dataset, split="test")
+        query_dataset = BeirDataset(beir_queries, information_type="query")
+    else:
+        query_dataset = MSMARCOQueryDataset(args.query_path)
+    q_loader = DataLoader(query_dataset, batch_size=args.eval_batch_size, shuffle=False, num_workers=0,
                           collate_fn=LlamaDenseCollectionCollator(tokenizer=tokenizer, max_length=args.query_max_length))
     vec_files, id_files = obtain_doc_vec_dir_files(args.doc_embed_dir)
     # files in plan order (rank-major) get consecutive positions, exactly the order the reference concatenates them in
@@ -175,7 +196,7 @@ def retrieval(args):
     offsets = np.concatenate([[0], np.cumsum(sizes)])
     index = DenseIndexHIP(model.hidden_size, device=device)
     for fi in range(rank, len(vec_files), world):
-        index.add_host_rows(np.load(vec_files[fi]), id_base=int(offsets[fi]))
+        index.add_npy_file(vec_files[fi], id_base=int(offsets[fi]))        # mmap -> pinned ring -> async H2D
     q_reps, qids = generate_query_vecs(model, q_loader, device)
     scores, idx = index.search(q_reps, args.top_k)
     if world > 1:
@@ -214,7 +235,12 @@ def main(argv=None):
     elif args.task_name == "retrieval":
         retrieval(args)
     elif args.task_name == "evaluate_msmarco":
-        evaluate_msmarco(args)
+        return evaluate_msmarco(args)
+    elif args.task_name == "evaluate_beir":                       # eval_dense.py:244-249
+        from scaling_retriever_amd.utils.beir import load_beir
+        from scaling_retriever_amd.utils.metrics import evaluate_beir
+        _, _, qrels = load_beir(args.beir_dataset_dir, args.beir_dataset, split="test")
+        return evaluate_beir(args, qrels)
     else:
         raise NotImplementedError(args.task_name)
     if dist.is_available() and dist.is_initialized():

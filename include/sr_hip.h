@@ -99,8 +99,9 @@ typedef struct sr_sparse_index sr_sparse_index;
 int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_indptr,
                            const int32_t* d_doc_ids, const float* d_vals,
                            int64_t n_terms, int64_t n_docs, sr_stream stream);
-/* Queries as CSR: d_q_indptr int64 [nq+1], d_q_cols int32, d_q_vals fp32 (term
- * order inside a query = accumulation order).  Outputs [nq, k] padded with
+/* Queries as CSR: d_q_indptr int64 [nq+1] (non-decreasing), d_q_cols int32, d_q_vals fp32 (term
+ * order inside a query = accumulation order).  A term id outside [0, n_terms) is an
+ * empty posting list, as in the reference's vocabulary-filled dict (indexer.py:364-370).  Outputs [nq, k] padded with
  * (0, -1); d_out_counts int32 [nq] = number of valid entries per row.
  * Global doc index = id_base + doc * id_stride.                              */
 int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
@@ -173,6 +174,12 @@ int sr_encode_dense_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t*
                          int32_t B, int32_t L, float* d_out, sr_stream stream);
 int sr_encode_sparse_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
                           int32_t B, int32_t L, float* d_out, sr_stream stream);
+/* Both heads from ONE backbone pass - the hybrid model HybridIndexer / HybridRetriever drive
+ * (`batch_sparse_reps, batch_dense_reps = self.model.encode(**inputs)`, indexer.py:764, :939):
+ * d_out_sparse fp32 [B, vocab], d_out_dense fp32 [B, hidden]; fp32 = 0 autocast regime, 1 fp32 regime. */
+int sr_encode_both(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
+                   int32_t B, int32_t L, int32_t fp32, float* d_out_sparse, float* d_out_dense,
+                   sr_stream stream);
 /* Debug/test hook: last_hidden_state (after the final norm) of the packed
  * tokens of the last encode call, fp32 [n_tokens, hidden]; returns n_tokens
  * through *n_tokens.                                                         */

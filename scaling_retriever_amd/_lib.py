@@ -61,6 +61,7 @@ SIGNATURES = {
     "sr_encode_sparse": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "sr_encode_dense_fp32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "sr_encode_sparse_fp32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "sr_encode_both": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sr_model_last_hidden": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     "sr_model_destroy": (c_int, [c_void_p]),
     "sr_lora_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),

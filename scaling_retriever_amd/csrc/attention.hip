@@ -555,11 +555,12 @@ template <int HD, int CKB>
 static int launch_long(const AttnArgs& a, hipStream_t s) {
     constexpr int KC = CKB * 32;
     constexpr size_t lds = (size_t)KC * HD * 2 + (size_t)HD * (KC + 4) * 2 + KC;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_long_kernel<HD, CKB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 3) / 4));
@@ -572,11 +573,12 @@ template <int HD, int MAXKB>
 static int launch_small(const AttnArgs& a, hipStream_t s) {
     constexpr int KC = MAXKB * 32;
     constexpr size_t lds = (size_t)KC * HD * 2 + (size_t)HD * (KC + 4) * 2 + KC;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<HD, MAXKB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     const int max_items = (a.nh / a.nkv) * ((a.max_seqlen + 31) / 32);
     const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)((max_items + 4 * AT_IPW - 1) / (4 * AT_IPW)));
@@ -588,13 +590,14 @@ static int launch_small(const AttnArgs& a, hipStream_t s) {
 template <int HD>
 static int launch_hd(const AttnArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)AT_KC * HD * 2 + (size_t)HD * AT_VT_LD * 2 + AT_KC;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HD, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     if constexpr (HD == 128) {
         if (!a.apply_rope && a.max_seqlen > 64) {

@@ -35,6 +35,19 @@ void sr_set_error(const char* fmt, ...);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: a per-kernel flag array indexed by the CURRENT device, so a
+// process that drives several GPUs sets it on each (set twice by racing threads is harmless: same value).
+#define SR_MAX_DEVICES 64
+struct DeviceOnce {
+    bool done[SR_MAX_DEVICES] = {};
+    // returns the slot to mark after a successful set, or nullptr if already set on the current device
+    bool* pending() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SR_MAX_DEVICES) d = 0;
+        return done[d] ? nullptr : &done[d];
+    }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

@@ -356,11 +356,12 @@ template <int WN>
 static int launch_dense_pipe(const DenseArgs& a, int64_t rows, hipStream_t s) {
     constexpr int TN = 128 * WN;
     constexpr size_t lds = sizeof(float) * 3 * (256 + TN) * (16 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_pipe_kernel<WN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     dim3 grid((unsigned)ceil_div64(rows, 256), (unsigned)ceil_div64(a.nq, TN));
     hipLaunchKernelGGL(dense_score_pipe_kernel<WN>, grid, dim3(512), lds, s, a);
@@ -414,11 +415,12 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int BK = 16, int OCC = (WAVE
 static int launch_dense(const DenseArgs& a, int64_t rows, hipStream_t s) {
     constexpr int TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
     constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK, OCC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     dim3 grid((unsigned)ceil_div64(rows, TM), (unsigned)ceil_div64(a.nq, TN));
     hipLaunchKernelGGL((dense_score_kernel<WAVES_M, WAVES_N, WM, WN, BK, OCC>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);

@@ -222,11 +222,12 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
     SR_REQUIRE(a.n_pairs >= 3 && a.n_pairs <= 6, "dense_split: bad plane-pair count %d", a.n_pairs);
     constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     const dim3 grid((unsigned)ceil_div64(rows, SP_BN), (unsigned)ceil_div64(a.nq, SP_BM));
     hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, a);

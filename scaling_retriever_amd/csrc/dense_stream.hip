@@ -119,13 +119,14 @@ int launch_dense_stream(const DenseStreamArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)ceil_div64(rows, DS_TM));
     const int nqb = (a.nq + 15) / 16;
     const size_t lds = (size_t)nqb * 16 * DS_LDQ * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stream_kernel<3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * DS_LDQ * 4));
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stream_kernel<4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * DS_LDQ * 4));
-        attr_set = true;
+        *attr_slot = true;
     }
     switch (nqb) {
         case 1: hipLaunchKernelGGL(dense_stream_kernel<1>, grid, dim3(256), lds, s, a); break;

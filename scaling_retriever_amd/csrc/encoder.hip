@@ -24,7 +24,7 @@
 
 // ============================================================== small kernels ===
 // ---- plan: per-row span ------------------------------------------------------
-// mode 0 (dense): span = [min(first1, L - len), L); pool_start = L - len (0 if len == 0)
+// mode 0 (dense) and 2 (both heads): span = [min(first1, L - len), L); pool_start = L - len (0 if len == 0)
 // mode 1 (sparse): span = [first1, last1 + 1)
 __global__ void plan_rows_kernel(const int64_t* __restrict__ mask, int B, int L, int mode, int* __restrict__ span_start,
                                  int* __restrict__ span_len, int* __restrict__ pool_start, int* __restrict__ row_len) {
@@ -48,7 +48,7 @@ __global__ void plan_rows_kernel(const int64_t* __restrict__ mask, int B, int L,
         int st, ln, ps;
         if (len == 0) {
             st = 0; ln = 0; ps = 0;
-        } else if (mode == 0) {
+        } else if (mode != 1) {
             ps = L - len;
             st = first < ps ? first : ps;
             ln = L - st;
@@ -100,7 +100,7 @@ __global__ void plan_tokens_kernel(const int64_t* __restrict__ ids, const int64_
         const bool valid = mask[(int64_t)b * L + p] != 0;
         key_valid[t0 + j] = valid ? 1 : 0;
         // sparse head: masked positions inside the span take no part in the max (-2 = skip row)
-        seq_of[t0 + j] = (mode == 1 && !valid) ? -2 : b;
+        seq_of[t0 + j] = (mode != 0 && !valid) ? -2 : b;
     }
 }
 
@@ -798,12 +798,7 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     return SR_OK;
 }
 
-static int encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
-                        float* d_out, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(m->mu);
-    StreamOrder::Scope in_order(m->order, s);
-    int T = 0;
-    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 0, prec, s, &T));
+static int head_dense(sr_model* m, int B, int T, int prec, float* d_out, hipStream_t s) {
     const int H = m->cfg.hidden_size;
     if (T == 0) {
         SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * H * 4, s));
@@ -819,12 +814,7 @@ static int encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* 
     return SR_OK;
 }
 
-static int encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
-                         float* d_out, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(m->mu);
-    StreamOrder::Scope in_order(m->order, s);
-    int T = 0;
-    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, 1, prec, s, &T));
+static int head_sparse(sr_model* m, int B, int T, int prec, float* d_out, hipStream_t s) {
     const int H = m->cfg.hidden_size, V = m->cfg.vocab_size;
     SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
     if (T == 0) return SR_OK;       // log(1 + relu(max over no tokens)) = 0
@@ -851,6 +841,28 @@ static int encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t*
     return SR_OK;
 }
 
+// mode 0: dense head, 1: sparse head, 2: both from ONE backbone pass (the hybrid model)
+static int encode_any(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int mode,
+                      int prec, float* d_dense, float* d_sparse, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    StreamOrder::Scope in_order(m->order, s);
+    int T = 0;
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, mode, prec, s, &T));
+    if (mode != 1) SR_TRY(head_dense(m, B, T, prec, d_dense, s));     // first: its scratch is the sparse head's GEMM input
+    if (mode != 0) SR_TRY(head_sparse(m, B, T, prec, d_sparse, s));
+    return SR_OK;
+}
+
+static int encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
+                        float* d_out, hipStream_t s) {
+    return encode_any(m, d_input_ids, d_attention_mask, B, L, 0, prec, d_out, nullptr, s);
+}
+
+static int encode_sparse(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int prec,
+                         float* d_out, hipStream_t s) {
+    return encode_any(m, d_input_ids, d_attention_mask, B, L, 1, prec, nullptr, d_out, s);
+}
+
 extern "C" int sr_encode_dense(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
                                float* d_out, sr_stream stream) {
     SR_REQUIRE(m && d_out, "sr_encode_dense: null argument");
@@ -875,6 +887,14 @@ extern "C" int sr_encode_sparse_fp32(sr_model* m, const int64_t* d_input_ids, co
     SR_REQUIRE(m && d_out, "sr_encode_sparse_fp32: null argument");
     SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_sparse_fp32: model was created without an lm_head (LlamaBiModel)");
     return encode_sparse(m, d_input_ids, d_attention_mask, B, L, PREC_FP32, d_out, (hipStream_t)stream);
+}
+
+extern "C" int sr_encode_both(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                              int32_t fp32, float* d_out_sparse, float* d_out_dense, sr_stream stream) {
+    SR_REQUIRE(m && d_out_sparse && d_out_dense, "sr_encode_both: null argument");
+    SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_both: model was created without an lm_head (LlamaBiModel)");
+    return encode_any(m, d_input_ids, d_attention_mask, B, L, 2, fp32 ? PREC_FP32 : PREC_BF16, d_out_dense, d_out_sparse,
+                      (hipStream_t)stream);
 }
 
 extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_rows, int64_t* n_tokens, sr_stream stream) {

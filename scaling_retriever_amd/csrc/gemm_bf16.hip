@@ -536,11 +536,12 @@ template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, 
 static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr size_t lds = NS * (size_t)(BN + BM) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    bool* attr_slot = attr_once.pending();
+    if (attr_slot) {
         SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        *attr_slot = true;
     }
     GemmArgs g = g_in;
     // Tile order.  Feature-tile-fastest keeps an XCD on the same 1/8 of W (good while W fits the Infinity Cache).  A weight

@@ -28,6 +28,7 @@ struct SparseArgs {
     const int32_t* skip;  // [n_terms, n_tiles + 1] offsets relative to indptr[t]
     int n_tiles;
     int64_t n_docs;
+    int64_t n_terms;
     const int64_t* q_indptr;
     const int32_t* q_cols;
     const float* q_vals;
@@ -89,11 +90,14 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
         if (tid < 64) {
             int n = 0;
             if (tid < nt) {
+                // a query term the index does not know has an empty posting list (the reference fills its numba dict with
+                // an empty array for every vocabulary id, indexer.py:364-370)
                 const int term = a.q_cols[t0 + tid];
-                const int32_t* sk = a.skip + (int64_t)term * (a.n_tiles + 1) + tile;
+                const bool known = term >= 0 && (int64_t)term < a.n_terms;
+                const int32_t* sk = a.skip + (int64_t)(known ? term : 0) * (a.n_tiles + 1) + tile;
                 const int b = sk[0], e = sk[1];
-                n = e - b;
-                seg_b[tid] = a.indptr[term] + b;
+                n = known ? e - b : 0;
+                seg_b[tid] = a.indptr[known ? term : 0] + b;
                 seg_n[tid] = n;
                 seg_w[tid] = a.q_vals[t0 + tid];
             }
@@ -232,12 +236,13 @@ struct sr_sparse_index {
 };
 
 // postings of the batch's query terms inside tiles [tile_begin, tile_begin + n_t): one thread per query term
-__global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, int n_tiles, const int64_t* __restrict__ q_indptr,
+__global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, int n_tiles, int64_t n_terms,
+                                             const int64_t* __restrict__ q_indptr,
                                              const int32_t* __restrict__ q_cols, int64_t q_begin, int64_t q_end, int tile_begin,
                                              int n_t, unsigned long long* __restrict__ total) {
     const int64_t t = q_indptr[q_begin] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long n = 0;
-    if (t < q_indptr[q_end]) {
+    if (t < q_indptr[q_end] && q_cols[t] >= 0 && (int64_t)q_cols[t] < n_terms) {
         const int32_t* sk = skip + (int64_t)q_cols[t] * (n_tiles + 1);
         n = (unsigned long long)(sk[tile_begin + n_t] - sk[tile_begin]);
     }
@@ -376,6 +381,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             a.skip = idx->skip;
             a.n_tiles = idx->n_tiles;
             a.n_docs = idx->n_docs;
+            a.n_terms = idx->n_terms;
             a.q_indptr = d_q_indptr;
             a.q_cols = d_q_cols;
             a.q_vals = d_q_vals;
@@ -400,7 +406,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 const int64_t nterms = h[1] - h[0];
                 if (nterms > 0)
                     hipLaunchKernelGGL(sparse_count_postings_kernel, dim3((unsigned)ceil_div64(nterms, 256)), dim3(256), 0, s,
-                                       idx->skip, idx->n_tiles, d_q_indptr, d_q_cols, qb, qb + nqb, (int)t0, (int)nt,
+                                       idx->skip, idx->n_tiles, idx->n_terms, d_q_indptr, d_q_cols, qb, qb + nqb, (int)t0, (int)nt,
                                        idx->d_postings);
             }
             SR_TRY(topk_compact(idx->ws, nqb, k, s));

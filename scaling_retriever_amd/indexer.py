@@ -145,7 +145,7 @@ class DenseFlatIndexer(DenseIndexer):
         if isinstance(doc_reps, torch.Tensor) and doc_reps.is_cuda:
             self.index.add_device_rows(doc_reps.float())
         else:
-            self.index.add_host_rows(np.asarray(doc_reps), buffer_size=self.buffer_size)
+            self.index.add_host_rows(doc_reps if isinstance(doc_reps, np.ndarray) else np.asarray(doc_reps), buffer_size=self.buffer_size)
         n_total = self._update_id_mapping(list(doc_ids))
         logger.info("total data indexed %d", n_total)
         assert self.index.ntotal == n_total, (self.index.ntotal, n_total)
@@ -245,29 +245,41 @@ class SparseIndexer:
         self.world_size = get_world_size()
         print("world_size: {}, local_rank: {}".format(self.world_size, self.local_rank))
 
+    def _encode_batch(self, inputs, batch_ids):
+        return self.model.encode(**inputs)
+
     def index(self, collection_loader, id_dict=None):
         doc_ids = {}
         stats = defaultdict(float)
         count = 0
+        # index() builds a whole index: postings are adopted with set_csr, so a container that already holds postings
+        # (a second index() call, or force_new=False over an existing file) would lose them while keeping their doc count
+        if self.sparse_index.nb_docs() != 0 or len(self.sparse_index.doc_ids) != 0:
+            raise ValueError("SparseIndexer.index builds a new index; this container already holds documents "
+                             "(use force_new=True, or IndexDictOfArray.add_batch_document to append)")
         # COO triples stay on the device; ONE stable sort by term at the end builds the CSR (the reference appends
         # posting by posting in Python, inverted_index.py:74-76).  12 B per posting: 13.5 GB for MS MARCO at L0_d = 128.
         dev_rows, dev_cols, dev_vals = [], [], []
+        n_batches = 0
         for t, batch in enumerate(tqdm(collection_loader, disable=not is_first_worker())):
+            n_batches += 1
             inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
+            batch_ids = to_list(batch["ids"]) if isinstance(batch["ids"], torch.Tensor) else batch["ids"]
+            assert isinstance(batch_ids, list)
+            if id_dict:
+                batch_ids = [id_dict[x] for x in batch_ids]
             with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:255-256
-                batch_documents = self.model.encode(**inputs)      # [bz, vocab_size] fp32 on device
+                batch_documents = self._encode_batch(inputs, batch_ids)      # [bz, vocab_size] fp32 on device
             if self.compute_stats:
                 stats["L0_d"] += self.l0(batch_documents).item()
             row_ptr, col, data = sparse_reps_to_csr(batch_documents)
             nnz_per_row = (row_ptr[1:] - row_ptr[:-1])
             row = torch.repeat_interleave(torch.arange(len(nnz_per_row), device=row_ptr.device), nnz_per_row) + count
+            if (count + len(nnz_per_row)) * self.world_size + self.local_rank >= 2 ** 31:
+                raise OverflowError("global document index exceeds int32 (the posting lists hold int32 doc ids, inverted_index.py:22-55)")
             dev_rows.append((row * self.world_size + self.local_rank).to(torch.int32))   # g_row = (row + count) * W + rank
             dev_cols.append(col.clone())
             dev_vals.append(data.clone())
-            batch_ids = to_list(batch["ids"]) if isinstance(batch["ids"], torch.Tensor) else batch["ids"]
-            assert isinstance(batch_ids, list)
-            if id_dict:
-                batch_ids = [id_dict[x] for x in batch_ids]
             has_posting = (nnz_per_row > 0).cpu().numpy()
             all_idxes = (count + np.arange(len(batch_ids))) * self.world_size + self.local_rank
             for _i, _idx in enumerate(all_idxes):            # docs without any posting get no entry (:271-283)
@@ -281,11 +293,17 @@ class SparseIndexer:
             V = max(int(self.sparse_index.dim_voc or 0), int(cols_t.max().item()) + 1 if cols_t.numel() else 0)
             counts = torch.bincount(cols_t.long(), minlength=V)
             indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=counts.device), torch.cumsum(counts, 0)])
-            self.sparse_index.set_csr(indptr.cpu().numpy(), rows_t[order].cpu().numpy(), vals_t[order].cpu().numpy(),
-                                      self.sparse_index.nb_docs() + count)
+            rows_t, vals_t = rows_t[order].contiguous(), vals_t[order].contiguous()
+            n_docs = (count - 1) * self.world_size + self.local_rank + 1 if self.world_size > 1 else count   # nb_docs() = max g_row + 1
+            if self.index_dir is not None:       # the host copy is only needed to write the files
+                self.sparse_index.set_csr(indptr.cpu().numpy(), rows_t.cpu().numpy(), vals_t.cpu().numpy(), n_docs)
+            else:
+                self.sparse_index.n = int(n_docs)
+            # an immediately following SparseRetrieval(index_d=...) scores from these device arrays: no 13 GB round trip
+            self.device_csr = (indptr, rows_t, vals_t, int(n_docs))
 
         if self.compute_stats:
-            stats = {key: value / len(collection_loader) for key, value in stats.items()}
+            stats = {key: value / max(1, n_batches) for key, value in stats.items()}     # mean over batches, as the reference
         if self.index_dir is not None:
             self.sparse_index.save()
             pickle.dump(doc_ids, open(os.path.join(self.index_dir, "doc_ids.pkl"), "wb"))
@@ -296,7 +314,7 @@ class SparseIndexer:
                 with open(os.path.join(self.index_dir, "index_stats.json"), "w") as handler:
                     json.dump(stats, handler)
         else:
-            out = {"index": self.sparse_index, "ids_mapping": doc_ids}
+            out = {"index": self.sparse_index, "ids_mapping": doc_ids, "device_csr": getattr(self, "device_csr", None)}
             if self.compute_stats:
                 out["stats"] = stats
             return out
@@ -320,7 +338,7 @@ def _csr_sorted_by_doc(indptr, doc_ids, vals, device):
 class SparseRetrieval:
     """indexer.py:311-540."""
 
-    _static_cache = {}
+    _static_cache = None      # (the caller's dict - held, so its id cannot be recycled -, device index, n_terms)
 
     def __init__(self, model, config, dim_voc, device, dataset_name=None, index_d=None, compute_stats=False,
                  is_beir=False, **kwargs):
@@ -328,24 +346,39 @@ class SparseRetrieval:
         self.model.eval()
         assert ("index_dir" in config and index_d is None) or ("index_dir" not in config and index_d is not None)
         if "index_dir" in config:
-            self.sparse_index = IndexDictOfArray(config["index_dir"], dim_voc=dim_voc)
-            self.doc_ids = pickle.load(open(os.path.join(config["index_dir"], "doc_ids.pkl"), "rb"))
+            self.sparse_index, self.doc_ids = self._open_index(config["index_dir"], dim_voc)
         else:
             self.sparse_index = index_d["index"]
             self.doc_ids = index_d["ids_mapping"]
         self.device = device
         self.model.to(device)
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
-        indptr, ids, vals = self.sparse_index.csr(dim_voc)
+        self._dev = dev
+        dcsr = index_d.get("device_csr") if index_d is not None else None
         with torch.cuda.device(dev):
-            indptr_t, ids_t, vals_t = _csr_sorted_by_doc(indptr, ids, vals, dev)
-            self.hip_index = SparseIndexHIP(indptr_t, ids_t, vals_t, max(1, self.sparse_index.nb_docs()), device=dev)
+            if dcsr is not None and get_world_size() == 1:
+                # built by SparseIndexer.index in this process: term-major, doc-ascending inside a term, already in HBM
+                indptr_t, ids_t, vals_t, n_docs = dcsr
+                if dim_voc is not None and indptr_t.numel() - 1 < dim_voc:
+                    indptr_t = torch.cat([indptr_t, indptr_t[-1:].expand(dim_voc + 1 - indptr_t.numel())])
+                self.hip_index = SparseIndexHIP(indptr_t, ids_t, vals_t, max(1, n_docs), device=dev)
+            else:
+                self.hip_index = self._build_hip_index(dim_voc, dev)
         self.out_dir = os.path.join(config["out_dir"], dataset_name) if (dataset_name is not None and not is_beir) \
             else config["out_dir"]
         self.doc_stats = index_d["stats"] if (index_d is not None and compute_stats) else None
         self.compute_stats = compute_stats
         if self.compute_stats:
             self.l0 = L0()
+
+    def _open_index(self, index_dir, dim_voc):
+        with open(os.path.join(index_dir, "doc_ids.pkl"), "rb") as f:
+            return IndexDictOfArray(index_dir, dim_voc=dim_voc), pickle.load(f)
+
+    def _build_hip_index(self, dim_voc, dev):
+        indptr, ids, vals = self.sparse_index.csr(dim_voc)
+        indptr_t, ids_t, vals_t = _csr_sorted_by_doc(indptr, ids, vals, dev)
+        return SparseIndexHIP(indptr_t, ids_t, vals_t, max(1, self.sparse_index.nb_docs()), device=dev)
 
     # -- kept for callers of the reference's static helpers (indexer.py:315-344) ------------
     @staticmethod
@@ -361,10 +394,11 @@ class SparseRetrieval:
         """Same signature/returns as the reference: (doc indexes with score > threshold ascending int64,
         NEGATED scores fp32).  Scores come from the HIP scorer with k = all candidates capped at the top-k
         width, so use SparseRetrieval.retrieve for bulk work; this entry point exists for drop-in callers."""
-        key = id(inverted_index_ids)
-        hit = SparseRetrieval._static_cache.get(key)
-        if hit is None:
-            terms = sorted(inverted_index_ids.keys())
+        cache = SparseRetrieval._static_cache
+        if cache is not None and cache[0] is inverted_index_ids and cache[3] == size_collection:
+            hit = cache[1]
+        else:
+            terms = sorted(t for t in inverted_index_ids.keys() if len(inverted_index_ids[t]))
             V = (max(terms) + 1) if terms else 1
             counts = np.zeros(V, np.int64)
             for t in terms:
@@ -374,7 +408,7 @@ class SparseRetrieval:
             vals = np.concatenate([np.asarray(inverted_index_floats[t], np.float32) for t in terms]) if terms else np.zeros(0, np.float32)
             dev = torch.device("cuda", torch.cuda.current_device())
             hit = SparseIndexHIP(*_csr_sorted_by_doc(indptr, ids, vals, dev), size_collection, device=dev)
-            SparseRetrieval._static_cache = {key: hit}
+            SparseRetrieval._static_cache = (inverted_index_ids, hit, V, size_collection)
         k = _lib.load().sr_max_topk()
         cols = np.asarray(indexes_to_retrieve, np.int32)
         s, i, c = hit.search(np.array([0, len(cols)], np.int64), cols, np.asarray(query_values, np.float32), k,
@@ -428,3 +462,188 @@ class SparseRetrieval:
         with open(os.path.join(self.out_dir, "run.json"), "w") as handler:
             json.dump(res, handler)
         return res
+
+
+class ShardedSparseRetrieval(SparseRetrieval):
+    """Doc-sharded SparseRetrieval for world_size > 1 (the reference asserts world_size == 1, eval_sparse.py:114, and
+    needs a merge_indexes pass first, scripts/eval_sparse.sh:19): rank r opens the directory `{index_dir}_{r}` the indexing
+    task wrote (eval_sparse.py:98-100), scores its own documents and the per-shard top-k meet in ONE gather
+    (distributed.ShardedSparseRetriever).  Every rank encodes only its block of the queries; the query CSR is
+    all-gathered (distributed.all_gather_query_csr).  run.json / q_stats.json are written by rank 0."""
+
+    def __init__(self, model, config, dim_voc, device, rank=None, world_size=None, **kwargs):
+        from .distributed import ShardedSparseRetriever
+        self.rank = get_rank() if rank is None else rank
+        self.world_size = get_world_size() if world_size is None else world_size
+        base = config["index_dir"][:-1] if config["index_dir"].endswith("/") else config["index_dir"]
+        self.shard_dir = f"{base}_{self.rank}"
+        self._base_dir = base
+        self._shard_factory = ShardedSparseRetriever
+        super().__init__(model, dict(config, index_dir=self.shard_dir), dim_voc, device, **kwargs)
+
+    def _open_index(self, index_dir, dim_voc):
+        # a shard's doc_ids.pkl holds only the global rows r, r + W, ...: count them here, not with the single-index rule
+        # (IndexDictOfArray: min key == 0, inverted_index.py:44-55)
+        with open(os.path.join(index_dir, "doc_ids.pkl"), "rb") as f:
+            doc_ids = pickle.load(f)
+        index = IndexDictOfArray(index_dir, dim_voc=dim_voc, _count_docs=False)
+        index.n = (max(doc_ids) + 1) if len(doc_ids) else 0      # max g_row + 1 of THIS shard
+        return index, doc_ids
+
+    def _build_hip_index(self, dim_voc, dev):
+        indptr, ids, vals = self.sparse_index.csr(dim_voc)
+        self.sharded = self._shard_factory(indptr, ids, vals, self.sparse_index.nb_docs(), rank=self.rank,
+                                           world_size=self.world_size, device=dev)
+        return self.sharded.index
+
+    def _all_doc_ids(self):
+        ids = {}
+        for r in range(self.world_size):
+            with open(os.path.join(f"{self._base_dir}_{r}", "doc_ids.pkl"), "rb") as f:
+                ids.update(pickle.load(f))
+        return ids
+
+    def retrieve(self, q_loader, topk, threshold=0.):
+        """q_loader yields THIS rank's block of the queries (distributed.query_slice order) or all of them when
+        `q_loader.replicated` is set."""
+        from .distributed import all_gather_query_csr
+        import torch.distributed as dist
+        sparse_query_vecs, qids = self._generate_query_vecs(q_loader)
+        dev = self._dev
+        counts = [len(c) for c, _ in sparse_query_vecs]
+        row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(dev)
+        cols = torch.from_numpy(np.concatenate([c for c, _ in sparse_query_vecs]) if counts else np.zeros(0, np.int32)).to(dev)
+        vals = torch.from_numpy(np.concatenate([v for _, v in sparse_query_vecs]) if counts else np.zeros(0, np.float32)).to(dev)
+        if self.world_size > 1 and not getattr(q_loader, "replicated", False):
+            all_qids = [None] * self.world_size
+            dist.all_gather_object(all_qids, qids)
+            qids = [q for part in all_qids for q in part]
+            row_ptr, cols, vals = all_gather_query_csr(row_ptr, cols, vals, len(qids))
+        scores, ids, counts_t = self.sharded.search(row_ptr, cols, vals, topk, threshold=threshold)
+        if scores is None:
+            return None
+        scores, ids, counts_t = scores.cpu().numpy(), ids.cpu().numpy(), counts_t.cpu().numpy()
+        doc_ids = self._all_doc_ids()
+        res = defaultdict(dict)
+        nnz = (row_ptr[1:] - row_ptr[:-1]).cpu().numpy()
+        stats = {"L0_q": float(nnz.mean()) if len(nnz) else 0.0}
+        for qi, qid in enumerate(qids):
+            r = res[str(qid)]
+            for id_, sc in zip(ids[qi, :counts_t[qi]], scores[qi, :counts_t[qi]]):
+                r[str(doc_ids[int(id_)])] = float(sc)
+        os.makedirs(self.out_dir, exist_ok=True)
+        if self.compute_stats:
+            with open(os.path.join(self.out_dir, "q_stats.json"), "w") as handler:
+                json.dump(stats, handler)
+        with open(os.path.join(self.out_dir, "run.json"), "w") as handler:
+            json.dump(res, handler)
+        return res
+
+
+# ============================================================================== hybrid
+class HybridIndexer(SparseIndexer):
+    """indexer.py:710-857: ONE pass over the collection writes both the inverted index (sparse_index_dir) and the dense
+    shard files embs_{rank}_{chunk}.npy / ids_*.npy / plan.json (dense_index_dir).  model.encode returns
+    (sparse reps [B, V], dense reps [B, H]) from one backbone pass (LlamaBiHybrid -> sr_encode_both)."""
+
+    def __init__(self, model, sparse_index_dir, dense_index_dir, device, chunk_size=2_000_000, compute_stats=False,
+                 dim_voc=None, force_new=True, filename="array_index.h5py", **kwargs):
+        super().__init__(model, sparse_index_dir, device, compute_stats=compute_stats, dim_voc=dim_voc, force_new=force_new,
+                         filename=filename)
+        self.sparse_index_dir, self.dense_index_dir, self.chunk_size = sparse_index_dir, dense_index_dir, chunk_size
+        os.makedirs(dense_index_dir, exist_ok=True)
+        self._dense, self._dense_ids, self._chunk_idx = [], [], 0
+
+    def _flush_dense(self):
+        embs = torch.cat(self._dense).float().cpu().numpy()
+        ids = self._dense_ids
+        if isinstance(ids[0], int):
+            ids = np.array(ids, dtype=np.int64)
+        assert len(embs) == len(ids), (len(embs), len(ids))
+        np.save(os.path.join(self.dense_index_dir, "embs_{}_{}.npy".format(self.local_rank, self._chunk_idx)), embs)
+        np.save(os.path.join(self.dense_index_dir, "ids_{}_{}.npy".format(self.local_rank, self._chunk_idx)), ids)
+        self._dense, self._dense_ids = [], []
+        self._chunk_idx += 1
+
+    def _encode_batch(self, inputs, batch_ids):
+        sparse, dense = self.model.encode(**inputs)
+        self._dense.append(dense)
+        self._dense_ids.extend(batch_ids)
+        if len(self._dense_ids) >= self.chunk_size:
+            self._flush_dense()
+        return sparse
+
+    def index(self, collection_loader, id_dict=None):
+        out = super().index(collection_loader, id_dict=id_dict)
+        if self._dense:
+            print("last embedddings shape = {}".format((len(self._dense_ids), self._dense[0].shape[1])))
+            self._flush_dense()
+        plan = {"nranks": get_world_size(), "num_chunks": self._chunk_idx, "index_path": os.path.join(self.dense_index_dir, "model.index")}
+        print("plan: ", plan)
+        if is_first_worker():
+            with open(os.path.join(self.dense_index_dir, "plan.json"), "w") as fout:
+                json.dump(plan, fout)
+        return out
+
+
+class HybridRetriever(SparseRetrieval):
+    """indexer.py:859-1019: queries are encoded once (both heads), scored against the inverted index and against the flat
+    dense index; writes {out_dir}/sparse/run.json + q_stats.json and {out_dir}/dense/run.json."""
+
+    def __init__(self, model, sparse_index_dir, dense_index_dir, out_dir, dim_voc, device, **kwargs):
+        from .utils.utils import obtain_doc_vec_dir_files
+        super().__init__(model, {"index_dir": sparse_index_dir, "out_dir": out_dir}, dim_voc, device, compute_stats=True)
+        self.sparse_out_dir, self.dense_out_dir = os.path.join(out_dir, "sparse"), os.path.join(out_dir, "dense")
+        if is_first_worker():
+            os.makedirs(self.sparse_out_dir, exist_ok=True)
+            os.makedirs(self.dense_out_dir, exist_ok=True)
+        self.dense_index = DenseFlatIndexer()
+        self.dense_index.init_index(self.model.hidden_size)
+        self._index_encoded_data(*obtain_doc_vec_dir_files(dense_index_dir))
+
+    def _index_encoded_data(self, doc_vec_files, doc_id_files):
+        total = 0
+        for doc_file, id_file in zip(doc_vec_files, doc_id_files):       # one HBM segment per shard file
+            total += self.dense_index.index_data(np.load(doc_file, mmap_mode="r"), np.load(id_file).tolist())
+        print("size of doc reps to index: ", total)
+
+    def _generate_query_vecs(self, q_loader):
+        sparse_query_vecs, dense_query_vecs, qids = [], [], []
+        for t, batch in enumerate(tqdm(q_loader, total=len(q_loader), desc="generate query vecs", disable=not is_first_worker())):
+            inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
+            with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):      # indexer.py:938-939
+                batch_sparse_reps, batch_dense_reps = self.model.encode(**inputs)
+            qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
+            dense_query_vecs.append(batch_dense_reps)
+            row_ptr, cols, vals = sparse_reps_to_csr(batch_sparse_reps)
+            row_ptr, cols, vals = row_ptr.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+            for b in range(len(row_ptr) - 1):
+                sparse_query_vecs.append((cols[row_ptr[b]:row_ptr[b + 1]].astype(np.int32),
+                                          vals[row_ptr[b]:row_ptr[b + 1]].astype(np.float32)))
+        dense_query_vecs = torch.cat(dense_query_vecs)
+        assert len(sparse_query_vecs) == len(dense_query_vecs) == len(qids)
+        return sparse_query_vecs, dense_query_vecs, qids
+
+    def _dense_retrieve(self, query_reps, qids, topk=1000):
+        res = defaultdict(dict)
+        top_doc_ids, top_scores = self.dense_index.search_knn(query_reps, topk)
+        for qid, docids, scores in zip(qids, top_doc_ids, top_scores):
+            for docid, score in zip(docids, scores):
+                if docid is not None:
+                    res[str(qid)][str(docid)] = float(score)
+        return res
+
+    def _sparse_retrieve(self, sparse_query_vecs, qids, threshold=0., topk=1000):
+        return self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
+
+    def retrieve(self, q_loader, topk, id_dict=False, threshold=0.):
+        sparse_query_vecs, dense_query_vecs, qids = self._generate_query_vecs(q_loader)
+        sparse_res, sparse_stats = self._sparse_retrieve(sparse_query_vecs, qids, threshold=threshold, topk=topk)
+        dense_res = self._dense_retrieve(dense_query_vecs, qids, topk=topk)
+        with open(os.path.join(self.sparse_out_dir, "q_stats.json"), "w") as handler:
+            json.dump(sparse_stats, handler)
+        with open(os.path.join(self.sparse_out_dir, "run.json"), "w") as handler:
+            json.dump(sparse_res, handler)
+        with open(os.path.join(self.dense_out_dir, "run.json"), "w") as handler:
+            json.dump(dense_res, handler)
+        return sparse_res, dense_res

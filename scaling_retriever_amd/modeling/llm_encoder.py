@@ -265,6 +265,7 @@ class HipLlamaBackbone(torch.nn.Module):
         return "fp32"
 
     def _encode(self, input_ids, attention_mask, sparse):
+        """sparse: False = dense head, True = sparse head, "both" = (sparse, dense) from one backbone pass."""
         if input_ids.dim() != 2 or attention_mask.shape != input_ids.shape:
             raise ValueError("input_ids and attention_mask must both be [batch, length]")
         prec = self.resolve_precision()
@@ -277,6 +278,16 @@ class HipLlamaBackbone(torch.nn.Module):
         ids = input_ids.to(device=self._device, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=self._device, dtype=torch.int64).contiguous()
         B, L = ids.shape
+        if sparse == "both":
+            out_s = torch.empty((B, self.config.vocab_size), dtype=torch.float32, device=self._device)
+            out_d = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self._device)
+            with torch.cuda.device(self._device):
+                stream = _lib.stream_ptr()
+                for b0, b1 in self._call_ranges(mask, False):          # the dense span is the larger one
+                    _lib.check(self._lib.sr_encode_both(self._h, ids[b0:b1].data_ptr(), mask[b0:b1].data_ptr(), b1 - b0, L,
+                                                        int(prec == "fp32"), out_s[b0:b1].data_ptr(), out_d[b0:b1].data_ptr(),
+                                                        stream), "sr_encode_both")
+            return (out_s, out_d) if src_device == self._device else (out_s.to(src_device), out_d.to(src_device))
         width = self.config.vocab_size if sparse else self.config.hidden_size
         out = torch.empty((B, width), dtype=torch.float32, device=self._device)
         what = ("sr_encode_sparse" if sparse else "sr_encode_dense") + ("_fp32" if prec == "fp32" else "")
@@ -392,18 +403,36 @@ class LLM2Retriever(torch.nn.Module):
             with open(cfg_path) as f:
                 lora_config = json.load(f)
             cls._check_adapter_layout(state, lora_config)
+            # what peft's merge_and_unload would do that this loader does not implement: refuse instead of ignoring
+            if lora_config.get("use_dora"):
+                raise NotImplementedError("DoRA adapters (use_dora) are not supported")
+            if lora_config.get("rank_pattern") or lora_config.get("alpha_pattern"):
+                raise NotImplementedError("per-module rank_pattern / alpha_pattern are not supported")
+            if lora_config.get("bias", "none") not in ("none", None):
+                raise NotImplementedError(f"adapter bias='{lora_config['bias']}' is not supported (Llama linears have no bias)")
             r, alpha = int(lora_config["r"]), float(lora_config["lora_alpha"])
             scale = alpha / (r ** 0.5) if lora_config.get("use_rslora") else alpha / r
             A, Bm, extra = {}, {}, {}
             for k, v in state.items():
                 name, ab = _adapter_target(k)
-                if name is None:
-                    if "modules_to_save" in k:   # fully fine-tuned module shipped inside the adapter
-                        kk = k[len("base_model.model."):] if k.startswith("base_model.model.") else k
-                        kk = kk.replace(".modules_to_save.default", "").replace(".modules_to_save", "")
-                        extra[_canonical_name(kk)] = v
+                if name is not None:
+                    (A if ab == "A" else Bm)[name] = v
                     continue
-                (A if ab == "A" else Bm)[name] = v
+                # A module listed in modules_to_save (e.g. a trained lm_head or embed_tokens, --lora_modules_to_save) ships
+                # as a whole tensor: peft saves it as `base_model.model.<module>.weight` (adapter name and the
+                # `modules_to_save.` level stripped), older files keep `.modules_to_save.<adapter>.`; PeftModel.from_pretrained
+                # + merge_and_unload puts it in place of the base tensor.
+                kk = k[len("base_model.model."):] if k.startswith("base_model.model.") else k
+                if ".original_module." in kk:
+                    continue                                   # peft's frozen copy of the base tensor
+                for tag in (".modules_to_save.default.", ".modules_to_save."):
+                    if tag in kk:
+                        kk = kk.replace(tag, ".")
+                        break
+                if any(t in kk for t in ("lora_embedding_", "lora_magnitude_vector", ".lora_")) or not kk.endswith(".weight"):
+                    raise ValueError(f"adapter tensor '{k}' is neither a LoRA A/B pair of a linear nor a full replacement weight; "
+                                     "loading would silently drop it")
+                extra[_canonical_name(kk)] = v
             if set(A) != set(Bm):
                 raise ValueError("adapter has unmatched lora_A / lora_B tensors")
             lora = {"scale": scale, "A": A, "B": Bm, "extra": extra}
@@ -412,7 +441,13 @@ class LLM2Retriever(torch.nn.Module):
             config = LlamaConfigLite.from_dict(json.load(f))
         weights = _read_checkpoint(base_dir)
         if lora is not None:
-            weights.update(lora.pop("extra"))
+            extra = lora.pop("extra")
+            unknown = [n for n in extra if n not in weights and not (n == "lm_head.weight" and cls.HAS_LM_HEAD)]
+            if unknown:
+                raise ValueError(f"adapter replaces tensors absent from the base checkpoint: {unknown[:3]}")
+            if "lm_head.weight" in extra and config.tie_word_embeddings:
+                config.tie_word_embeddings = False             # the trained head no longer equals embed_tokens
+            weights.update(extra)
             missing = [n for n in lora["A"] if n not in weights]
             if missing:
                 raise ValueError(f"adapter targets tensors absent from the base checkpoint: {missing[:3]}")
@@ -501,6 +536,29 @@ class DecoderOnlyBiDense(LLM2Retriever):
 
 
 class LlamaBiSparse(DecoderOnlyBiSparse):
+    TRANSFORMER_CLS = "LlamaBiForMNTP"
+
+
+class DecoderOnlyBiHybrid(DecoderOnlyBiSparse):
+    """The model HybridIndexer / HybridRetriever drive (/root/reference/scaling_retriever/indexer.py:710-1019:
+    `batch_sparse_reps, batch_dense_reps = self.model.encode(**inputs)`, `self.model.hidden_size`): a LlamaBiForMNTP
+    backbone whose ONE forward pass feeds both heads - the sparse head of llm_encoder.py:186-196 and the dense head of
+    :424-443.  (The reference ships the retriever classes but no encoder class of this shape; eval_reranker.py:120 names a
+    LlamaBiHybridRetrieverForNCE that is not in the tree.)"""
+
+    def __init__(self, base_model, T=0.01):
+        super().__init__(base_model)
+        self.hidden_size = self.base_model.config.hidden_size
+        self.T = T
+
+    def encode(self, **inputs):
+        return self.base_model._encode(inputs["input_ids"], inputs["attention_mask"], sparse="both")
+
+    def rerank_forward(self, **inputs):
+        raise NotImplementedError
+
+
+class LlamaBiHybrid(DecoderOnlyBiHybrid):
     TRANSFORMER_CLS = "LlamaBiForMNTP"
 
 

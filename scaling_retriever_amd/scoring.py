@@ -24,6 +24,8 @@ class DenseIndexHIP:
         self.lib = _lib.load()
         self.dim = int(dim)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._h = ctypes.c_void_p()
         _lib.check(self.lib.sr_dense_index_create(ctypes.byref(self._h), self.dim), "sr_dense_index_create")
         self._segments = []  # keeps the device tensors alive (the C side holds non-owning views)
@@ -37,20 +39,58 @@ class DenseIndexHIP:
         rows = rows.contiguous()
         if id_base is None:
             id_base = self.ntotal
-        _lib.check(self.lib.sr_dense_index_add(self._h, _ptr(rows), rows.shape[0], int(id_base), int(id_stride)),
-                   "sr_dense_index_add")
+        if rows.device != self.device:
+            raise ValueError(f"rows live on {rows.device}, the index on {self.device}")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_dense_index_add(self._h, _ptr(rows), rows.shape[0], int(id_base), int(id_stride)),
+                       "sr_dense_index_add")
         self._segments.append(rows)
 
-    def add_host_rows(self, rows, buffer_size=50000, id_base=None, id_stride=1):
-        """rows: np.float32 [n, dim]; streamed to HBM in `buffer_size`-row pieces."""
-        rows = np.ascontiguousarray(rows, dtype=np.float32)
-        if rows.ndim != 2 or rows.shape[1] != self.dim:
-            raise ValueError(f"expected [n, {self.dim}] rows, got {rows.shape}")
+    def add_host_rows(self, rows, buffer_size=50000, id_base=None, id_stride=1, piece_bytes=64 << 20, n_buffers=8, n_threads=8):
+        """rows: np.float32 [n, dim] - an in-memory array or an np.load(..., mmap_mode="r") view of a shard file.
+        Streamed into ONE HBM segment through a ring of pinned staging buffers: worker threads copy pieces of the
+        source into pinned memory (numpy releases the GIL for the copy, a memory-mapped source is read from the page
+        cache / the file right there) and queue the H2D copy of each piece on a side stream, so file reads, host
+        copies and PCIe transfers overlap and no second host copy of the matrix ever exists (the reference
+        concatenates every shard on the host, eval_dense.py:113-121, then faiss copies it again, indexer.py:203).
+        `buffer_size` (rows per add, indexer.py:198-208) is accepted for signature compatibility."""
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        if rows.dtype != np.float32 or rows.ndim != 2 or rows.shape[1] != self.dim:
+            if rows.ndim != 2 or rows.shape[1] != self.dim:
+                raise ValueError(f"expected [n, {self.dim}] rows, got {rows.shape}")
+            rows = np.asarray(rows, dtype=np.float32)
         n = rows.shape[0]
         dev = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
-        for i in range(0, n, buffer_size):
-            dev[i:i + buffer_size].copy_(torch.from_numpy(rows[i:i + buffer_size]), non_blocking=False)
+        if n == 0:
+            self.add_device_rows(dev, id_base=id_base, id_stride=id_stride)
+            return
+        piece_rows = max(1, int(piece_bytes) // (4 * self.dim))
+        pieces = [(r0, min(n, r0 + piece_rows)) for r0 in range(0, n, piece_rows)]
+        n_buffers = max(1, min(n_buffers, len(pieces)))
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream()
+            bufs = [torch.empty((piece_rows, self.dim), dtype=torch.float32, pin_memory=True) for _ in range(n_buffers)]
+            free = [torch.cuda.Event() for _ in range(n_buffers)]
+            locks = [threading.Lock() for _ in range(n_buffers)]
+
+            def move(i):
+                r0, r1 = pieces[i]
+                b = i % n_buffers
+                with locks[b]:                          # pieces i, i + n_buffers, ... share buffer b, in order
+                    free[b].synchronize()               # its previous H2D copy has left the buffer
+                    np.copyto(bufs[b].numpy()[:r1 - r0], rows[r0:r1])
+                    with torch.cuda.device(self.device), torch.cuda.stream(side):
+                        dev[r0:r1].copy_(bufs[b][:r1 - r0], non_blocking=True)
+                        free[b].record(side)
+            with ThreadPoolExecutor(max_workers=max(1, min(n_threads, n_buffers))) as pool:
+                list(pool.map(move, range(len(pieces))))
+            side.synchronize()
         self.add_device_rows(dev, id_base=id_base, id_stride=id_stride)
+
+    def add_npy_file(self, path, id_base=None, id_stride=1):
+        """One embs_{rank}_{chunk}.npy shard file -> one HBM segment, memory-mapped (never loaded whole on the host)."""
+        self.add_host_rows(np.load(path, mmap_mode="r"), id_base=id_base, id_stride=id_stride)
 
     @property
     def ntotal(self):
@@ -74,8 +114,11 @@ class DenseIndexHIP:
         nq = queries.shape[0]
         scores = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
         ids = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
-        _lib.check(self.lib.sr_dense_search(self._h, _ptr(queries), nq, int(k), _ptr(scores), _ptr(ids),
-                                            _lib.stream_ptr()), "sr_dense_search")
+        if queries.device != self.device:
+            raise ValueError(f"queries live on {queries.device}, the index on {self.device}")
+        with torch.cuda.device(self.device):      # the library allocates its workspace on the current device
+            _lib.check(self.lib.sr_dense_search(self._h, _ptr(queries), nq, int(k), _ptr(scores), _ptr(ids),
+                                                _lib.stream_ptr()), "sr_dense_search")
         return scores, ids
 
     def close(self):
@@ -116,9 +159,10 @@ class SparseIndexHIP:
         self.n_terms = self.indptr.numel() - 1
         self.n_docs = int(n_docs)
         self._h = ctypes.c_void_p()
-        _lib.check(self.lib.sr_sparse_index_create(ctypes.byref(self._h), _ptr(self.indptr), _ptr(self.doc_ids),
-                                                   _ptr(self.vals), self.n_terms, self.n_docs, _lib.stream_ptr()),
-                   "sr_sparse_index_create")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_sparse_index_create(ctypes.byref(self._h), _ptr(self.indptr), _ptr(self.doc_ids),
+                                                       _ptr(self.vals), self.n_terms, self.n_docs, _lib.stream_ptr()),
+                       "sr_sparse_index_create")
 
     def set_workspace_limit(self, nbytes):
         _lib.check(self.lib.sr_sparse_index_set_workspace_limit(self._h, int(nbytes)))
@@ -139,9 +183,10 @@ class SparseIndexHIP:
         scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         counts = torch.empty((nq,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.sr_sparse_search(self._h, _ptr(q_indptr), _ptr(q_cols), _ptr(q_vals), nq, int(k),
-                                             float(threshold), int(id_base), int(id_stride), _ptr(scores), _ptr(ids),
-                                             _ptr(counts), _lib.stream_ptr()), "sr_sparse_search")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_sparse_search(self._h, _ptr(q_indptr), _ptr(q_cols), _ptr(q_vals), nq, int(k),
+                                                 float(threshold), int(id_base), int(id_stride), _ptr(scores), _ptr(ids),
+                                                 _ptr(counts), _lib.stream_ptr()), "sr_sparse_search")
         return scores, ids, counts
 
     def close(self):

@@ -92,3 +92,34 @@ def load_and_evaluate(qrel_file_path, run_file_path, metric):
     res = evaluate(run, qrel, metric=metric)
     print(metric, "==>", res)
     return res
+
+
+def recall_cap_k(run, qrel, k, agg=True):
+    """beir's capped recall R_cap@k [3P beir EvaluateRetrieval.evaluate_custom(metric="r_cap")]: relevant docs among the
+    top k, over min(k, number of relevant docs)."""
+    per_q = {}
+    for q, docs in run.items():
+        if q not in qrel:
+            continue
+        rel = {d for d, r in qrel[q].items() if r > 0}
+        top = [d for d, _ in sorted(docs.items(), key=lambda kv: kv[1], reverse=True)[:k]]
+        denom = min(len(rel), k)
+        per_q[q] = (len(rel.intersection(top)) / denom) if denom else 0.0
+    return sum(per_q.values()) / max(1, len(per_q)) if agg else per_q
+
+
+def evaluate_beir(args, qrels):
+    """/root/reference/scaling_retriever/utils/metrics.py:131-151: drop hits whose doc id equals the query id, then
+    NDCG@10, Recall@100 (trec_eval definitions, over the queries of the qrels that the run answers) and beir's
+    R_cap@100; written to {out_dir}/perf.json.  beir rounds its figures to 5 decimals."""
+    import os
+    with open(os.path.join(args.out_dir, "run.json")) as reader:
+        run = json.load(reader)
+    print("Removing query id from document list")
+    new_run = {qid: {d: v for d, v in docs.items() if d != qid} for qid, docs in run.items()}
+    qrels = {str(q): {str(d): int(r) for d, r in docs.items()} for q, docs in qrels.items()}
+    res = {"NDCG@10": round(ndcg_k(new_run, qrels, 10), 5), "Recall@100": round(recall_k(new_run, qrels, 100), 5),
+           "R_cap@100": round(recall_cap_k(new_run, qrels, 100), 5)}
+    with open(os.path.join(args.out_dir, "perf.json"), "w") as writer:
+        json.dump(res, writer, indent=4)
+    return res

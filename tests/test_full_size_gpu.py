@@ -58,3 +58,39 @@ def test_full_corpus_search_properties(corpus, nq):
     for q in range(2):
         above = (slab[q] > s[q, -1]).nonzero()[:, 0]
         assert set(above.tolist()) <= set(i[q].tolist())
+
+
+def test_full_msmarco_shape_sparse_search_bit_exact():
+    """BASELINE.json configs[2] at FULL size (V = 128 256, N = 8 841 823, 1.12 G postings, Zipf(1.0) lists up to N long,
+    tools/synth.py): a handful of queries through sr_sparse_search vs the oracle's C port of numba_score_float +
+    select_topk - ids and fp32 scores bit-exact - plus the size-independent properties on a larger query batch."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth
+    from oracle import scoring as SC
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    V, N, k = 128256, 8_841_823, 1000
+    indptr, doc_ids, vals, _ = synth.build_index(V, N, 128, dev, 3)
+    q_indptr, q_cols, q_vals = synth.build_queries(V, 256, 32, dev, 4)
+    idx = SparseIndexHIP(indptr, doc_ids, vals, N, device=dev)
+    s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
+    assert bool((c == k).all()) and bool((s[:, :-1] >= s[:, 1:]).all()) and bool((s[:, -1] > 0).all())
+    assert bool(((i >= 0) & (i < N)).all())
+    assert all(len(set(r.tolist())) == k for r in i[:8])                       # no duplicate docs in a row
+    s2, i2, c2 = idx.search(q_indptr, q_cols, q_vals, k)                       # reproducible
+    assert torch.equal(s, s2) and torch.equal(i, i2)
+    # a query alone == the same query inside the batch (tiles and query batches do not interact)
+    one = slice(int(q_indptr[5]), int(q_indptr[6]))
+    s1, i1, _ = idx.search(torch.tensor([0, one.stop - one.start]), q_cols[one], q_vals[one], k)
+    assert torch.equal(s1[0], s[5]) and torch.equal(i1[0], i[5])
+    n_check = 6
+    h = [t.cpu().numpy() for t in (indptr, doc_ids, vals)]
+    hq = (q_indptr[:n_check + 1].cpu().numpy(), q_cols[:n_check * 32].cpu().numpy(), q_vals[:n_check * 32].cpu().numpy())
+    oi, os_, oc = SC.sparse_retrieve_c(*h, *hq, k, 0.0, N, q_threads=n_check, inner_threads=8)
+    for q in range(n_check):
+        assert oc[q] == int(c[q])
+        assert np.array_equal(i[q].cpu().numpy(), oi[q]) and np.array_equal(s[q].cpu().numpy(), os_[q]), q

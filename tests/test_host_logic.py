@@ -138,6 +138,42 @@ if rank == 0:
     print("MERGE_OK")
 else:
     assert gs is None
+
+# ---- sparse twin: query CSR all-gather + doc-sharded inverted-index search (per-shard scorer = oracle test double)
+from scaling_retriever_amd.distributed import all_gather_query_csr
+V, N, nq, k = 40, 203, 9, 12
+cnt = rng.integers(0, 6, size=nq); cnt[3] = 0                                  # ragged, one empty query
+q_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+q_cols = np.concatenate([np.sort(rng.choice(V, size=c, replace=False)) for c in cnt]).astype(np.int32)
+q_vals = rng.random(len(q_cols), dtype=np.float32) + 0.1
+lo, hi = query_slice(nq, rank, W)
+p, c, v = all_gather_query_csr(torch.from_numpy(q_ptr[lo:hi + 1] - q_ptr[lo]), torch.from_numpy(q_cols[q_ptr[lo]:q_ptr[hi]]),
+                               torch.from_numpy(q_vals[q_ptr[lo]:q_ptr[hi]]), nq)
+assert np.array_equal(p.numpy(), q_ptr) and np.array_equal(c.numpy(), q_cols) and np.array_equal(v.numpy(), q_vals)
+dense = (rng.random((N, V)) < 0.2) * (rng.random((N, V), dtype=np.float32) + 0.05)
+def csr_of(rows):                                                              # CSR by term over the given doc rows
+    sub = dense[rows]
+    ids, vals, ptr = [], [], [0]
+    for t in range(V):
+        nz = np.nonzero(sub[:, t])[0]
+        ids.append(nz.astype(np.int32)); vals.append(sub[nz, t].astype(np.float32)); ptr.append(ptr[-1] + len(nz))
+    return np.array(ptr, np.int64), np.concatenate(ids), np.concatenate(vals)
+rows = np.arange(rank, N, W)                                                   # this rank's documents: g_row = local * W + rank
+ptr_r, ids_r, vals_r = csr_of(rows)
+li, ls, lc = SC.sparse_retrieve_c(ptr_r, ids_r, vals_r, q_ptr, q_cols, q_vals, k, 0.0, len(rows))
+gi = np.where(np.arange(k)[None, :] < lc[:, None], li * W + rank, -1)
+ls = np.where(gi >= 0, ls, 0.0).astype(np.float32)
+gs, gids = gather_topk(torch.from_numpy(ls), torch.from_numpy(gi), dst=0)
+if rank == 0:
+    ptr_a, ids_a, vals_a = csr_of(np.arange(N))
+    ei, es, ec = SC.sparse_retrieve_c(ptr_a, ids_a, vals_a, q_ptr, q_cols, q_vals, k, 0.0, N)
+    cs = gs.permute(1, 0, 2).reshape(nq, -1).numpy(); ci = gids.permute(1, 0, 2).reshape(nq, -1).numpy()
+    for q in range(nq):
+        keep = ci[q] >= 0
+        o = np.lexsort((ci[q][keep], -cs[q][keep].astype(np.float64)))[:k]
+        assert np.array_equal(ci[q][keep][o], ei[q, :ec[q]]), q              # ids AND fp32 scores equal the single-index search
+        assert np.array_equal(cs[q][keep][o], es[q, :ec[q]]), q
+    print("SPARSE_MERGE_OK")
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -151,4 +187,4 @@ def test_gather_topk_world_size_2_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "MERGE_OK" in out.stdout
+    assert "MERGE_OK" in out.stdout and "SPARSE_MERGE_OK" in out.stdout

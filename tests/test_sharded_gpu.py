@@ -66,7 +66,7 @@ def test_bench_multi_rank_path_dry_run():
     env = dict(os.environ, SR_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-docs", "300000",
-           "--encode-batches", "1", "--layers", "2", "--no-cpu-baseline"]
+           "--encode-passages", "4096", "--layers", "2", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -74,3 +74,4 @@ def test_bench_multi_rank_path_dry_run():
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
     assert res["fast_mode"]["value"] > 0 and res["small_batch"][0]["nq"] == 1
+    assert res["encode"]["value"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
