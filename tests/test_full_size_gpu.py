@@ -2,6 +2,9 @@
 where the CPU oracle cannot finish: sortedness, id validity, exact linearity in the query, agreement of every returned
 score with an independent torch fp32 dot product, and equality of the top-1 with a chunked torch argmax.  Covers the
 MFMA-tiled kernel (nq > 64) and the streaming kernel (nq <= 64).  Skipped when the device has < 100 GB free."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
