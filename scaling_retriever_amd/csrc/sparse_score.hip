@@ -19,7 +19,6 @@
 #define SP_TERMS 64   // query terms staged per batch (one wave builds the batch's work list)
 #define SP_U 4        // postings per thread and group
 #define SP_GROUP (SP_U * 256)                              // postings per group
-#define SP_MAXG (SP_TERMS * (SP_TILE / SP_GROUP))          // groups per batch of terms, worst case
 
 struct SparseArgs {
     const int64_t* indptr;
@@ -42,23 +41,28 @@ struct SparseArgs {
     uint32_t id_base, id_stride;
 };
 
-// The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term (work list in
-// LDS, built by wave 0 from the skip table).  The groups are walked in term order with the loads of group i + 1 (8 per
-// thread, clamped so that they are always issued) in flight while group i is applied to the LDS score tile, and the
-// barrier - an s_barrier behind lgkmcnt(0) only, so that it does not drain those loads - is taken only after the last
-// group of a term: postings of one term never share a doc, terms do.  Same per-doc addition order as before.
+// The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term.  The run of
+// every query term inside this tile (skip table) is held in REGISTERS, lane j of every wave = term j of the current batch
+// of 64 terms, and read back with v_readlane (wave-uniform j): the group walk needs no LDS bookkeeping at all, so the
+// LDS pipe carries nothing but the score read-modify-writes.  The groups are walked in term order with the loads of
+// group i + 1 (8 per thread, clamped so that they are always issued) in flight while group i is applied to the LDS score
+// tile, and the barrier - an s_barrier behind lgkmcnt(0) only, so that it does not drain those loads - is taken only
+// after the last group of a term: postings of one term never share a doc, terms do.  Same per-doc addition order as the
+// reference's term-serial loop.
+__device__ inline int64_t readlane64(int64_t v, int j) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v & 0xffffffffll), j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 #pragma clang fp contract(off)
     __shared__ float sc[SP_TILE];
-    __shared__ int64_t seg_b[SP_TERMS];
-    __shared__ int seg_n[SP_TERMS];
-    __shared__ float seg_w[SP_TERMS];
-    __shared__ int glist[SP_MAXG];             // term | group << 8 | last-group-of-term << 16
-    __shared__ int s_ng;
     __shared__ int wave_tot[4];
     __shared__ int s_base;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int ql = blockIdx.x;                 // query within batch
     const int64_t q = a.q_base + ql;
     const int tile = a.tile_begin + blockIdx.y;
@@ -67,56 +71,57 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 
     for (int d = tid; d < SP_TILE; d += 256) sc[d] = 0.f;
 
-    auto load_group = [&](int e, bool live, int (&dd)[SP_U], float (&vv)[SP_U], float& w, unsigned& ok) {
-        ok = 0;
-        const int j = e & 255, g = (e >> 8) & 255;
-        const int64_t b = seg_b[j];
-        const int n = seg_n[j];              // >= 1 for every listed group
-        w = seg_w[j];
-#pragma unroll
-        for (int u = 0; u < SP_U; ++u) {
-            const int p = (g * SP_U + u) * 256 + tid;
-            const int pc = p < n ? p : n - 1;
-            dd[u] = a.doc_ids[b + pc];       // raw: nothing may depend on the loaded values before apply_group
-            vv[u] = a.vals[b + pc];
-            ok |= (live && p < n) ? (1u << u) : 0u;
-        }
-    };
-
     const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
     for (int64_t t0 = tb; t0 < te; t0 += SP_TERMS) {
         const int nt = (int)((te - t0) < SP_TERMS ? (te - t0) : SP_TERMS);
-        __syncthreads();  // previous batch fully applied (also covers the zero fill)
-        if (tid < 64) {
-            int n = 0;
-            if (tid < nt) {
-                // a query term the index does not know has an empty posting list (the reference fills its numba dict with
-                // an empty array for every vocabulary id, indexer.py:364-370)
-                const int term = a.q_cols[t0 + tid];
-                const bool known = term >= 0 && (int64_t)term < a.n_terms;
-                const int32_t* sk = a.skip + (int64_t)(known ? term : 0) * (a.n_tiles + 1) + tile;
-                const int b = sk[0], e = sk[1];
-                n = known ? e - b : 0;
-                seg_b[tid] = a.indptr[known ? term : 0] + b;
-                seg_n[tid] = n;
-                seg_w[tid] = a.q_vals[t0 + tid];
-            }
-            const int ngr = (n + SP_GROUP - 1) / SP_GROUP;
-            int incl = ngr;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off);
-                if (tid >= off) incl += o;
-            }
-            const int pre = incl - ngr;
-            for (int g = 0; g < ngr; ++g) glist[pre + g] = tid | (g << 8) | ((g == ngr - 1) ? (1 << 16) : 0);
-            if (tid == 63) s_ng = incl;
+        // lane j: run of term j inside this tile (every wave holds the same 64 entries)
+        int64_t seg_b = 0;
+        int seg_n = 0;
+        float seg_w = 0.f;
+        if (lane < nt) {
+            // a query term the index does not know has an empty posting list (the reference fills its numba dict with
+            // an empty array for every vocabulary id, indexer.py:364-370)
+            const int term = a.q_cols[t0 + lane];
+            const bool known = term >= 0 && (int64_t)term < a.n_terms;
+            const int32_t* sk = a.skip + (int64_t)(known ? term : 0) * (a.n_tiles + 1) + tile;
+            const int b = sk[0], e = sk[1];
+            seg_n = known ? e - b : 0;
+            seg_b = a.indptr[known ? term : 0] + b;
+            seg_w = a.q_vals[t0 + lane];
         }
-        __syncthreads();
-        const int ng = s_ng;
-        if (ng == 0) continue;
-        int dA[SP_U], dB[SP_U];
-        float vA[SP_U], vB[SP_U], wA, wB;
-        auto apply_group = [&](const int (&dd)[SP_U], const float (&vv)[SP_U], float w, unsigned ok, int e) {
+        uint64_t todo = __ballot(seg_n > 0);          // terms with postings here, walked in ascending lane = query order
+        if (t0 == tb) __syncthreads();                // zero fill done (later batches: the last term's barrier covers it)
+        if (todo == 0) continue;
+
+        // wave-uniform cursor over (term j, group g of that term)
+        struct Cur { int j, g, ngr, n; int64_t b; float w; };
+        auto first_of = [&](uint64_t& m, Cur& c) {
+            c.j = __builtin_ctzll(m);
+            m &= m - 1;
+            c.g = 0;
+            c.n = __builtin_amdgcn_readlane(seg_n, c.j);
+            c.ngr = (c.n + SP_GROUP - 1) / SP_GROUP;
+            c.b = readlane64(seg_b, c.j);
+            c.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(seg_w), c.j));
+        };
+        auto advance = [&](uint64_t& m, Cur& c) -> bool {     // false: c was the last group of the batch
+            if (c.g + 1 < c.ngr) { ++c.g; return true; }
+            if (m == 0) return false;
+            first_of(m, c);
+            return true;
+        };
+        auto load_group = [&](const Cur& c, bool live, int (&dd)[SP_U], float (&vv)[SP_U], unsigned& ok) {
+            ok = 0;
+#pragma unroll
+            for (int u = 0; u < SP_U; ++u) {
+                const int p = (c.g * SP_U + u) * 256 + tid;
+                const int pc = p < c.n ? p : c.n - 1;
+                dd[u] = a.doc_ids[c.b + pc];       // raw: nothing may depend on the loaded values before apply_group
+                vv[u] = a.vals[c.b + pc];
+                ok |= (live && p < c.n) ? (1u << u) : 0u;
+            }
+        };
+        auto apply_group = [&](const int (&dd)[SP_U], const float (&vv)[SP_U], float w, unsigned ok, bool last_of_term) {
             // doc ids are unique inside one posting list: the group's reads can all be in flight before its writes
             int d[SP_U];
             float cur[SP_U];
@@ -131,21 +136,27 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
                     const float prod = w * vv[u];
                     sc[d[u]] = cur[u] + prod;
                 }
-            if (e & (1 << 16))   // term-serial: the next term may touch the same docs
+            if (last_of_term)   // term-serial: the next term may touch the same docs
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
         // two groups per trip, the register sets swapping roles (a copy would have to wait for the loads it copies)
-        int eA = glist[0], eB;
+        int dA[SP_U], dB[SP_U];
+        float vA[SP_U], vB[SP_U];
         unsigned okA, okB;
-        load_group(eA, true, dA, vA, wA, okA);
-        for (int i = 0; i < ng; i += 2) {
-            eB = glist[i + 1 < ng ? i + 1 : i];
-            load_group(eB, i + 1 < ng, dB, vB, wB, okB);
-            apply_group(dA, vA, wA, okA, eA);
-            if (i + 1 >= ng) break;
-            eA = glist[i + 2 < ng ? i + 2 : i + 1];
-            load_group(eA, i + 2 < ng, dA, vA, wA, okA);
-            apply_group(dB, vB, wB, okB, eB);
+        Cur cA, cB;
+        first_of(todo, cA);
+        load_group(cA, true, dA, vA, okA);
+        for (;;) {
+            cB = cA;
+            const bool moreB = advance(todo, cB);
+            load_group(cB, moreB, dB, vB, okB);            // re-loads cA's group (unused) when there is no next one
+            apply_group(dA, vA, cA.w, okA, cA.g == cA.ngr - 1);
+            if (!moreB) break;
+            cA = cB;
+            const bool moreA = advance(todo, cA);
+            load_group(cA, moreA, dA, vA, okA);
+            apply_group(dB, vB, cB.w, okB, cB.g == cB.ngr - 1);
+            if (!moreA) break;
         }
     }
     __syncthreads();
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
     }
     // block exclusive scan of cnt
     int incl = cnt;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int wave = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) {
         int o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
