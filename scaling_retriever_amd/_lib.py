@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsr_hip.so")
+LIB_PATH = os.environ.get("SR_HIP_LIB") or os.path.join(_HERE, "libsr_hip.so")     # SR_HIP_LIB: diagnostic builds (tools/micro)
 
 SR_OK, SR_ERR_INVALID, SR_ERR_HIP, SR_ERR_NOMEM, SR_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 SR_DTYPE_F32, SR_DTYPE_BF16 = 0, 1

@@ -19,6 +19,12 @@
 #define SP_TERMS 64   // query terms staged per batch (one wave builds the batch's work list)
 #define SP_U 4        // postings per thread and group
 #define SP_GROUP (SP_U * 256)                              // postings per group
+#ifndef SP_DIAG
+#define SP_DIAG 0
+#endif
+#ifndef SP_RING
+#define SP_RING 3     // register sets of the group walk: SP_RING - 1 groups of loads in flight per workgroup
+#endif
 
 struct SparseArgs {
     const int64_t* indptr;
@@ -49,6 +55,9 @@ struct SparseArgs {
 // tile, and the barrier - an s_barrier behind lgkmcnt(0) only, so that it does not drain those loads - is taken only
 // after the last group of a term: postings of one term never share a doc, terms do.  Same per-doc addition order as the
 // reference's term-serial loop.
+typedef int i32x2_u __attribute__((ext_vector_type(2), aligned(4)));      // 8-byte loads from 4-byte aligned runs
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
 __device__ inline int64_t readlane64(int64_t v, int j) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v & 0xffffffffll), j);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
@@ -57,7 +66,7 @@ __device__ inline int64_t readlane64(int64_t v, int j) {
 
 __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 #pragma clang fp contract(off)
-    __shared__ float sc[SP_TILE];
+    __shared__ float sc[SP_TILE + 64];         // + one dummy slot per lane for the postings beyond a run's end
     __shared__ int wave_tot[4];
     __shared__ int s_base;
 
@@ -110,53 +119,94 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
             first_of(m, c);
             return true;
         };
-        auto load_group = [&](const Cur& c, bool live, int (&dd)[SP_U], float (&vv)[SP_U], unsigned& ok) {
-            ok = 0;
+        // A group is SP_GROUP = 1024 consecutive postings of one term; thread t takes postings t, t + 256, t + 512, t + 768
+        // (coalesced 4-byte loads from a wave-uniform base + one 32-bit lane offset, the 1 KB steps in the instruction's
+        // immediate; consecutive docs land in consecutive LDS banks).  FULL groups - all of a heavy term's run but its
+        // tail - need no bounds handling: per posting one subtract, one shift, the LDS read, the multiply, the add and
+        // the LDS write.  The tail group clamps its loads to the run and sends the lanes beyond it to a dummy slot past
+        // the tile (no exec-mask branches either way).
+        // SP_RING register sets keep SP_RING - 1 groups of loads in flight, also across term boundaries.  Loads are ALWAYS
+        // issued (past the last group they re-read it), which keeps hipcc's wait counts static (vmcnt(16..23) in the loop).
+        // What bounds the walk (tools/micro/sparse_diag.sh, full MSMARCO shape, one pass of 6 980 queries): the complete
+        // kernel 352 ms; posting loads alone (tile untouched) 281 ms; LDS read-modify-writes alone (no loads) 305 ms - the
+        // two sides overlap almost completely and each is within 15-20 % of the whole, so neither fewer VALU instructions
+        // (40 -> 9 per posting slot), nor a deeper ring (2 / 3 / 4 / 6 sets: 344 - 355 ms), nor dropping the LDS bookkeeping
+        // moved it by more than 5 %; skipping the LDS instructions of all-dummy wave steps with wave-uniform branches made it
+        // 24 % SLOWER (the reads of a group no longer fly together).
+        auto load_group = [&](const Cur& c, int (&dd)[SP_U], float (&vv)[SP_U]) {
+            const int32_t* ib = a.doc_ids + c.b;       // wave-uniform
+            const float* vb = a.vals + c.b;
+            const uint32_t p0 = (uint32_t)c.g * SP_GROUP + (uint32_t)tid;
+            // one branch-free form for full and tail groups (a uniform branch around the loads makes hipcc merge its wait
+            // counts pessimistically and drain the ring): clamp to the run, lanes beyond it go to their dummy slot
+            const uint32_t last = (uint32_t)c.n - 1u;
 #pragma unroll
             for (int u = 0; u < SP_U; ++u) {
-                const int p = (c.g * SP_U + u) * 256 + tid;
-                const int pc = p < c.n ? p : c.n - 1;
-                dd[u] = a.doc_ids[c.b + pc];       // raw: nothing may depend on the loaded values before apply_group
-                vv[u] = a.vals[c.b + pc];
-                ok |= (live && p < c.n) ? (1u << u) : 0u;
+                const uint32_t p = p0 + 256u * u;
+                const uint32_t pc = p < last ? p : last;
+#if SP_DIAG == 2      // diagnostic build (tools/micro/sparse_diag.sh): no posting loads, synthetic in-tile doc ids
+                dd[u] = (int)doc0 + (int)((pc * 2654435761u) >> 19);
+                vv[u] = 1.0f;
+#else
+                dd[u] = ib[pc];       // raw: nothing may depend on the loaded values before apply_group (a use here would
+                vv[u] = vb[pc];       // make the compiler wait for the loads right away and drain the ring)
+#endif
             }
         };
-        auto apply_group = [&](const int (&dd)[SP_U], const float (&vv)[SP_U], float w, unsigned ok, bool last_of_term) {
-            // doc ids are unique inside one posting list: the group's reads can all be in flight before its writes
+        auto apply_group = [&](const int (&dd)[SP_U], const float (&vv)[SP_U], float w, bool last_of_term, uint32_t left) {
+            // doc ids are unique inside one posting list: the group's reads can all be in flight before its writes;
+            // `left` = postings of the run from this group's first one on: lanes at or beyond it use their dummy slot
             int d[SP_U];
             float cur[SP_U];
+#if SP_DIAG == 1          // diagnostic build: loads only, the score tile is not touched (one dummy-slot update per group)
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) acc += (float)dd[u] * vv[u];
+                sc[SP_TILE + lane] += acc * w;
+                if (last_of_term) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                return;
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < SP_U; ++u) {
-                d[u] = (ok & (1u << u)) ? dd[u] - (int)doc0 : 0;
+                d[u] = ((uint32_t)tid + 256u * u < left) ? dd[u] - (int)doc0 : SP_TILE + lane;
                 cur[u] = sc[d[u]];
             }
 #pragma unroll
-            for (int u = 0; u < SP_U; ++u)
-                if (ok & (1u << u)) {
-                    const float prod = w * vv[u];
-                    sc[d[u]] = cur[u] + prod;
-                }
+            for (int u = 0; u < SP_U; ++u) {
+                const float prod = w * vv[u];
+                sc[d[u]] = cur[u] + prod;
+            }
             if (last_of_term)   // term-serial: the next term may touch the same docs
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
-        // two groups per trip, the register sets swapping roles (a copy would have to wait for the loads it copies)
-        int dA[SP_U], dB[SP_U];
-        float vA[SP_U], vB[SP_U];
-        unsigned okA, okB;
-        Cur cA, cB;
-        first_of(todo, cA);
-        load_group(cA, true, dA, vA, okA);
-        for (;;) {
-            cB = cA;
-            const bool moreB = advance(todo, cB);
-            load_group(cB, moreB, dB, vB, okB);            // re-loads cA's group (unused) when there is no next one
-            apply_group(dA, vA, cA.w, okA, cA.g == cA.ngr - 1);
-            if (!moreB) break;
-            cA = cB;
-            const bool moreA = advance(todo, cA);
-            load_group(cA, moreA, dA, vA, okA);
-            apply_group(dB, vB, cB.w, okB, cB.g == cB.ngr - 1);
-            if (!moreA) break;
+        // ring of SP_RING register sets: set s holds group i = s (mod SP_RING); while group i is applied, groups
+        // i + 1 .. i + SP_RING - 1 are in flight
+        int dR[SP_RING][SP_U];
+        float vR[SP_RING][SP_U];
+        float wR[SP_RING];
+        uint32_t leftR[SP_RING];
+        bool lastR[SP_RING], liveR[SP_RING];
+        Cur head;                                  // cursor of the most recently LOADED group
+        first_of(todo, head);
+        bool more = true;
+#pragma unroll
+        for (int s2 = 0; s2 < SP_RING - 1; ++s2) {
+            load_group(head, dR[s2], vR[s2]);
+            wR[s2] = head.w; lastR[s2] = head.g == head.ngr - 1; liveR[s2] = more; leftR[s2] = (uint32_t)(head.n - head.g * SP_GROUP);
+            if (more) { Cur nx = head; more = advance(todo, nx); if (more) head = nx; }
+        }
+        for (bool done = false; !done;) {
+#pragma unroll
+            for (int s2 = 0; s2 < SP_RING; ++s2) {
+                const int ld = (s2 + SP_RING - 1) % SP_RING;
+                load_group(head, dR[ld], vR[ld]);
+                wR[ld] = head.w; lastR[ld] = head.g == head.ngr - 1; liveR[ld] = more; leftR[ld] = (uint32_t)(head.n - head.g * SP_GROUP);
+                if (more) { Cur nx = head; more = advance(todo, nx); if (more) head = nx; }
+                if (!liveR[s2]) { done = true; break; }
+                apply_group(dR[s2], vR[s2], wR[s2], lastR[s2], leftR[s2]);
+            }
         }
     }
     __syncthreads();
