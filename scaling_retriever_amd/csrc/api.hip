@@ -26,7 +26,7 @@ extern "C" int sr_gemm_bf16(const void* d_A, const void* d_W, int32_t M, int32_t
     SR_REQUIRE(epilogue != EPI_SEGMAX || d_seq_of, "sr_gemm_bf16: epilogue 3 needs d_seq_of");
     GemmArgs g{};
     g.A = (const bf16_t*)d_A; g.W = (const bf16_t*)d_W; g.M = M; g.N = N; g.K = K; g.C = d_C; g.seq_of = d_seq_of; g.out_ld = N;
-    if (epilogue != EPI_SEGMAX && d_seq_of && getenv("SR_GEMM_STAMPS")) {   // tools/micro diagnostics: d_seq_of carries the stamp buffer
+    if (epilogue != EPI_SEGMAX && d_seq_of && sr_dev_getenv("SR_GEMM_STAMPS")) {   // tools/micro diagnostics: d_seq_of carries the stamp buffer
         g.stamps = (unsigned long long*)d_seq_of;
         g.seq_of = nullptr;
     }

@@ -601,7 +601,7 @@ static int launch_hd(const AttnArgs& a, hipStream_t s) {
     }
     if constexpr (HD == 128) {
         if (!a.apply_rope && a.max_seqlen > 64) {
-            const char* e = getenv("SR_ATTN_CKB");      // A/B switch: key blocks per chunk for head dim 128 (2 | 3 | 8)
+            const char* e = sr_dev_getenv("SR_ATTN_CKB");      // A/B switch: key blocks per chunk for head dim 128 (2 | 3 | 8)
             const int ckb = e ? atoi(e) : 2;
             if (ckb == 2) return launch_long<HD, 2>(a, s);
             if (ckb == 3) return launch_long<HD, 3>(a, s);

@@ -8,6 +8,17 @@
 
 void sr_set_error(const char* fmt, ...);
 
+// Development switches (A/B tile plans, kernel variants, diagnostics) are read from the environment ONLY when
+// SR_DEV_SWITCHES=1 is set as well: a stray SR_* variable in a production environment cannot change which kernel runs.
+// tests/ and tools/ that force a path set both.
+#include <stdlib.h>
+#include <string.h>
+static inline const char* sr_dev_getenv(const char* name) {
+    const char* on = getenv("SR_DEV_SWITCHES");
+    if (!on || strcmp(on, "1") != 0) return nullptr;
+    return getenv(name);
+}
+
 #define SR_CHECK_HIP(expr)                                                                   \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

@@ -502,7 +502,7 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
     int TN;
-    const char* env_variant = getenv("SR_DENSE_VARIANT");   // A/B switch, read per call: 5 = pipelined kernel (default), 1 = plain double buffer
+    const char* env_variant = sr_dev_getenv("SR_DENSE_VARIANT");   // A/B switch, read per call: 5 = pipelined kernel (default), 1 = plain double buffer
     const int variant = env_variant ? atoi(env_variant) : 5;
     if (nq > 128) { cfg = 0; TN = (variant == 4) ? 128 : 256; }
     else if (nq > 64) { cfg = 1; TN = 128; }

@@ -548,9 +548,9 @@ static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     // matrix far larger than that (the 525 MB vocabulary head) would be streamed from HBM once per token tile: walk the
     // token tiles fastest instead, so that a W tile is used by all of them while it is hot and W is read once.
     g.m_fastest = ((int64_t)g.N * g.K * 2 > (128ll << 20) && (int64_t)g.N > 4 * (int64_t)g.M) ? 1 : 0;
-    if (const char* e = getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
+    if (const char* e = sr_dev_getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
-    const char* env = getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
+    const char* env = sr_dev_getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
     // resident workgroups on 256 CUs: one 8-wave workgroup, up to 3 of 4 waves, up to 8 single-wave ones (LDS permitting)
     constexpr int64_t by_lds = (160 * 1024) / lds;
     const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (by_lds > 3 ? 3 : by_lds) : (WAVES_N * WAVES_M == 1 ? (by_lds > 8 ? 8 : by_lds) : 1));
@@ -582,7 +582,7 @@ static double plan_cost(int64_t big_tiles, int64_t small_tiles) {
 
 // rows of g.M handled with 256^2 tiles (0 = none, g.M = all)
 static int plan_big_rows(const GemmArgs& g, bool small_allowed) {
-    const char* env = getenv("SR_GEMM_TILE");   // test / A-B switch: 128 | 256 | split (read per call)
+    const char* env = sr_dev_getenv("SR_GEMM_TILE");   // test / A-B switch: 128 | 256 | split (read per call)
     if (env && *env) {
         if (atoi(env) == 256) return g.M;
         if (atoi(env) == 128) return 0;
@@ -608,13 +608,13 @@ static int plan_big_rows(const GemmArgs& g, bool small_allowed) {
 
 template <int EPI>
 static int launch_big(const GemmArgs& g, hipStream_t s) {
-    const char* env = getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
+    const char* env = sr_dev_getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
     if (g.K / G_BK >= 4 && !(env && *env == '0')) return launch_cfg<EPI, 2, 4, 8, 4, true>(g, s);
     return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);
 }
 
 static bool env_off(const char* name) {
-    const char* e = getenv(name);
+    const char* e = sr_dev_getenv(name);
     return e && *e == '0';
 }
 
@@ -652,7 +652,7 @@ static GemmArgs rows_from(const GemmArgs& g, int row0) {
 
 // token rows up to which the single-wave streaming configurations are used (SR_GEMM_SKINNY = 0 disables, = n overrides)
 static int skinny_max_rows() {
-    const char* e = getenv("SR_GEMM_SKINNY");
+    const char* e = sr_dev_getenv("SR_GEMM_SKINNY");
     if (!e || !*e) return 64;
     return atoi(e);
 }

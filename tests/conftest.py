@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# tests force kernel variants / tile plans through the library's development switches (SR_GEMM_TILE, SR_DENSE_VARIANT ...),
+# which libsr_hip.so only honours when SR_DEV_SWITCHES=1 (csrc/common.h: sr_dev_getenv)
+os.environ["SR_DEV_SWITCHES"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -286,3 +286,41 @@ def test_dense_pipelined_kernel_equals_plain_kernel(nq, n, h, k, monkeypatch):
     monkeypatch.setenv("SR_DENSE_VARIANT", "1")
     s1, i1 = idx.search(Q, k)
     assert torch.equal(s1, s5) and torch.equal(i1, i5)
+
+
+def test_topk_ties_straddling_rank_k_resolve_by_ascending_doc_index():
+    """The reference's select_topk keeps an ARBITRARY k of the docs tied at the cut (np.argpartition, indexer.py:315-322) and
+    faiss keeps whichever it met first; here the rule is fixed - score descending, then doc index ascending - and must hold
+    exactly when a group of equal scores straddles rank k (a comparison sorted by id cannot see a wrong choice there)."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP, SparseIndexHIP
+    # sparse: one posting list, all values equal except a few higher ones -> 20 000 docs tied below 5 leaders
+    N, k = 20000, 37
+    ids = np.arange(N, dtype=np.int32)
+    vals = np.full(N, 0.5, np.float32)
+    leaders = np.array([19000, 7, 12345, 8191, 8192])
+    vals[leaders] = 2.0
+    idx = SparseIndexHIP(np.array([0, N], np.int64), ids, vals, N)
+    s, i, c = idx.search(np.array([0, 1], np.int64), np.array([0], np.int32), np.array([1.5], np.float32), k)
+    tied = np.setdiff1d(np.arange(N), leaders)[:k - len(leaders)]              # the LOWEST doc indices of the tie group
+    assert int(c) == k
+    assert i[0].cpu().numpy().tolist() == sorted(leaders.tolist()) + tied.tolist()
+    assert np.array_equal(s[0].cpu().numpy(), np.float32([3.0] * 5 + [0.75] * (k - 5)))
+    oi, os_ = O.select_topk(np.arange(N, dtype=np.int64), -(vals * np.float32(1.5)), k)
+    assert np.array_equal(oi, i[0].cpu().numpy()) and np.array_equal(os_, s[0].cpu().numpy())
+    # dense: duplicated rows -> exact score ties across tile and segment boundaries
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((3, 64), dtype=np.float32)
+    D = np.repeat(base, 3000, axis=0)[rng.permutation(9000)]
+    q = rng.standard_normal((70, 64), dtype=np.float32)                        # 70 queries: the tiled MFMA kernel
+    d = DenseIndexHIP(64)
+    d.add_host_rows(D[:5000])
+    d.add_host_rows(D[5000:])
+    for Q in (q, q[:4]):                                                       # ... and the streaming kernel
+        s, i = d.search(torch.from_numpy(Q).cuda(), 3500)
+        es, ei = O.topk_rows(O.dense_scores_fma(Q, D, O.dense_korder(Q.shape[0], 64)), 3500)
+        assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+        row = i[0].cpu().numpy()
+        sc = s[0].cpu().numpy()
+        for g0 in np.flatnonzero(np.diff(sc, prepend=np.inf) != 0):            # inside every tie group: ascending ids
+            g1 = g0 + np.argmax(np.append(sc[g0:] != sc[g0], True))
+            assert np.all(np.diff(row[g0:g1]) > 0)

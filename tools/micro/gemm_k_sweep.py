@@ -1,5 +1,7 @@
 """Fixed (X) vs per-k-step (s) cost of the 256x256 GEMM tile: time at M = N = 8192 (1024 tiles = 4 full rounds) over K."""
-import os, sys, json
+import os, sys
+import json
+os.environ["SR_DEV_SWITCHES"] = "1"   # the library reads its development switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from scaling_retriever_amd import _lib as L

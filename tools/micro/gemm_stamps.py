@@ -1,5 +1,7 @@
 """Where a 256x256 GEMM tile's time goes: s_memrealtime stamps (100 MHz) from inside gemm_bf16_kernel (diagnostic path)."""
-import os, sys, json
+import os, sys
+import json
+os.environ["SR_DEV_SWITCHES"] = "1"   # the library reads its development switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SR_GEMM_STAMPS"] = "1"; os.environ["SR_GEMM_TILE"] = "256"
 import numpy as np, torch

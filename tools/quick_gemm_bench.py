@@ -1,5 +1,7 @@
 """Ad-hoc GEMM timing (development aid): the four 1B-layer GEMM shapes at a given token count, forced tilings vs the automatic tile plan."""
-import os, sys, json
+import os, sys
+import json
+os.environ["SR_DEV_SWITCHES"] = "1"   # the library reads its development switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from scaling_retriever_amd import _lib
