@@ -139,7 +139,7 @@ def synth_token_chunks(n, mu, sigma, lo, hi, vocab, seed, rows, chunk=8192):
     return chunks, lens[r0:r1]
 
 
-def encode_leg(args, cfg, model, device, rank, world, share_gpu):
+def encode_leg(args, cfg, model, device, rank, world, share_gpu, flop_per_token=FLOP_PER_TOKEN_1B, layers_ref=16):
     import shutil
     import tempfile
     from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
@@ -182,7 +182,7 @@ def encode_leg(args, cfg, model, device, rank, world, share_gpu):
     # whole-job figures: every rank encoded 1/W of the sample, times are the max over ranks
     all_lens = np.clip(np.round(np.random.default_rng(3).lognormal(4.25, 0.35, size=args.encode_passages)), 8, 192)
     tokens = float(all_lens.sum())
-    flop = tokens * FLOP_PER_TOKEN_1B * L / 16 + 4.0 * float((all_lens.astype(np.float64) ** 2).sum()) * H * L
+    flop = tokens * flop_per_token * L / layers_ref + 4.0 * float((all_lens.astype(np.float64) ** 2).sum()) * H * L
     ach, ach_gpu = flop / te / 1e12 / world, flop / gpu_s / 1e12 / world
     return {"value": round(args.encode_passages / te, 1), "unit": "passages/s (whole job, through store_embs: encode + D2H + .npy files)",
             "passages_per_s_per_gpu": round(args.encode_passages / te / world, 1), "sample_passages": int(args.encode_passages),
@@ -288,6 +288,61 @@ def sparse_leg(args, device):
     return out
 
 
+LION_8B = dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+               num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False)
+FLOP_PER_TOKEN_8B = 13.96e9  # 2 x linear params of the 8B body
+
+
+def config5_leg(args, device):
+    """BASELINE.json configs[4] on ONE of its 8 GPUs: Lion-DS-8B dims (llama-3-8b, train_configs/mntp/meta_llama3_8b_msmarco.json:2),
+    bf16-autocast corpus encode through store_embs and the score stage over this GPU's 1/8 doc shard at H = 4096."""
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    cfg = dict(LION_8B)
+    H, L = cfg["hidden_size"], cfg["num_hidden_layers"]
+    model = LlamaBiDense.from_weights(cfg, random_weights(cfg, device, seed=5), max_batch_tokens=32768, max_batch_seqs=2048,
+                                      fp32_planes=0).to(device).eval()          # documents only here: no fp32-regime planes
+    sub = argparse.Namespace(encode_passages=args.config5_passages, token_budget=args.token_budget)
+    enc = encode_leg(sub, cfg, model, device, 0, 1, False, flop_per_token=FLOP_PER_TOKEN_8B, layers_ref=32)
+    del model
+    torch.cuda.empty_cache()
+    n_shard = (args.n_docs + 7) // 8
+    D = torch.empty((n_shard, H), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device).manual_seed(7)
+    for r0 in range(0, n_shard, 1 << 19):
+        D[r0:r0 + (1 << 19)].normal_(0.0, 0.5 / H ** 0.5, generator=g)
+    Q = torch.empty((args.n_queries, H), dtype=torch.float32, device=device).normal_(0.0, 0.5 / H ** 0.5, generator=g)
+    index = DenseIndexHIP(H, device=device)
+    index.add_device_rows(D, id_base=0, id_stride=8)
+    index.search(Q, args.topk)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        index.search(Q, args.topk)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t) / 3
+    tf = 2.0 * args.n_queries * n_shard * H / t / 1e12
+    q1 = Q[:1].contiguous()
+    index.search(q1, args.topk)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        index.search(q1, args.topk)
+    torch.cuda.synchronize()
+    t1 = (time.perf_counter() - t1) / 5
+    gbps = n_shard * H * 4 / t1 / 1e9
+    index.close()
+    return {"workload": "Lion-DS-8B dims (H 4096, 32 layers, 32/8 heads of 128, MLP 14336), one GPU of the 8: bf16-autocast corpus encode + "
+                        f"exact fp32 score stage over its {n_shard} x {H} doc shard",
+            "encode": enc,
+            "score_shard": {"queries_per_s": round(args.n_queries / t, 1), "ms": round(t * 1e3, 1),
+                            "roofline": {"kernel": "dense_score_pipe_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F32_MFMA_TF,
+                                         "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4)}},
+            "score_shard_one_query": {"ms": round(t1 * 1e3, 2),
+                                      "roofline": {"kernel": "dense_stream_kernel", "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+                                                   "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,6 +356,8 @@ def main():
     ap.add_argument("--token-budget", type=int, default=16384, help="real tokens per doc_encode batch of the encode leg")
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-sparse", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the Lion-DS-8B leg (BASELINE.json configs[4], one GPU's share)")
+    ap.add_argument("--config5-passages", type=int, default=8192)
     ap.add_argument("--sparse-cpu-queries", type=int, default=768, help="bounded CPU sample of the sparse baseline (~10 s per threading shape)")
     ap.add_argument("--layers", type=int, default=None, help="override num layers (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -530,6 +587,10 @@ def main():
         del model
         torch.cuda.empty_cache()
         sparse = sparse_leg(args, device)
+    config5 = None
+    if rank == 0 and world == 1 and not args.no_config5 and not args.layers:
+        torch.cuda.empty_cache()
+        config5 = config5_leg(args, device)
 
     if rank == 0:
         res = {
@@ -548,7 +609,7 @@ def main():
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,
-            "encode": encode, "sparse": sparse,
+            "encode": encode, "sparse": sparse, "config5_8b": config5,
         }
         print(json.dumps(res), flush=True)
     if world > 1:
