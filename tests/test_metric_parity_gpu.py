@@ -58,12 +58,16 @@ def _oracle_encode(fn, w, cfg, seqs, side, hooks=None, batch=250):
     return np.concatenate(out)
 
 
-def _hip_encode(model, seqs, side, query, batch=128):
+def _hip_encode(model, seqs, side, query, batch=128, autocast=True):
+    """autocast=True: the reference's document / sparse-query regime (indexer.py:46-52, :255-256, :390-391); False: its
+    dense-query regime (eval_dense.py:94-106)."""
+    import contextlib
     out = []
     for b in range(0, len(seqs), batch):
         ids, mask = _pad(seqs[b:b + batch], side)
         f = model.query_encode if query else model.doc_encode
-        out.append(f(input_ids=torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda()))
+        with (torch.autocast("cuda", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()):
+            out.append(f(input_ids=torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda()))
     return torch.cat(out)
 
 
@@ -92,10 +96,11 @@ def test_dense_pipeline_reproduces_mrr_and_ndcg(setup):
         q = _oracle_encode(LB.dense_encode, w, cfg, queries, "left", hooks)
         s, i = SC.flat_ip_search(q, d, K)
         ref[name] = _metrics(i, s, src)
-    model = LlamaBiDense.from_weights(cfg, w, precision="bf16").to("cuda").eval()
+    # the reference's precision map: documents under bf16 autocast, queries in fp32 (the model follows the autocast context)
+    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
     index = DenseIndexHIP(cfg["hidden_size"])
-    index.add_device_rows(_hip_encode(model, docs, "left", False))
-    s, i = index.search(_hip_encode(model, queries, "left", True), K)
+    index.add_device_rows(_hip_encode(model, docs, "left", False, autocast=True))
+    s, i = index.search(_hip_encode(model, queries, "left", True, autocast=False), K)
     got = _metrics(i.cpu().numpy(), s.cpu().numpy(), src)
     print("dense MRR@10/nDCG@10: hip", got, "oracle fp32", ref["fp32"], "oracle bf16-autocast", ref["bf16"])
     assert 0.2 < ref["fp32"][0] < 0.999                      # the task is neither trivial nor hopeless
@@ -119,7 +124,7 @@ def test_sparse_pipeline_reproduces_mrr_and_ndcg(setup):
         sc = q @ d.T
         i = np.argsort(-sc, axis=1, kind="stable")[:, :K]
         ref[name] = _metrics(i, np.take_along_axis(sc, i, 1), src)
-    model = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
+    model = LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()          # both sides under autocast, as eval_sparse.py does
     d_reps = _hip_encode(model, docs, "right", False)
     q_reps = _hip_encode(model, queries, "right", True)
     from scaling_retriever_amd.scoring import SparseIndexHIP
