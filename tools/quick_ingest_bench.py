@@ -35,6 +35,16 @@ try:
         idx.close()
         del idx
         torch.cuda.empty_cache()
+    pinned = torch.empty((1 << 28,), dtype=torch.float32, pin_memory=True)      # 1 GiB
+    devb = torch.empty_like(pinned, device="cuda")
+    devb.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(4):
+        devb.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    print(f"raw pinned H2D copy (the link's rate): {4 * pinned.numel() * 4 / (time.perf_counter() - t) / 1e9:.1f} GB/s", flush=True)
+    del pinned, devb
     t = time.perf_counter()
     host = np.load(path)                                    # the reference: whole file into host memory ...
     dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()       # ... then one pageable H2D copy
