@@ -35,6 +35,18 @@ try:
         idx.close()
         del idx
         torch.cuda.empty_cache()
+    for threads, bufs in ((4, 4), (8, 8), (16, 16), (32, 32)):
+        idx = DenseIndexHIP(H)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        idx.add_npy_file(path, n_buffers=bufs, n_threads=threads)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t
+        print(f"preadv -> pinned ring ({threads} threads, {bufs} x 64 MB buffers) -> HBM: {n * H * 4 / t / 1e9:.1f} GB/s ({gib:.0f} GiB in {t:.2f}s)", flush=True)
+        assert float(idx._segments[0][-1, -1]) == 1.0
+        idx.close()
+        del idx
+        torch.cuda.empty_cache()
     pinned = torch.empty((1 << 28,), dtype=torch.float32, pin_memory=True)      # 1 GiB
     devb = torch.empty_like(pinned, device="cuda")
     devb.copy_(pinned, non_blocking=True)
