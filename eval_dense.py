@@ -195,6 +195,8 @@ def retrieval(args):
     sizes = [int(np.load(f, mmap_mode="r").shape[0]) for f in id_files]
     offsets = np.concatenate([[0], np.cumsum(sizes)])
     index = DenseIndexHIP(model.hidden_size, device=device)
+    if model.hidden_size % 64 == 0:
+        index.set_precision("fp32_filtered")          # exact results, ~3x faster for the whole query set (csrc/dense_filter.hip)
     for fi in range(rank, len(vec_files), world):
         index.add_npy_file(vec_files[fi], id_base=int(offsets[fi]))        # mmap -> pinned ring -> async H2D
     q_reps, qids = generate_query_vecs(model, q_loader, device)

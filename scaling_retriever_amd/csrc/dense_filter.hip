@@ -1,0 +1,169 @@
+// Exact dense top-k at split-bf16 speed: a certified filter in front of an exact re-score (gfx950).
+//
+// sr_dense_search must return what faiss.IndexFlatIP.search returns (scaling_retriever/indexer.py:210-214): the k largest
+// fp32 inner products.  dense_score_pipe_kernel computes every one of the nq x N products on the fp32 MFMA pipe (157 TF
+// peak).  The bf16 MFMA pipe is 16x faster, and the two-plane split score S_a = q0.d0 + q0.d1 + q1.d0 (dense_split.hip)
+// differs from the fp32 chain S_x by a PROVABLY small amount, so it can decide which few documents need the exact
+// arithmetic at all:
+//
+//   1. approximate pass: the kp = ~2k best documents by S_a per query (dense_split_kernel + the fused top-k, unchanged);
+//   2. certificate: with E = c |q| max|d| >= |S_a - S_x| for every document, a document whose S_a is below a_k - 2E
+//      (a_k = k-th best S_a) has k documents strictly above it in S_x, so it is not in the exact top-k; if the kp-th best
+//      S_a is itself below a_k - 2E, the kp candidates CONTAIN the exact top-k;
+//   3. exact pass: S_x for the kp candidates only - the same fp32 fmaf chain, in the same k order, as
+//      dense_score_pipe_kernel (oracle: scoring.mfma_korder) - then the top-k by (S_x desc, doc index asc).
+// The result is bit-identical to the exact kernel's (tests/test_dense_filtered_gpu.py).  A query whose certificate fails
+// (more than kp - k approximate scores inside the margin: near-duplicate documents, a zero query) or for which any
+// candidate's |S_a - S_x| exceeds E (the bound is checked on every pair that is re-scored) makes sr_dense_search redo the
+// batch with the exact kernel - correctness never rests on the filter.
+//
+// The bound.  B = sum |q_i||d_i| <= |q||d|.
+//   fp32 chain of H fmaf:                |S_x - q.d| <= gamma_H B,    gamma_n = n u / (1 - n u), u = 2^-24
+//   planes: x0 = bf16(x), x1 = bf16(x - x0): |x - x0 - x1| <= 2^-18 |x|, |x1| <= 2^-9 |x| (1 + 2^-9)
+//     dropped q1.d1 + (q - q0 - q1).d + (q0 + q1).(d - d0 - d1):       <= 3.02 * 2^-18 B
+//   3H bf16 products (exact in fp32) summed in fp32 by the MFMA, 32 per instruction, modelled as no better than a plain
+//     fp32 summation of 3H terms:                                      <= gamma_3H * 1.008 B
+//   c(H) = 1.25 * (4 H 2^-24) + 1.5e-5   (6.3e-4 at H = 2048, 1.24e-3 at 4096) covers the sum with 25 % to spare;
+//   measured max |S_a - S_x| / (|q||d|) is 1e-6.
+#include "dense_filter.h"
+#include <math.h>
+
+double sr_filter_c(int H) { return 1.25 * (4.0 * (double)H * ldexp(1.0, -24)) + 1.5e-5; }
+
+__global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ rows, int64_t n, int H, float* __restrict__ d_max2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float ss = 0.f;
+    if (r < n) {
+        const float* p = rows + r * H;
+        for (int i = lane * 4; i < H; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    // NaN / inf rows make every bound meaningless: record +inf so that nothing is ever certified
+    if (!(ss < INFINITY)) ss = INFINITY;
+    if (lane == 0 && r < n) atomicMax(reinterpret_cast<unsigned int*>(d_max2), __float_as_uint(ss * 1.0001f));   // summation slack
+}
+
+int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s) {
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(row_norm2_max_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, s, rows, n, H, d_max2);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+__global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict__ Q, int64_t nq, int H, float* __restrict__ qnorm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float ss = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Q + q * H + i);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) qnorm[q] = (ss < INFINITY) ? sqrtf(ss * 1.0001f) : INFINITY;
+}
+
+int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStream_t s) {
+    hipLaunchKernelGGL(query_norm_kernel, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, s, Q, nq, H, qnorm);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+__global__ void filter_certify_kernel(const float* __restrict__ a_scores, const float* __restrict__ qnorm,
+                                      const float* __restrict__ d_max2, int64_t nq, int k, int kp, double c, int* __restrict__ flags) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
+    const double ak = (double)a_scores[q * kp + (k - 1)];      // -FLT_MAX pads when fewer than k documents exist
+    const double akp = (double)a_scores[q * kp + (kp - 1)];
+    // fewer than kp documents: every document is a candidate.  Otherwise the kp-th approximate score must be clear of
+    // the margin.  NaN / inf anywhere -> not certified.
+    const bool all_docs = akp <= -3.0e38;
+    const bool ok = all_docs || (E < INFINITY && ak > -3.0e38 && akp < ak - 2.0 * E);
+    flags[q] = ok ? 0 : 1;
+}
+
+int launch_filter_certify(const float* a_scores, const float* qnorm, const float* d_max2, int64_t nq, int k, int kp, double c,
+                          int* flags, hipStream_t s) {
+    hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, a_scores, qnorm, d_max2, nq, k,
+                       kp, c, flags);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+// One wave per (query, 64 candidates).  The candidates' rows are gathered 64 columns at a time through LDS (coalesced
+// 256-byte pieces of each row; lane = candidate reads its row conflict-free from the padded tile), the query chunk is a
+// broadcast read, and every lane runs the fp32 fmaf chain of ITS candidate in dense_score_pipe_kernel's k order: per
+// group of 8 columns, k = 8s + j then 8s + 4 + j for j = 0..3.
+#define RS_KC 64
+__global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, const float* __restrict__ Q, const float* __restrict__ a_scores,
+                                                            const int64_t* __restrict__ a_ids, const float* __restrict__ qnorm,
+                                                            const float* __restrict__ d_max2, int kp, int H, double c,
+                                                            uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
+                                                            int64_t cand_cap, int* __restrict__ flags) {
+#pragma clang fp contract(off)
+    __shared__ float tile[64][RS_KC + 1];
+    __shared__ float qs[RS_KC];
+    __shared__ const float* rowp[64];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int j0 = blockIdx.y * 64;
+    const int j = j0 + lane;
+    const int64_t gid = j < kp ? a_ids[q * kp + j] : -1;
+    const float* row = nullptr;
+    if (gid >= 0) {
+        for (int sgi = 0; sgi < segs.count; ++sgi) {
+            const int64_t off = gid - (int64_t)segs.id_base[sgi];
+            if (off >= 0 && off % segs.id_stride[sgi] == 0 && off / segs.id_stride[sgi] < segs.n[sgi]) {
+                row = segs.rows[sgi] + (off / segs.id_stride[sgi]) * (int64_t)H;
+                break;
+            }
+        }
+    }
+    rowp[lane] = row;
+    __syncthreads();
+    float acc = 0.f;
+    for (int k0 = 0; k0 < H; k0 += RS_KC) {
+        __syncthreads();
+        // 64 rows x 256 B: 16 lanes per row, 4 rows per instruction
+        for (int r0 = 0; r0 < 64; r0 += 4) {
+            const int r = r0 + (lane >> 4);
+            const float* p = rowp[r];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p) v = *reinterpret_cast<const f32x4*>(p + k0 + (lane & 15) * 4);
+            float* t = &tile[r][(lane & 15) * 4];
+            t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        }
+        qs[lane] = Q[q * H + k0 + lane];
+        __syncthreads();
+#pragma unroll
+        for (int s8 = 0; s8 < RS_KC; s8 += 8)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc = __builtin_fmaf(qs[s8 + jj], tile[lane][s8 + jj], acc);
+                acc = __builtin_fmaf(qs[s8 + 4 + jj], tile[lane][s8 + 4 + jj], acc);
+            }
+    }
+    if (row) {
+        // the bound, checked on every pair that is re-scored
+        const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
+        if (!(fabs((double)acc - (double)a_scores[q * kp + j]) <= E)) atomicOr(&flags[q], 2);
+        const int pos = atomicAdd(&cand_count[q], 1);
+        if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
+    }
+}
+
+int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
+                          const float* d_max2, int64_t nq, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
+                          int64_t cand_cap, int* flags, hipStream_t s) {
+    SR_REQUIRE(H % RS_KC == 0, "filter(rescore): dim %d must be a multiple of %d", H, RS_KC);
+    SR_REQUIRE(nq <= 0x7fffffff && ceil_div64(kp, 64) <= 65535, "filter(rescore): grid too large");
+    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp, 64)), dim3(64), 0, s, segs, Q, a_scores, a_ids,
+                       qnorm, d_max2, kp, H, c, cand_keys, cand_count, cand_cap, flags);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "dense_stream.h"
 #include "dense_split.h"
+#include "dense_filter.h"
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
@@ -376,6 +377,7 @@ struct DenseSegment {
     int64_t id_base, id_stride;
     unsigned short* pl[3] = {nullptr, nullptr, nullptr};   // library-owned bf16 planes (split precisions only)
     int n_planes = 0;
+    bool in_dmax = false;      // its rows are folded into sr_dense_index::d_max2 (filtered mode)
 };
 
 struct sr_dense_index {
@@ -390,16 +392,30 @@ struct sr_dense_index {
     StreamOrder order;
     LaunchProfile prof;
     std::mutex mu;
+    // SR_PRECISION_FP32_FILTERED (dense_filter.hip)
+    TopkWS ws2;                       // exact top-k over the re-scored candidates
+    float* d_max2 = nullptr;          // max |row|^2 over all segments
+    float* qnorm = nullptr;           // [fq_cap]
+    float* a_scores = nullptr;        // [fq_cap, fkp] approximate top-kp, sorted
+    int64_t* a_ids = nullptr;
+    int* flags = nullptr;             // [fq_cap + 1]: per query, + the OR of all of them
+    int64_t fq_cap = 0;
+    int fkp = 0;
+    int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter / redone by the exact kernel
 };
 
-static int planes_of(int precision) { return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : 0); }
+static int planes_of(int precision) {
+    return precision == SR_PRECISION_BF16X6 ? 3 : ((precision == SR_PRECISION_BF16X3 || precision == SR_PRECISION_FP32_FILTERED) ? 2 : 0);
+}
 
 static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
     if (seg.n_planes >= want) return SR_OK;
     const size_t bytes = (size_t)seg.n * (size_t)idx->dim * 2;
     for (int p = seg.n_planes; p < want; ++p) {
         if (hipMalloc((void**)&seg.pl[p], bytes) != hipSuccess) {
+            (void)hipGetLastError();
             seg.pl[p] = nullptr;
+            for (int r = seg.n_planes; r < p; ++r) { (void)hipFree(seg.pl[r]); seg.pl[r] = nullptr; }
             sr_set_error("split precision needs %zu more bytes of device memory per plane of this segment", bytes);
             return SR_ERR_NOMEM;
         }
@@ -447,7 +463,11 @@ extern "C" int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int6
     std::lock_guard<std::mutex> lock(idx->mu);
     DenseSegment seg;
     seg.rows = d_rows; seg.n = n_rows; seg.id_base = id_base; seg.id_stride = id_stride;
-    if (planes_of(idx->precision)) SR_TRY(split_segment(idx, seg, planes_of(idx->precision)));
+    if (planes_of(idx->precision)) {
+        const int rc = split_segment(idx, seg, planes_of(idx->precision));
+        // the filtered mode is an accelerator of the exact search: without room for the planes it simply is not used
+        if (rc != SR_OK && !(rc == SR_ERR_NOMEM && idx->precision == SR_PRECISION_FP32_FILTERED)) return rc;
+    }
     idx->segs.push_back(seg);
     idx->ntotal += n_rows;
     return SR_OK;
@@ -470,34 +490,36 @@ extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
             if (seg.pl[p]) (void)hipFree(seg.pl[p]);
     for (int p = 0; p < 3; ++p)
         if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
+    idx->ws2.release();
+    if (idx->d_max2) (void)hipFree(idx->d_max2);
+    if (idx->qnorm) (void)hipFree(idx->qnorm);
+    if (idx->a_scores) (void)hipFree(idx->a_scores);
+    if (idx->a_ids) (void)hipFree(idx->a_ids);
+    if (idx->flags) (void)hipFree(idx->flags);
     delete idx;
     return SR_OK;
 }
 
 extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
     SR_REQUIRE(idx, "sr_dense_index_set_precision: null index");
-    SR_REQUIRE(mode == SR_PRECISION_FP32 || mode == SR_PRECISION_BF16X3 || mode == SR_PRECISION_BF16X6,
+    SR_REQUIRE(mode == SR_PRECISION_FP32 || mode == SR_PRECISION_BF16X3 || mode == SR_PRECISION_BF16X6 ||
+                   mode == SR_PRECISION_FP32_FILTERED,
                "sr_dense_index_set_precision: unknown mode %d", mode);
     std::lock_guard<std::mutex> lock(idx->mu);
     if (planes_of(mode)) {
         SR_REQUIRE(idx->dim % 64 == 0, "split precisions need dim %% 64 == 0 (dim = %d)", idx->dim);
-        for (DenseSegment& seg : idx->segs) SR_TRY(split_segment(idx, seg, planes_of(mode)));
+        for (DenseSegment& seg : idx->segs) {
+            const int rc = split_segment(idx, seg, planes_of(mode));
+            if (rc != SR_OK && !(rc == SR_ERR_NOMEM && mode == SR_PRECISION_FP32_FILTERED)) return rc;
+        }
     }
     idx->precision = mode;
     return SR_OK;
 }
 
-extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
-                               int64_t* d_out_ids, sr_stream stream) {
-    SR_REQUIRE(idx, "sr_dense_search: null index");
-    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_dense_search: bad nq=%lld", (long long)nq);
-    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_dense_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
-    if (nq == 0) return SR_OK;
-    SR_REQUIRE(d_queries && d_out_scores && d_out_ids, "sr_dense_search: null pointer");
-    SR_REQUIRE(((uintptr_t)d_queries & 15) == 0, "sr_dense_search: queries must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(idx->mu);
-    StreamOrder::Scope in_order(idx->order, s);
+// one pass in the given arithmetic (SR_PRECISION_FP32 | _BF16X3 | _BF16X6); caller holds idx->mu
+static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
+                             int64_t* d_out_ids, int precision, hipStream_t s) {
 
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
@@ -520,9 +542,9 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if (planes_of(idx->precision) && nq > 64) {
+    if (planes_of(precision) && nq > 64) {
         // fp32-class scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
-        const int np = planes_of(idx->precision);
+        const int np = planes_of(precision);
         if (idx->q_cap < nq) {
             for (int p = 0; p < 3; ++p) {
                 if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
@@ -646,6 +668,95 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
         }
     }
     SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    return SR_OK;
+}
+
+// SR_PRECISION_FP32_FILTERED: exact results at split-bf16 speed (dense_filter.hip).  Returns SR_OK with *done = false when the
+// batch has to go through the exact kernel instead (not applicable, or not certified).
+static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
+                                 int64_t* d_out_ids, hipStream_t s, bool* done) {
+    *done = false;
+    int kp = 2 * k > k + 1048 ? 2 * k : k + 1048;            // candidates per query: k = 1000 -> 2048
+    if (kp > SR_MAX_TOPK) kp = SR_MAX_TOPK;
+    if (nq <= 64 || kp < k + 64 || idx->dim % 64 != 0 || (int)idx->segs.size() > SR_FILTER_MAX_SEGS) return SR_OK;
+    for (const DenseSegment& seg : idx->segs)
+        if (seg.n_planes < 2) return SR_OK;                   // planes could not be allocated: exact kernel
+    if (!idx->d_max2) {
+        SR_CHECK_HIP(hipMalloc((void**)&idx->d_max2, 4));
+        SR_CHECK_HIP(hipMemsetAsync(idx->d_max2, 0, 4, s));
+    }
+    for (DenseSegment& seg : idx->segs)
+        if (!seg.in_dmax) {
+            SR_TRY(launch_row_norm2_max(seg.rows, seg.n, idx->dim, idx->d_max2, s));
+            seg.in_dmax = true;
+        }
+    if (idx->fq_cap < nq || idx->fkp != kp) {
+        auto F = [](void* p) { if (p) (void)hipFree(p); };
+        F(idx->qnorm); F(idx->a_scores); F(idx->a_ids); F(idx->flags);
+        idx->qnorm = nullptr; idx->a_scores = nullptr; idx->a_ids = nullptr; idx->flags = nullptr;
+        idx->fq_cap = 0;
+        if (hipMalloc((void**)&idx->qnorm, (size_t)nq * 4) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
+            hipMalloc((void**)&idx->a_ids, (size_t)nq * kp * 8) != hipSuccess || hipMalloc((void**)&idx->flags, (size_t)(nq + 1) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return SR_OK;                                     // no room for the candidate lists: exact kernel
+        }
+        idx->fq_cap = nq;
+        idx->fkp = kp;
+    }
+    const double c = sr_filter_c(idx->dim);
+    SR_TRY(launch_query_norms(d_queries, nq, idx->dim, idx->qnorm, s));
+    // 1. the kp best documents by the two-plane score
+    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PRECISION_BF16X3, s));
+    // 2. certificate, 3. exact scores of the candidates -> exact top-k
+    SR_TRY(launch_filter_certify(idx->a_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
+    SR_TRY(idx->ws2.ensure(nq, k, kp));
+    SR_TRY(topk_reset(idx->ws2, nq, s));
+    FilterSegs fs;
+    fs.count = (int)idx->segs.size();
+    for (int i = 0; i < fs.count; ++i) {
+        fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
+        fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
+    }
+    SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, kp, idx->dim, c,
+                                 idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
+    SR_TRY(topk_compact(idx->ws2, nq, k, s));
+    SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    // any query not certified -> the whole batch goes through the exact kernel (one small D2H per search)
+    std::vector<int> h((size_t)nq);
+    SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    for (int64_t q = 0; q < nq; ++q)
+        if (h[(size_t)q]) return SR_OK;
+    *done = true;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
+                               int64_t* d_out_ids, sr_stream stream) {
+    SR_REQUIRE(idx, "sr_dense_search: null index");
+    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_dense_search: bad nq=%lld", (long long)nq);
+    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_dense_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_queries && d_out_scores && d_out_ids, "sr_dense_search: null pointer");
+    SR_REQUIRE(((uintptr_t)d_queries & 15) == 0, "sr_dense_search: queries must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    StreamOrder::Scope in_order(idx->order, s);
+    if (idx->precision == SR_PRECISION_FP32_FILTERED) {
+        bool done = false;
+        SR_TRY(dense_search_filtered(idx, d_queries, nq, k, d_out_scores, d_out_ids, s, &done));
+        if (done) { ++idx->n_filtered; return SR_OK; }
+        if (nq > 64) ++idx->n_fallback;
+        return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, SR_PRECISION_FP32, s);
+    }
+    return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, idx->precision, s);
+}
+
+extern "C" int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback) {
+    SR_REQUIRE(idx && n_filtered && n_fallback, "sr_dense_index_filter_stats: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *n_filtered = idx->n_filtered;
+    *n_fallback = idx->n_fallback;
     return SR_OK;
 }
 

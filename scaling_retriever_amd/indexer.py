@@ -138,6 +138,10 @@ class DenseFlatIndexer(DenseIndexer):
     def init_index(self, hidden_dim):
         self.hidden_dim = int(hidden_dim)
         self.index = DenseIndexHIP(self.hidden_dim)
+        # IndexFlatIP's exact results (bit-identical to the exact fp32 kernel) through the certified bf16 filter + exact
+        # re-score; the library uses the exact kernel by itself when HBM has no room for the filter's bf16 planes
+        if self.hidden_dim % 64 == 0:
+            self.index.set_precision("fp32_filtered")
 
     def index_data(self, doc_reps, doc_ids):
         assert len(doc_reps) == len(doc_ids)

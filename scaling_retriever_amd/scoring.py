@@ -146,9 +146,18 @@ class DenseIndexHIP:
         _lib.check(self.lib.sr_dense_index_set_workspace_limit(self._h, int(nbytes)))
 
     def set_precision(self, mode):
-        """"fp32" (default, exact) or "bf16x3" (fp32-equivalent on the bf16 MFMA pipe, query batches > 64)."""
-        code = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}[mode]   # bf16x6: 3 planes, 6 products, fp32-class error
-        _lib.check(self.lib.sr_dense_index_set_precision(self._h, code), "sr_dense_index_set_precision")
+        """"fp32" (default: the exact kernel), "fp32_filtered" (the same results bit for bit through a certified bf16 filter +
+        exact re-score, ~3x faster for batches > 64 queries, two bf16 planes of the corpus in HBM), "bf16x3" / "bf16x6"
+        (split-bf16 scores, not bit-identical)."""
+        code = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp32_filtered": 3}[mode]
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_dense_index_set_precision(self._h, code), "sr_dense_index_set_precision")
+
+    def filter_stats(self):
+        """(searches answered through the certified filter, searches redone by the exact kernel)."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.sr_dense_index_filter_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def search(self, queries, k):
         """queries: fp32 cuda tensor [nq, dim] -> (scores fp32 [nq,k], ids int64 [nq,k]) cuda tensors."""

@@ -1,0 +1,126 @@
+"""SR_PRECISION_FP32_FILTERED: sr_dense_search through the certified bf16 filter + exact re-score must return EXACTLY what
+the exact fp32 kernel returns - ids and fp32 scores, bit for bit (= the oracle's k-ordered fmaf chain, i.e. what
+faiss.IndexFlatIP.search is restated as, /root/reference/scaling_retriever/indexer.py:210-214) - on benign and on
+adversarial data, and must fall back to the exact kernel when the certificate cannot be given.  Also pins the error bound
+the certificate rests on."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(D_parts, Q, k, bases=None):
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    H = Q.shape[1]
+    exact, filt = DenseIndexHIP(H), DenseIndexHIP(H)
+    filt.set_precision("fp32_filtered")
+    for i, part in enumerate(D_parts):
+        kw = {} if bases is None else {"id_base": bases[i][0], "id_stride": bases[i][1]}
+        exact.add_host_rows(part, **kw)
+        filt.add_host_rows(part, **kw)
+    q = torch.from_numpy(Q).cuda()
+    es, ei = exact.search(q, k)
+    fs, fi = filt.search(q, k)
+    return (es, ei), (fs, fi), filt
+
+
+@pytest.mark.parametrize("H,N,nq,k", [(128, 30000, 200, 100), (256, 12000, 70, 1000), (2048, 40000, 300, 1000), (4096, 9000, 130, 50)])
+def test_filtered_equals_exact_and_oracle(H, N, nq, k):
+    rng = np.random.default_rng(H + N)
+    D = (rng.standard_normal((N, H), dtype=np.float32) * (0.5 / np.sqrt(H))).astype(np.float32)
+    Q = (rng.standard_normal((nq, H), dtype=np.float32) * (0.5 / np.sqrt(H))).astype(np.float32)
+    (es, ei), (fs, fi), filt = _both([D[:N // 3], D[N // 3:]], Q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_stats() == (1, 0)                                  # answered by the filter, not by the fallback
+    n_or = min(nq, 40)
+    os_, oi = O.topk_rows(O.dense_scores_fma(Q[:n_or], D, O.mfma_korder(H)), k)
+    assert np.array_equal(fi[:n_or].cpu().numpy(), oi) and np.array_equal(fs[:n_or].cpu().numpy(), os_)
+
+
+def test_filtered_adversarial_data_still_exact():
+    """Same-sign vectors (no cancellation: the largest |S_a - S_x| per unit of |q||d|), a 1e6 dynamic range inside the rows,
+    documents of very different norms, near-duplicate documents around the cut, strided global ids."""
+    rng = np.random.default_rng(7)
+    H, N, nq, k = 512, 20000, 96, 200
+    D = np.abs(rng.standard_normal((N, H), dtype=np.float32))
+    D *= np.exp(rng.uniform(-7, 7, size=(1, H))).astype(np.float32)               # per-column scales over 1e6
+    D *= np.exp(rng.uniform(-2, 2, size=(N, 1))).astype(np.float32)               # norms spread over e^4
+    base = D[100].copy()
+    for j in range(150):                                                           # 150 near-duplicates of one document
+        D[200 + j] = base * np.float32(1.0 + 1e-7 * j)
+    Q = np.abs(rng.standard_normal((nq, H), dtype=np.float32))
+    Q[0] = base                                                                    # ... which the first query hits head on
+    (es, ei), (fs, fi), filt = _both([D[0::2], D[1::2]], Q, k, bases=[(0, 2), (1, 2)])
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    os_, oi = O.topk_rows(O.dense_scores_fma(Q[:16], D, O.mfma_korder(H)), k)
+    assert np.array_equal(fi[:16].cpu().numpy(), oi) and np.array_equal(fs[:16].cpu().numpy(), os_)
+
+
+def test_filtered_falls_back_when_it_cannot_certify():
+    """More than kp - k documents tie with the k-th one (exact duplicates): no certificate -> the exact kernel answers, the
+    result is still the exact kernel's (ties by ascending doc index)."""
+    rng = np.random.default_rng(3)
+    H, k = 128, 50
+    base = rng.standard_normal((8, H), dtype=np.float32)
+    D = np.repeat(base, 1500, axis=0)[rng.permutation(12000)]                      # 1 499 exact twins each: more than kp - k
+    Q = rng.standard_normal((100, H), dtype=np.float32)
+    (es, ei), (fs, fi), filt = _both([D], Q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_stats() == (0, 1)
+    # a zero query: every score is 0, nothing can be separated
+    Q[5] = 0
+    (es, ei), (fs, fi), filt = _both([rng.standard_normal((5000, H), dtype=np.float32)], Q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es) and filt.filter_stats() == (0, 1)
+    # non-finite data: never certified
+    Dn = rng.standard_normal((5000, H), dtype=np.float32)
+    Dn[17, 3] = np.inf
+    _, (fs, fi), filt = _both([Dn], rng.standard_normal((100, H), dtype=np.float32), k)
+    assert filt.filter_stats() == (0, 1)
+
+
+def test_filtered_small_index_and_small_batches():
+    """Fewer documents than candidates (every document is re-scored), fewer than k documents (padding), and batches of <= 64
+    queries, which the streaming kernel answers in its own k order whatever the mode."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(5)
+    H = 256
+    for N, k in ((1500, 1000), (700, 1000)):
+        D = rng.standard_normal((N, H), dtype=np.float32)
+        Q = rng.standard_normal((80, H), dtype=np.float32)
+        (es, ei), (fs, fi), filt = _both([D], Q, k)
+        assert torch.equal(fi, ei) and torch.equal(fs, es) and filt.filter_stats() == (1, 0)
+        assert int((fi[0] >= 0).sum()) == min(N, k)
+    D = rng.standard_normal((20000, H), dtype=np.float32)
+    Q = rng.standard_normal((16, H), dtype=np.float32)
+    (es, ei), (fs, fi), filt = _both([D], Q, 100)
+    assert torch.equal(fi, ei) and torch.equal(fs, es) and filt.filter_stats() == (0, 0)
+
+
+def test_two_plane_error_bound_holds_with_a_wide_margin():
+    """The certificate's E = c(H) |q| |d| must dominate |S_a - S_x|.  S_a is read back through the bf16x3 mode's scores, S_x
+    from the exact kernel, on Gaussian and on same-sign data; the observed maximum stays far below the bound."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(11)
+    for H in (256, 2048):
+        c = 1.25 * (4.0 * H * 2.0 ** -24) + 1.5e-5
+        for same_sign in (False, True):
+            D = rng.standard_normal((3000, H), dtype=np.float32)
+            Q = rng.standard_normal((128, H), dtype=np.float32)
+            if same_sign:
+                D, Q = np.abs(D), np.abs(Q)
+            a, b = DenseIndexHIP(H), DenseIndexHIP(H)
+            a.add_host_rows(D)
+            b.add_host_rows(D)
+            b.set_precision("bf16x3")
+            q = torch.from_numpy(Q).cuda()
+            es, ei = a.search(q, 3000)
+            as_, ai = b.search(q, 3000)
+            ex = torch.zeros((128, 3000), device="cuda").scatter_(1, ei, es)
+            ap = torch.zeros((128, 3000), device="cuda").scatter_(1, ai, as_)
+            bound = torch.from_numpy(np.linalg.norm(Q, axis=1)[:, None] * np.linalg.norm(D, axis=1)[None, :]).cuda()
+            worst = float(((ex - ap).abs() / bound).max())
+            print(f"H {H} same_sign {same_sign}: max |S_a - S_x| / (|q||d|) = {worst:.2e}, bound c = {c:.2e}")
+            assert worst < c / 20

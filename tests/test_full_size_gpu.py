@@ -63,6 +63,24 @@ def test_full_corpus_search_properties(corpus, nq):
         assert set(above.tolist()) <= set(i[q].tolist())
 
 
+def test_full_corpus_filtered_search_equals_exact_kernel(corpus):
+    """SR_PRECISION_FP32_FILTERED at BASELINE.json's full size (8 841 823 x 2048; + 72 GB of bf16 planes): ids and fp32
+    scores bit-identical to the exact fp32 MFMA kernel for 512 queries, answered by the filter (no fallback)."""
+    D, idx, g = corpus
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        pytest.skip("needs 75 GB more HBM for the bf16 planes")
+    Q = torch.empty((512, H), dtype=torch.float32, device="cuda").normal_(0.0, 0.5 / H ** 0.5, generator=g)
+    es, ei = idx.search(Q, K)
+    idx.set_precision("fp32_filtered")
+    try:
+        fs, fi = idx.search(Q, K)
+        assert idx.filter_stats() == (1, 0)
+    finally:
+        idx.set_precision("fp32")
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+
+
 def test_full_msmarco_shape_sparse_search_bit_exact():
     """BASELINE.json configs[2] at FULL size (V = 128 256, N = 8 841 823, 1.12 G postings, Zipf(1.0) lists up to N long,
     tools/synth.py): a handful of queries through sr_sparse_search vs the oracle's C port of numba_score_float +
