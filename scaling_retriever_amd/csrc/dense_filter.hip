@@ -32,24 +32,27 @@ double sr_filter_c(int H) { return 1.25 * (4.0 * (double)H * ldexp(1.0, -24)) + 
 
 __global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ rows, int64_t n, int H, float* __restrict__ d_max2) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    float ss = 0.f;
-    if (r < n) {
+    float mx = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {   // grid-stride (< 2^32 threads)
         const float* p = rows + r * H;
+        float ss = 0.f;
         for (int i = lane * 4; i < H; i += 256) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        // NaN / inf rows make every bound meaningless: record +inf so that nothing is ever certified
+        if (!(ss < INFINITY)) ss = INFINITY;
+        mx = fmaxf(mx, ss);
     }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    // NaN / inf rows make every bound meaningless: record +inf so that nothing is ever certified
-    if (!(ss < INFINITY)) ss = INFINITY;
-    if (lane == 0 && r < n) atomicMax(reinterpret_cast<unsigned int*>(d_max2), __float_as_uint(ss * 1.0001f));   // summation slack
+    if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(d_max2), __float_as_uint(mx * 1.0001f));   // summation slack
 }
 
 int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s) {
     if (n == 0) return SR_OK;
-    hipLaunchKernelGGL(row_norm2_max_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, s, rows, n, H, d_max2);
+    int64_t blocks = ceil_div64(n, 4);
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(row_norm2_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows, n, H, d_max2);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

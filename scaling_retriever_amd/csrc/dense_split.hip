@@ -22,29 +22,32 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 // ---- fp32 -> bf16 planes ---------------------------------------------------------------------------
 __global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ p0, unsigned short* __restrict__ p1,
                                   unsigned short* __restrict__ p2, int64_t n4) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    bf16x4 a, b, c;
+    // grid-stride: a launch may not carry 2^32 or more threads (HIP), and 8 841 823 x 2048 / 4 elements is 4.5e9
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        bf16x4 a, b, c;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned short h = f32_to_bf16(v[e]);
-        const float r1 = v[e] - bf16_to_f32(h);          // exact
-        const unsigned short m = f32_to_bf16(r1);
-        const float r2 = r1 - bf16_to_f32(m);            // exact
-        a[e] = (short)h;
-        b[e] = (short)m;
-        c[e] = (short)f32_to_bf16(r2);
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short h = f32_to_bf16(v[e]);
+            const float r1 = v[e] - bf16_to_f32(h);          // exact
+            const unsigned short m = f32_to_bf16(r1);
+            const float r2 = r1 - bf16_to_f32(m);            // exact
+            a[e] = (short)h;
+            b[e] = (short)m;
+            c[e] = (short)f32_to_bf16(r2);
+        }
+        reinterpret_cast<bf16x4*>(p0)[i] = a;
+        reinterpret_cast<bf16x4*>(p1)[i] = b;
+        if (p2) reinterpret_cast<bf16x4*>(p2)[i] = c;
     }
-    reinterpret_cast<bf16x4*>(p0)[i] = a;
-    reinterpret_cast<bf16x4*>(p1)[i] = b;
-    if (p2) reinterpret_cast<bf16x4*>(p2)[i] = c;
 }
 
 int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, unsigned short* p2, int64_t n_elems, hipStream_t s) {
     const int64_t n4 = n_elems / 4;
     if (n4 == 0) return SR_OK;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, src, p0, p1, p2, n4);
+    int64_t blocks = ceil_div64(n4, 256);
+    if (blocks > (1 << 22)) blocks = 1 << 22;          // 2^30 threads per launch, the rest by the grid stride
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, p0, p1, p2, n4);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
