@@ -78,18 +78,30 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         qoff[i] = (int64_t)rq * H + schunk * 8;
     }
     const int nk = H / 64;
-    auto stage = [&](int st, int kt) {
-        const int pair = kt / nk, k0 = (kt - pair * nk) * 64;
-        const unsigned short* dsrc = a.D[a.pair_d[pair]];
-        const unsigned short* qsrc = a.Q[a.pair_q[pair]];
+    // k-tiles are staged strictly in order (0, 1, 2, ...), so the plane pair of the NEXT tile is tracked incrementally:
+    // the plane pointers change once per H / 64 tiles.  (Looking them up per tile - a division, then two dependent
+    // scalar loads from the kernel arguments - sat right behind the k-step barrier, in front of the LDS-DMA issue.)
+    int st_pair = 0, st_k0 = 0;
+    const unsigned short* st_d = a.D[a.pair_d[0]];
+    const unsigned short* st_q = a.Q[a.pair_q[0]];
+    auto stage = [&](int st, int /*kt: the next tile in order*/) {
         unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 4) * 1024;
         unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 4) * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(dsrc + doff[i] + k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + doff[i] + st_k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(qsrc + qoff[i] + k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + qoff[i] + st_k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+        st_k0 += 64;
+        if (st_k0 == H) {
+            st_k0 = 0;
+            ++st_pair;
+            if (st_pair < a.n_pairs) {
+                st_d = a.D[a.pair_d[st_pair]];
+                st_q = a.Q[a.pair_q[st_pair]];
+            }
+        }
     };
 
     f32x4 acc[NB][MB];
