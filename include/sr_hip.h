@@ -153,9 +153,10 @@ typedef struct {
     int32_t has_lm_head;              /* 0: LlamaBiModel (dense), 1: LlamaBiForMNTP (sparse) */
     int32_t max_batch_tokens;         /* workspace sizing: max packed tokens per encode call */
     int32_t max_batch_seqs;
-    int32_t fp32_planes;              /* fp32 regime (sr_encode_*_fp32): 0 = not available, 3 = every weight also kept as
-                                         three bf16 planes (the whole fp32 significand, 6 plane products per GEMM),
-                                         2 = two planes / 3 products (~2^-17 relative per product, half the work)   */
+    int32_t fp32_planes;              /* fp32 regime (sr_encode_*_fp32): 0 = not available; 16 = every weight also kept as two
+                                         fp16 planes of power-of-two scaled rows (22 significand bits, 3 plane products
+                                         per GEMM: truncation below the fp32 accumulation's own rounding); 3 = three bf16
+                                         planes (24 bits, 6 products); 2 = two bf16 planes (3 products, ~2^-17)        */
 } sr_model_config;
 
 int sr_model_create(sr_model** out, const sr_model_config* cfg);
@@ -227,6 +228,10 @@ int sr_gemm_bf16(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t
 /* QKV projection with the RoPE rotation fused into the epilogue (fp32, HF rotate_half layout):
  * C bf16 [M,N]; features [0, n_rope) = q heads then k heads are rotated with the angle of
  * d_pos[m], features [n_rope, N) (v heads) are stored as is.                      */
+/* The GEMM of the encoder's fp32 regime on fp16 planes (fp32_planes = 16): d_A [M, K] / d_W [N, K] fp16 plane segments of rows
+ * scaled by powers of two, d_a_scale [M] / d_w_scale [N] the inverse scales; C fp32 [M, N] += (A W^T) a_scale[m] w_scale[n]. */
+int sr_gemm_f16_scaled(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, const float* d_a_scale,
+                       const float* d_w_scale, float* d_C, sr_stream stream);
 int sr_gemm_qkv_rope(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, void* d_C,
                      const int32_t* d_pos, const float* d_rope_cos, const float* d_rope_sin,
                      int32_t n_rope, int32_t head_dim, sr_stream stream);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sr_model_destroy": (c_int, [c_void_p]),
     "sr_lora_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "sr_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "sr_gemm_f16_scaled": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sr_gemm_qkv_rope": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int32, c_int32, c_void_p]),
     "sr_attention_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

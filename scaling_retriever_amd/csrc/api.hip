@@ -64,3 +64,13 @@ extern "C" int sr_attention_varlen(const void* d_qkv, void* d_out, const int32_t
     }
     return launch_attention(a, (hipStream_t)stream);
 }
+
+// fp16-plane GEMM of the encoder's fp32 regime, exported for the per-kernel parity test: C fp32 [M, N] += (A' @ W'^T) *
+// a_scale[m] * w_scale[n], A' / W' = [rows, K] fp16 plane segments.
+extern "C" int sr_gemm_f16_scaled(const void* d_A, const void* d_W, int32_t M, int32_t N, int32_t K, const float* d_a_scale,
+                                  const float* d_w_scale, float* d_C, sr_stream stream) {
+    SR_REQUIRE(d_A && d_W && d_C && d_a_scale && d_w_scale, "sr_gemm_f16_scaled: null pointer");
+    GemmArgs g{};
+    g.A = (const bf16_t*)d_A; g.W = (const bf16_t*)d_W; g.M = M; g.N = N; g.K = K; g.C = d_C; g.a_scale = d_a_scale; g.w_scale = d_w_scale;
+    return launch_gemm_bf16(EPI_RESID_F32_H, g, (hipStream_t)stream);
+}

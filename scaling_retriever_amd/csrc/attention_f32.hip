@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnF32Args a) {
         const int row = wave * AF_RPW + r;
         if (row >= nrows) break;
         const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+        if (a.out_f32) {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) a.out_f32[(int64_t)(t0 + r0 + row) * a.nh * HD + h * HD + lane + 64 * e] = o[r][e] * inv;
+            continue;
+        }
         bf16_t* orow = a.out + (int64_t)(t0 + r0 + row) * ldo;
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnF32Args a) {
 
 int launch_attention_f32(const AttnF32Args& a, hipStream_t s) {
     SR_REQUIRE(a.nh % a.nkv == 0, "attention(fp32): num_heads %d not a multiple of num_kv_heads %d", a.nh, a.nkv);
-    SR_REQUIRE(a.out_map.n_seg >= 1 && a.out_map.n_seg <= SR_MAX_SEG, "attention(fp32): bad segment map");
+    SR_REQUIRE(a.out_f32 || (a.out_map.n_seg >= 1 && a.out_map.n_seg <= SR_MAX_SEG), "attention(fp32): bad segment map");
     if (a.B == 0 || a.max_seqlen <= 0) return SR_OK;
     const dim3 grid((unsigned)a.B, (unsigned)a.nh, (unsigned)ceil_div64(a.max_seqlen, AF_ROWS)), block(256);
     SR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "attention(fp32): grid too large");

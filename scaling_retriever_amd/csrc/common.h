@@ -98,6 +98,25 @@ __device__ inline void split_bf16x3(float v, unsigned short& p0, unsigned short&
     p2 = f32_to_bf16(r2);
 }
 
+// fp32 -> two fp16 planes of v * scale (scale a power of two chosen per row so that the row maximum lands in [2^14, 2^15)):
+// v * scale = f0 + f1 up to 2^-22 |v * scale|; values that far below the row maximum lose bits only below 2^-24 of it
+__device__ inline void split_f16x2(float vs, unsigned short& f0, unsigned short& f1) {
+    const _Float16 h0 = (_Float16)vs;
+    const float r = vs - (float)h0;               // exact in fp32
+    const _Float16 h1 = (_Float16)r;
+    f0 = __builtin_bit_cast(unsigned short, h0);
+    f1 = __builtin_bit_cast(unsigned short, h1);
+}
+// power-of-two scale for a row whose largest magnitude is mx: mx * scale in [2^14, 2^15); 1 for an all-zero row
+__device__ inline float row_scale_pow2(float mx) {
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);                          // mx = m * 2^e, m in [0.5, 1)
+    int t = 15 - e;
+    t = t > 100 ? 100 : (t < -100 ? -100 : t);
+    return ldexpf(1.0f, t);
+}
+
 // ---- fused top-k workspace shared by the dense and sparse scorers ----
 struct TopkWS {
     int64_t nq_cap = 0;      // allocated queries

@@ -53,6 +53,9 @@ int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, 
 }
 
 // ---- scoring kernel ----------------------------------------------------------------------------------
+#ifndef SP_ORDER
+#define SP_ORDER 1
+#endif
 #define SP_BN 256   // docs per workgroup
 #define SP_BM 256   // queries per workgroup
 __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
@@ -61,8 +64,18 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+    // Workgroup order.  SP_ORDER 1 (default): query tile fastest - the ~256 resident workgroups are all the query tiles of
+    // a handful of doc tiles, so a doc tile (3 MB of plane rows) is fetched from HBM once and then shared through L2 /
+    // Infinity Cache by its 28 query tiles, and the query planes (84 MB at 6 980 queries) stay in the Infinity Cache.
+    // SP_ORDER 0: doc tile fastest - every resident workgroup streams a doc tile of its own, each of which is read again
+    // by every other query tile later (28 x 268 MB per launch).
+#if SP_ORDER
+    const int64_t row0 = a.row_begin + (int64_t)blockIdx.y * SP_BN;
+    const int q0 = blockIdx.x * SP_BM;
+#else
     const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * SP_BN;
     const int q0 = blockIdx.y * SP_BM;
+#endif
     const int H = a.H;
 
     const int srow = lane >> 3;
@@ -244,7 +257,12 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         *attr_slot = true;
     }
+#if SP_ORDER
+    const dim3 grid((unsigned)ceil_div64(a.nq, SP_BM), (unsigned)ceil_div64(rows, SP_BN));
+#else
     const dim3 grid((unsigned)ceil_div64(rows, SP_BN), (unsigned)ceil_div64(a.nq, SP_BM));
+#endif
+    SR_REQUIRE(grid.y <= 65535, "dense_split: launch of %lld rows x %d queries exceeds the grid", (long long)rows, a.nq);
     hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, a);
     SR_CHECK_LAUNCH();
     return SR_OK;

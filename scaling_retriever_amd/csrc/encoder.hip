@@ -339,6 +339,86 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* __restrict__ 
     }
 }
 
+// ---- fp16-plane regime (cfg.fp32_planes == SR_FP32_PLANES_F16): rows scaled by a power of two, two fp16 planes ----
+// weights: dst[row_map(r)] = [g0 | g1 | g0] (kernels.h split_map_w), w_inv[row_map(r)] = 1 / scale of that row
+__global__ __launch_bounds__(256) void convert_rows_split_h_kernel(const void* __restrict__ src, int src_dtype, int64_t rows, int64_t cols,
+                                                                   bf16_t* __restrict__ dst, float* __restrict__ w_inv,
+                                                                   int64_t dst_row_base, int interleave) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    int64_t dr = r;
+    if (interleave) dr = (r / 16) * 32 + (interleave == 2 ? 16 : 0) + (r % 16);
+    dr += dst_row_base;
+    auto at = [&](int64_t c) {
+        return src_dtype == SR_DTYPE_F32 ? reinterpret_cast<const float*>(src)[r * cols + c]
+                                         : bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[r * cols + c]);
+    };
+    float mx = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, fabsf(at(c)));
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = row_scale_pow2(mx);
+    if (threadIdx.x == 0) w_inv[dr] = 1.0f / sc;
+    bf16_t* drow = dst + dr * cols * 3;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        unsigned short f0, f1;
+        split_f16x2(at(c) * sc, f0, f1);
+        drow[c] = f0; drow[cols + c] = f1; drow[2 * cols + c] = f0;
+    }
+}
+
+// activations: one wave per row of src fp32 [T, K] -> [f1 | f0 | f0] (split_map_a) + a_inv[t]; with w: the RMSNorm of the row
+// first (x = embed[tok] if embed; y = (x * rsqrt(mean(x^2) + eps)) * w), i.e. rmsnorm_split_kernel on fp16 planes
+__global__ __launch_bounds__(256) void rows_split_h_kernel(float* __restrict__ x, const float* __restrict__ embed,
+                                                           const int* __restrict__ tok_id, const float* __restrict__ w,
+                                                           bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, int K, float eps) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float* xr = x + (int64_t)t * K;
+    const float* src = embed ? embed + (int64_t)tok_id[t] * K : xr;
+    float rs = 1.f;
+    if (w) {
+        float ss = 0.f;
+        for (int i = lane * 4; i < K; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            if (embed) *reinterpret_cast<f32x4*>(xr + i) = v;
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        rs = 1.0f / sqrtf(ss / (float)K + eps);
+    }
+    float mx = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f};
+        if (w) g = *reinterpret_cast<const f32x4*>(w + i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(w ? (v[c] * rs) * g[c] : v[c]));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float sc = row_scale_pow2(mx);
+    if (lane == 0) a_inv[t] = 1.0f / sc;
+    bf16_t* orow = xs + (int64_t)t * K * 3;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f};
+        if (w) g = *reinterpret_cast<const f32x4*>(w + i);
+        bf16x4 p0, p1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned short f0, f1;
+            split_f16x2((w ? (v[c] * rs) * g[c] : v[c]) * sc, f0, f1);
+            p0[c] = (short)f0; p1[c] = (short)f1;
+        }
+        *reinterpret_cast<bf16x4*>(orow + i) = p1;
+        *reinterpret_cast<bf16x4*>(orow + K + i) = p0;
+        *reinterpret_cast<bf16x4*>(orow + 2 * K + i) = p0;
+    }
+}
+
 // ---- LoRA merge: W += scale * B @ A -----------------------------------------------------
 __global__ void lora_merge_kernel(float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
                                   int64_t out_f, int64_t in_f, int r, float scale) {
@@ -405,6 +485,8 @@ struct LayerW {
     unsigned have = 0;        // bit per tensor: q k v o gate up down ln1 ln2
     // fp32 regime (cfg.fp32_planes > 0): the same matrices as split-bf16 plane segments along K, [rows, n_seg * K]
     bf16_t *wqkv_s = nullptr, *wo_s = nullptr, *wgu_s = nullptr, *wdown_s = nullptr;
+    // fp16-plane regime: inverse power-of-two scale of every weight row
+    float *wqkv_i = nullptr, *wo_i = nullptr, *wgu_i = nullptr, *wdown_i = nullptr;
 };
 
 struct sr_model {
@@ -414,6 +496,9 @@ struct sr_model {
     float* embed = nullptr;    // fp32 [V, H]
     bf16_t* lm_head = nullptr; // bf16 [V, H] (sparse head)
     bf16_t* lm_head_s = nullptr;   // fp32 regime: [V, n_seg * H] plane segments
+    float* lm_head_i = nullptr;    // fp16-plane regime: [V] inverse row scales
+    float *attn_f = nullptr, *act_f = nullptr;                  // fp16-plane regime: fp32 attention / SwiGLU outputs before the row split
+    float *xs_i = nullptr, *attn_i = nullptr, *act_i = nullptr; // ... and the inverse row scales of xs / attn_s / act_s
     // fp32-regime workspace, allocated by the first fp32 encode call
     bf16_t* xs = nullptr;      // [Tm, n_seg * H]    normed hidden state, plane segments
     float* qkv_f = nullptr;    // [Tm, (nh + 2 nkv) hd] rotated q/k/v, fp32
@@ -444,7 +529,11 @@ static void model_free(sr_model* m) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(m->embed); F(m->lm_head); F(m->norm_w); F(m->rope_cos); F(m->rope_sin);
     F(m->lm_head_s); F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s);
-    for (auto& l : m->layers) { F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); F(l.wqkv_s); F(l.wo_s); F(l.wgu_s); F(l.wdown_s); }
+    F(m->lm_head_i); F(m->attn_f); F(m->act_f); F(m->xs_i); F(m->attn_i); F(m->act_i);
+    for (auto& l : m->layers) {
+        F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); F(l.wqkv_s); F(l.wo_s); F(l.wgu_s); F(l.wdown_s);
+        F(l.wqkv_i); F(l.wo_i); F(l.wgu_i); F(l.wdown_i);
+    }
     F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act); F(m->delta);
     F(m->span_start); F(m->span_len); F(m->pool_start); F(m->row_len); F(m->cu);
     F(m->tok_id); F(m->pos); F(m->seq_of); F(m->key_valid);
@@ -504,7 +593,8 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
                "sr_model_create: hidden_size and intermediate_size must be multiples of 64");
     SR_REQUIRE(c.vocab_size % 16 == 0 || !c.has_lm_head, "sr_model_create: vocab_size must be a multiple of 16 for the sparse head");
     SR_REQUIRE(c.max_batch_tokens > 0 && c.max_batch_seqs > 0 && c.max_batch_seqs <= 65536, "sr_model_create: bad workspace sizes");
-    SR_REQUIRE(c.fp32_planes == 0 || c.fp32_planes == 2 || c.fp32_planes == 3, "sr_model_create: fp32_planes must be 0, 2 or 3");
+    SR_REQUIRE(c.fp32_planes == 0 || c.fp32_planes == 2 || c.fp32_planes == 3 || c.fp32_planes == SR_FP32_PLANES_F16,
+               "sr_model_create: fp32_planes must be 0, 2, 3 or 16");
     sr_model* m = new sr_model();
     m->cfg = c;
     m->Tm = (int)(ceil_div64(c.max_batch_tokens, 128) * 128);
@@ -516,7 +606,9 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
     SR_ALLOC(m->embed, V * H * 4);
     if (c.has_lm_head) SR_ALLOC(m->lm_head, V * H * 2);
     const int64_t nsg = c.fp32_planes ? split_map_w(c.fp32_planes).n_seg : 0;
+    const bool f16p = c.fp32_planes == SR_FP32_PLANES_F16;
     if (c.has_lm_head && nsg) SR_ALLOC(m->lm_head_s, V * H * 2 * nsg);
+    if (c.has_lm_head && f16p) SR_ALLOC(m->lm_head_i, V * 4);
     SR_ALLOC(m->norm_w, H * 4);
     for (auto& l : m->layers) {
         SR_ALLOC(l.wqkv, (nq + 2 * nkv) * H * 2);
@@ -528,6 +620,12 @@ extern "C" int sr_model_create(sr_model** out, const sr_model_config* cfg) {
             SR_ALLOC(l.wo_s, H * nq * 2 * nsg);
             SR_ALLOC(l.wgu_s, 2 * I * H * 2 * nsg);
             SR_ALLOC(l.wdown_s, H * I * 2 * nsg);
+        }
+        if (f16p) {
+            SR_ALLOC(l.wqkv_i, (nq + 2 * nkv) * 4);
+            SR_ALLOC(l.wo_i, H * 4);
+            SR_ALLOC(l.wgu_i, 2 * I * 4);
+            SR_ALLOC(l.wdown_i, H * 4);
         }
         SR_ALLOC(l.ln1, H * 4);
         SR_ALLOC(l.ln2, H * 4);
@@ -582,10 +680,13 @@ extern "C" int sr_model_destroy(sr_model* m) {
 }
 
 static int convert_rows(const void* src, int dtype, int64_t rows, int64_t cols, bf16_t* dbf, float* df32, int64_t base,
-                        int interleave, hipStream_t s, bf16_t* dsplit = nullptr, int planes = 0) {
+                        int interleave, hipStream_t s, bf16_t* dsplit = nullptr, int planes = 0, float* w_inv = nullptr) {
     hipLaunchKernelGGL(convert_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dbf, df32, base,
                        interleave);
-    if (dsplit && planes)
+    if (dsplit && planes == SR_FP32_PLANES_F16)
+        hipLaunchKernelGGL(convert_rows_split_h_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dsplit, w_inv, base,
+                           interleave);
+    else if (dsplit && planes)
         hipLaunchKernelGGL(convert_rows_split_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, dtype, rows, cols, dsplit, base,
                            interleave, split_map_w(planes));
     SR_CHECK_LAUNCH();
@@ -607,7 +708,7 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
     if (n == "model.embed_tokens.weight") {
         SHAPE_REQ(V, H);
         SR_TRY(convert_rows(d_ptr, dtype, V, H, (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head : nullptr, m->embed, 0, 0, s,
-                            (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head_s : nullptr, c.fp32_planes));
+                            (c.has_lm_head && c.tie_word_embeddings) ? m->lm_head_s : nullptr, c.fp32_planes, m->lm_head_i));
         m->have_embed = true;
         if (c.has_lm_head && c.tie_word_embeddings) m->have_lm_head = true;
         return SR_OK;
@@ -615,7 +716,7 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
     if (n == "lm_head.weight") {
         SR_REQUIRE(c.has_lm_head, "sr_model_set_weight: model was created without an lm_head");
         SHAPE_REQ(V, H);
-        SR_TRY(convert_rows(d_ptr, dtype, V, H, m->lm_head, nullptr, 0, 0, s, m->lm_head_s, c.fp32_planes));
+        SR_TRY(convert_rows(d_ptr, dtype, V, H, m->lm_head, nullptr, 0, 0, s, m->lm_head_s, c.fp32_planes, m->lm_head_i));
         m->have_lm_head = true;
         return SR_OK;
     }
@@ -630,13 +731,13 @@ extern "C" int sr_model_set_weight(sr_model* m, const char* name, const void* d_
     if (sscanf(name, "model.layers.%d.%127s", &li, rest) == 2 && li >= 0 && li < c.num_layers) {
         LayerW& l = m->layers[li];
         std::string r(rest);
-        if (r == "self_attn.q_proj.weight") { SHAPE_REQ(nq, H); SR_TRY(convert_rows(d_ptr, dtype, nq, H, l.wqkv, nullptr, 0, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 1; return SR_OK; }
-        if (r == "self_attn.k_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 2; return SR_OK; }
-        if (r == "self_attn.v_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq + nkv, 0, s, l.wqkv_s, c.fp32_planes)); l.have |= 4; return SR_OK; }
-        if (r == "self_attn.o_proj.weight") { SHAPE_REQ(H, nq); SR_TRY(convert_rows(d_ptr, dtype, H, nq, l.wo, nullptr, 0, 0, s, l.wo_s, c.fp32_planes)); l.have |= 8; return SR_OK; }
-        if (r == "mlp.gate_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 1, s, l.wgu_s, c.fp32_planes)); l.have |= 16; return SR_OK; }
-        if (r == "mlp.up_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 2, s, l.wgu_s, c.fp32_planes)); l.have |= 32; return SR_OK; }
-        if (r == "mlp.down_proj.weight") { SHAPE_REQ(H, I); SR_TRY(convert_rows(d_ptr, dtype, H, I, l.wdown, nullptr, 0, 0, s, l.wdown_s, c.fp32_planes)); l.have |= 64; return SR_OK; }
+        if (r == "self_attn.q_proj.weight") { SHAPE_REQ(nq, H); SR_TRY(convert_rows(d_ptr, dtype, nq, H, l.wqkv, nullptr, 0, 0, s, l.wqkv_s, c.fp32_planes, l.wqkv_i)); l.have |= 1; return SR_OK; }
+        if (r == "self_attn.k_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq, 0, s, l.wqkv_s, c.fp32_planes, l.wqkv_i)); l.have |= 2; return SR_OK; }
+        if (r == "self_attn.v_proj.weight") { SHAPE_REQ(nkv, H); SR_TRY(convert_rows(d_ptr, dtype, nkv, H, l.wqkv, nullptr, nq + nkv, 0, s, l.wqkv_s, c.fp32_planes, l.wqkv_i)); l.have |= 4; return SR_OK; }
+        if (r == "self_attn.o_proj.weight") { SHAPE_REQ(H, nq); SR_TRY(convert_rows(d_ptr, dtype, H, nq, l.wo, nullptr, 0, 0, s, l.wo_s, c.fp32_planes, l.wo_i)); l.have |= 8; return SR_OK; }
+        if (r == "mlp.gate_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 1, s, l.wgu_s, c.fp32_planes, l.wgu_i)); l.have |= 16; return SR_OK; }
+        if (r == "mlp.up_proj.weight") { SHAPE_REQ(I, H); SR_TRY(convert_rows(d_ptr, dtype, I, H, l.wgu, nullptr, 0, 2, s, l.wgu_s, c.fp32_planes, l.wgu_i)); l.have |= 32; return SR_OK; }
+        if (r == "mlp.down_proj.weight") { SHAPE_REQ(H, I); SR_TRY(convert_rows(d_ptr, dtype, H, I, l.wdown, nullptr, 0, 0, s, l.wdown_s, c.fp32_planes, l.wdown_i)); l.have |= 64; return SR_OK; }
         if (r == "input_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln1, 0, 0, s)); l.have |= 128; return SR_OK; }
         if (r == "post_attention_layernorm.weight") { SHAPE_REQ(H, 1); SR_TRY(convert_rows(d_ptr, dtype, H, 1, nullptr, l.ln2, 0, 0, s)); l.have |= 256; return SR_OK; }
     }
@@ -677,11 +778,17 @@ static int ensure_fp32_workspace(sr_model* m) {
         if (hipMalloc(p, (size_t)bytes) != hipSuccess) { *p = nullptr; return false; }
         return hipMemset(*p, 0, (size_t)bytes) == hipSuccess;
     };
-    if (!A((void**)&m->xs, Tm * H * 2 * nsg) || !A((void**)&m->qkv_f, Tm * (nq + 2 * nkv) * 4) ||
-        !A((void**)&m->attn_s, Tm * nq * 2 * nsg) || !A((void**)&m->act_s, Tm * I * 2 * nsg)) {
+    const bool f16p = c.fp32_planes == SR_FP32_PLANES_F16;
+    bool ok = A((void**)&m->xs, Tm * H * 2 * nsg) && A((void**)&m->qkv_f, Tm * (nq + 2 * nkv) * 4) &&
+              A((void**)&m->attn_s, Tm * nq * 2 * nsg) && A((void**)&m->act_s, Tm * I * 2 * nsg);
+    if (ok && f16p)
+        ok = A((void**)&m->attn_f, Tm * nq * 4) && A((void**)&m->act_f, Tm * I * 4) && A((void**)&m->xs_i, Tm * 4) &&
+             A((void**)&m->attn_i, Tm * 4) && A((void**)&m->act_i, Tm * 4);
+    if (!ok) {
         auto F = [](void* p) { if (p) (void)hipFree(p); };
-        F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s);
+        F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s); F(m->attn_f); F(m->act_f); F(m->xs_i); F(m->attn_i); F(m->act_i);
         m->xs = nullptr; m->qkv_f = nullptr; m->attn_s = nullptr; m->act_s = nullptr;
+        m->attn_f = nullptr; m->act_f = nullptr; m->xs_i = nullptr; m->attn_i = nullptr; m->act_i = nullptr;
         sr_set_error("encode(fp32): hipMalloc of the fp32-regime workspace failed (%lld tokens)", (long long)Tm);
         return SR_ERR_NOMEM;
     }
@@ -728,6 +835,41 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
                        m->pos, m->key_valid, m->seq_of, c.vocab_size, mode);
     SR_CHECK_LAUNCH();
 
+    if (prec == PREC_FP32 && c.fp32_planes == SR_FP32_PLANES_F16) {
+        // fp16 planes: every GEMM input is split by ONE kernel that sees whole rows (norm + split, or split of an fp32
+        // buffer), because the power-of-two scale is per row; 3 plane products per GEMM
+        auto split_rows = [&](float* src, const float* embed, const int* tok, const float* w, bf16_t* dst, float* inv, int K) {
+            hipLaunchKernelGGL(rows_split_h_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, src, embed, tok, w, dst, inv, T, K,
+                               c.rms_norm_eps);
+        };
+        for (int li = 0; li < c.num_layers; ++li) {
+            LayerW& l = m->layers[li];
+            split_rows(m->x, li == 0 ? m->embed : (const float*)nullptr, li == 0 ? m->tok_id : (const int*)nullptr, l.ln1, m->xs, m->xs_i, H);
+            GemmArgs g{};
+            g.A = m->xs; g.W = l.wqkv_s; g.M = T; g.N = nq + 2 * nkv; g.K = 3 * H; g.C = m->qkv_f; g.a_scale = m->xs_i; g.w_scale = l.wqkv_i;
+            g.pos = m->pos; g.rope_cos = m->rope_cos; g.rope_sin = m->rope_sin; g.n_rope = nq + nkv; g.head_dim = c.head_dim;
+            SR_TRY(launch_gemm_bf16(EPI_QKV_ROPE_F32_H, g, s));
+            AttnF32Args a{};
+            a.qkv = m->qkv_f; a.out_f32 = m->attn_f; a.out = nullptr; a.cu_seqlens = m->cu; a.key_valid = m->key_valid;
+            a.B = B; a.nh = c.num_heads; a.nkv = c.num_kv_heads; a.hd = c.head_dim;
+            a.scale = 1.0f / sqrtf((float)c.head_dim); a.max_seqlen = max_len;
+            SR_TRY(launch_attention_f32(a, s));
+            split_rows(m->attn_f, nullptr, nullptr, nullptr, m->attn_s, m->attn_i, nq);
+            g = GemmArgs{};
+            g.A = m->attn_s; g.W = l.wo_s; g.M = T; g.N = H; g.K = 3 * nq; g.C = m->x; g.a_scale = m->attn_i; g.w_scale = l.wo_i;
+            SR_TRY(launch_gemm_bf16(EPI_RESID_F32_H, g, s));
+            split_rows(m->x, nullptr, nullptr, l.ln2, m->xs, m->xs_i, H);
+            g = GemmArgs{};
+            g.A = m->xs; g.W = l.wgu_s; g.M = T; g.N = 2 * I; g.K = 3 * H; g.C = m->act_f; g.a_scale = m->xs_i; g.w_scale = l.wgu_i;
+            SR_TRY(launch_gemm_bf16(EPI_SWIGLU_F32_H, g, s));
+            split_rows(m->act_f, nullptr, nullptr, nullptr, m->act_s, m->act_i, I);
+            g = GemmArgs{};
+            g.A = m->act_s; g.W = l.wdown_s; g.M = T; g.N = H; g.K = 3 * I; g.C = m->x; g.a_scale = m->act_i; g.w_scale = l.wdown_i;
+            SR_TRY(launch_gemm_bf16(EPI_RESID_F32_H, g, s));
+        }
+        SR_CHECK_LAUNCH();
+        return SR_OK;
+    }
     if (prec == PREC_FP32) {
         const SplitMap ma = split_map_a(c.fp32_planes);
         const int nsg = ma.n_seg;
@@ -819,7 +961,13 @@ static int head_sparse(sr_model* m, int B, int T, int prec, float* d_out, hipStr
     SR_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)B * V * 4, s));
     if (T == 0) return SR_OK;       // log(1 + relu(max over no tokens)) = 0
     GemmArgs g{};
-    if (prec == PREC_FP32) {
+    GemmEpilogue epi = EPI_SEGMAX;
+    if (prec == PREC_FP32 && m->cfg.fp32_planes == SR_FP32_PLANES_F16) {
+        hipLaunchKernelGGL(rows_split_h_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
+                           (const int*)nullptr, (const float*)m->norm_w, m->xs, m->xs_i, T, H, m->cfg.rms_norm_eps);
+        g.A = m->xs; g.W = m->lm_head_s; g.K = 3 * H; g.a_scale = m->xs_i; g.w_scale = m->lm_head_i;
+        epi = EPI_SEGMAX_H;
+    } else if (prec == PREC_FP32) {
         const SplitMap ma = split_map_a(m->cfg.fp32_planes);
         SR_TRY(launch_rmsnorm_split(m->x, (const float*)nullptr, (const int*)nullptr, m->norm_w, m->xs, T, H, m->cfg.rms_norm_eps,
                                     ma, s));
@@ -832,7 +980,7 @@ static int head_sparse(sr_model* m, int B, int T, int prec, float* d_out, hipStr
     }
     g.M = T; g.N = V; g.C = d_out; g.seq_of = m->seq_of; g.out_ld = V;
     // rows with seq_of == -2 (mask == 0 inside the span) are skipped by the segmented max
-    SR_TRY(launch_gemm_bf16(EPI_SEGMAX, g, s));
+    SR_TRY(launch_gemm_bf16(epi, g, s));
     const int64_t n = (int64_t)B * V;
     // under autocast the lm_head output is bf16 (rounded before the fp32 upcast, llm_encoder.py:187-188); in fp32 it is not
     hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, d_out, n,

@@ -25,6 +25,15 @@
 #include <string.h>
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
+// one MFMA step of the k-loop: the fragments are 16 bytes of either bf16 or fp16
+template <bool F16>
+__device__ __forceinline__ f32x4 sr_mma(const mfma_bf16x8& w, const mfma_bf16x8& a, const f32x4& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, w), __builtin_bit_cast(mfma_f16x8, a), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 
@@ -36,6 +45,9 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
 void gemm_bf16_kernel(GemmArgs g) {
+    constexpr bool F16 = EPI >= EPI_H_FIRST;          // fp16 plane operands + row scales (fp32 regime), see kernels.h
+    constexpr int BEPI = !F16 ? EPI : (EPI == EPI_QKV_ROPE_F32_H ? EPI_QKV_ROPE_F32 : (EPI == EPI_RESID_F32_H ? EPI_RESID_F32
+                                      : (EPI == EPI_SWIGLU_F32_H ? EPI_SWIGLU_F32 : EPI_SEGMAX)));
     constexpr int NW = WAVES_N * WAVES_M;
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE_BYTES = W_BYTES + A_BYTES;
@@ -114,7 +126,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int j = 0; j < MB; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = sr_mma<F16>(wf[i], af[j], acc[i][j]);
     };
     // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile(s) of the NEXT output tile are
     // prefetched during the last k-step(s) of the current one, so only the epilogue's stores stay exposed between tiles.
@@ -126,7 +138,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int sj[MB];      // EPI_SEGMAX: sequence ids of this lane's token rows, fetched here so that the k-loop covers the latency
-    if constexpr (EPI == EPI_SEGMAX) {
+    if constexpr (BEPI == EPI_SEGMAX) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int m = m0 + wm * MB * 16 + j * 16 + frow;
@@ -159,7 +171,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #define SR_MFMA_HALF(H, WF, AF)                                                                              \
         _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                       \
             _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                   \
-                acc[(H) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(H) * HB + i][j], 0, 0, 0);
+                acc[(H) * HB + i][j] = sr_mma<F16>(WF[i], AF[j], acc[(H) * HB + i][j]);
         load_w(buf, 0, 0, wx);
         load_a(buf, 0, a0);
         int kt = 0;
@@ -241,7 +253,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #define SR_MFMA_HALF(H, WF, AF)                                                                              \
         _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                       \
             _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                   \
-                acc[(H) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(H) * HB + i][j], 0, 0, 0);
+                acc[(H) * HB + i][j] = sr_mma<F16>(WF[i], AF[j], acc[(H) * HB + i][j]);
         load_w(buf, 0, 0, wx);
         load_a(buf, 0, a0);
         int kt = 0;
@@ -333,8 +345,26 @@ void gemm_bf16_kernel(GemmArgs g) {
 
     if (stamp && titer < 16) stp[titer * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (stamp && titer == 1) stp[63] = __builtin_amdgcn_s_memtime();        // ... and at its end: clock = d(memtime) / d(realtime) * 100 MHz
+    if constexpr (F16) {       // undo the power-of-two row scales of both operands (exact)
+        float sa[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            sa[j] = m < g.M ? g.a_scale[m] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+            f32x4 sw = {0.f, 0.f, 0.f, 0.f};
+            if (n < g.N) sw = *reinterpret_cast<const f32x4*>(g.w_scale + n);
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa[j] * sw[r];
+        }
+    }
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
-    if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32) {
+    if constexpr (BEPI == EPI_STORE_BF16 || BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int m = m0 + wm * MB * 16 + j * 16 + frow;
@@ -344,14 +374,14 @@ void gemm_bf16_kernel(GemmArgs g) {
                 const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
                 if (n >= g.N) continue;
                 const f32x4 v = acc[i][j];
-                if constexpr (EPI == EPI_STORE_BF16) {
+                if constexpr (BEPI == EPI_STORE_BF16) {
                     bf16x4 o;
                     o[0] = (short)f32_to_bf16(v[0]);
                     o[1] = (short)f32_to_bf16(v[1]);
                     o[2] = (short)f32_to_bf16(v[2]);
                     o[3] = (short)f32_to_bf16(v[3]);
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.N + n) = o;
-                } else if constexpr (EPI == EPI_STORE_F32) {
+                } else if constexpr (BEPI == EPI_STORE_F32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.N + n) = v;
                 } else {
                     f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.N + n);
@@ -361,12 +391,12 @@ void gemm_bf16_kernel(GemmArgs g) {
                 }
             }
         }
-    } else if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+    } else if constexpr (BEPI == EPI_QKV_ROPE || BEPI == EPI_QKV_ROPE_F32) {
         // q/k heads: out[d] = x[d] cos - x[d + hd/2] sin, out[d + hd/2] = x[d + hd/2] cos + x[d] sin (HF rotate_half),
         // in fp32 on the accumulators; both halves of a head live in this lane (blocks i and i + hd/32).
         // A wave's feature range (16 * NB) covers whole heads: NB * 16 % head_dim == 0 is checked at launch.
         // EPI_QKV_ROPE_F32 (fp32 regime) stores the rotated fp32 values as they are.
-        constexpr bool F32OUT = EPI == EPI_QKV_ROPE_F32;
+        constexpr bool F32OUT = BEPI == EPI_QKV_ROPE_F32;
         const int hd = g.head_dim, hb = hd / 32;   // hb = block distance between rotation partners
         auto put = [&](int64_t off, const f32x4& v) {
             if constexpr (F32OUT) {
@@ -409,7 +439,7 @@ void gemm_bf16_kernel(GemmArgs g) {
                 }
             }
         }
-    } else if constexpr (EPI == EPI_SWIGLU) {
+    } else if constexpr (BEPI == EPI_SWIGLU) {
         const int half_n = g.N >> 1;
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
@@ -429,7 +459,24 @@ void gemm_bf16_kernel(GemmArgs g) {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * half_n + n) = o;
             }
         }
-    } else if constexpr (EPI == EPI_SWIGLU_SPLIT) {
+    } else if constexpr (BEPI == EPI_SWIGLU_F32) {
+        const int half_n = g.N >> 1;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int i = 0; i < NB; i += 2) {
+                const int n = (n0 >> 1) + wn * NB * 8 + (i >> 1) * 16 + fg * 4;
+                if (n >= half_n) continue;
+                const f32x4 gt = acc[i][j], up = acc[i + 1][j];
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (gt[r] / (1.f + expf(-gt[r]))) * up[r];
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * half_n + n) = y;
+            }
+        }
+    } else if constexpr (BEPI == EPI_SWIGLU_SPLIT) {
         // fp32 regime: silu(gate) * up with an accurate exp and a true division, then stored as the split-bf16 plane
         // segments the down_proj GEMM consumes: C [M, n_seg * N/2], segment sg holds plane out_map.plane[sg]
         const int half_n = g.N >> 1;
@@ -621,10 +668,10 @@ static bool env_off(const char* name) {
 template <int EPI>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
     const bool pipe = g.K / G_BK >= 4 && !env_off("SR_GEMM_PIPE");      // the pipelined k-loop needs >= 4 k-steps
-    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_QKV_ROPE_F32_H) {
         if (g.head_dim == 128) return launch_cfg<EPI, 1, 4, 8, 2>(g, s);        // 128 x 128 tile, wave = 128 features x 32 tokens
     }
-    if constexpr (EPI != EPI_QKV_ROPE && EPI != EPI_QKV_ROPE_F32) {
+    if constexpr (EPI != EPI_QKV_ROPE && EPI != EPI_QKV_ROPE_F32 && EPI != EPI_QKV_ROPE_F32_H) {
         // few 128^2 tiles (a short tail behind the 256^2 rounds, or a small problem): halve the token tile so that two or
         // three workgroups share every CU instead of one 4-wave workgroup idling half its MFMA pipe
         const int64_t t128 = ceil_div64(g.N, 128) * ceil_div64(g.M, 128);
@@ -641,9 +688,11 @@ static GemmArgs rows_from(const GemmArgs& g, int row0) {
     GemmArgs t = g;
     t.A = g.A + (int64_t)row0 * g.K;
     t.M = g.M - row0;
-    const int64_t ldc = (EPI == EPI_SWIGLU) ? g.N / 2 : (EPI == EPI_SWIGLU_SPLIT ? (int64_t)g.out_map.n_seg * (g.N / 2) : g.N);
-    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE_F32) ? 4 : 2;
-    if constexpr (EPI != EPI_SEGMAX) t.C = reinterpret_cast<unsigned char*>(g.C) + (int64_t)row0 * ldc * esz;
+    const int64_t ldc = (EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_F32 || EPI == EPI_SWIGLU_F32_H)
+                            ? g.N / 2 : (EPI == EPI_SWIGLU_SPLIT ? (int64_t)g.out_map.n_seg * (g.N / 2) : g.N);
+    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_SWIGLU_F32 || EPI >= EPI_H_FIRST) ? 4 : 2;
+    if constexpr (EPI != EPI_SEGMAX && EPI != EPI_SEGMAX_H) t.C = reinterpret_cast<unsigned char*>(g.C) + (int64_t)row0 * ldc * esz;
+    if (g.a_scale) t.a_scale = g.a_scale + row0;
     if (g.seq_of) t.seq_of = g.seq_of + row0;
     if (g.pos) t.pos = g.pos + row0;
     t.stamps = nullptr;
@@ -659,20 +708,20 @@ static int skinny_max_rows() {
 
 template <int EPI>
 static int launch_one(const GemmArgs& g, hipStream_t s) {
-    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_QKV_ROPE_F32_H) {
         SR_REQUIRE(g.head_dim == 64 || g.head_dim == 128, "gemm(qkv+rope): head_dim %d not supported", g.head_dim);
         SR_REQUIRE(g.pos && g.rope_cos && g.rope_sin && g.n_rope % g.head_dim == 0 && g.n_rope <= g.N && g.N % g.head_dim == 0,
                    "gemm(qkv+rope): bad rope arguments");
     }
     if (g.M <= skinny_max_rows() && g.K / G_BK >= 4) {
         if (g.M > 32) {
-            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_QKV_ROPE_F32_H) {
                 if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 4, true, 3>(g, s);
             }
             return launch_cfg<EPI, 1, 1, 4, 4, true, 4>(g, s);
         }
         if (g.M > 16) {
-            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+            if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_QKV_ROPE_F32_H) {
                 if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 2, true, 4>(g, s);
             }
             return launch_cfg<EPI, 1, 1, 4, 2, true, 4>(g, s);
@@ -680,7 +729,7 @@ static int launch_one(const GemmArgs& g, hipStream_t s) {
         // A handful of tokens (online queries): the work is streaming W once.  One WAVE per workgroup owns 64 features x 16
         // tokens (N / 64 independent workgroups instead of N / 128 four-wave ones idling on a 16-token tile), four 10 KB LDS
         // stages keep three k-steps of weights in flight per wave.  Same MFMA chain per output element as every other tile.
-        if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32) {
+        if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_QKV_ROPE_F32_H) {
             if (g.head_dim == 128) return launch_cfg<EPI, 1, 1, 8, 1, true, 4>(g, s);
         }
         return launch_cfg<EPI, 1, 1, 4, 1, true, 4>(g, s);
@@ -700,7 +749,9 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
     SR_REQUIRE(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0) return SR_OK;
     SR_REQUIRE(g.K % G_BK == 0, "gemm: K=%d must be a multiple of %d", g.K, G_BK);
-    SR_REQUIRE(g.N % 16 == 0 && ((epi != EPI_SWIGLU && epi != EPI_SWIGLU_SPLIT) || g.N % 32 == 0), "gemm: N=%d must be a multiple of 16 (32 for SwiGLU)", g.N);
+    const bool swiglu = epi == EPI_SWIGLU || epi == EPI_SWIGLU_SPLIT || epi == EPI_SWIGLU_F32 || epi == EPI_SWIGLU_F32_H;
+    SR_REQUIRE(g.N % 16 == 0 && (!swiglu || g.N % 32 == 0), "gemm: N=%d must be a multiple of 16 (32 for SwiGLU)", g.N);
+    SR_REQUIRE(epi < EPI_H_FIRST || (g.a_scale && g.w_scale), "gemm(fp16 planes): missing row scales");
     SR_REQUIRE(epi != EPI_SWIGLU_SPLIT || (g.out_map.n_seg >= 1 && g.out_map.n_seg <= SR_MAX_SEG), "gemm(swiglu split): bad segment map");
     switch (epi) {
         case EPI_STORE_BF16: return launch_one<EPI_STORE_BF16>(g, s);
@@ -711,6 +762,11 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
         case EPI_QKV_ROPE: return launch_one<EPI_QKV_ROPE>(g, s);
         case EPI_QKV_ROPE_F32: return launch_one<EPI_QKV_ROPE_F32>(g, s);
         case EPI_SWIGLU_SPLIT: return launch_one<EPI_SWIGLU_SPLIT>(g, s);
+        case EPI_SWIGLU_F32: return launch_one<EPI_SWIGLU_F32>(g, s);
+        case EPI_QKV_ROPE_F32_H: return launch_one<EPI_QKV_ROPE_F32_H>(g, s);
+        case EPI_RESID_F32_H: return launch_one<EPI_RESID_F32_H>(g, s);
+        case EPI_SWIGLU_F32_H: return launch_one<EPI_SWIGLU_F32_H>(g, s);
+        case EPI_SEGMAX_H: return launch_one<EPI_SEGMAX_H>(g, s);
     }
     sr_set_error("gemm: unknown epilogue %d", (int)epi);
     return SR_ERR_INVALID;

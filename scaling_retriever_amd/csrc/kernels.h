@@ -13,6 +13,12 @@ enum GemmEpilogue {
     EPI_QKV_ROPE = 5,    // C[M,N] bf16 = acc with RoPE applied (fp32) to features n < n_rope (q and k heads)
     EPI_QKV_ROPE_F32 = 6,   // same, C[M,N] fp32 (fp32 regime: the attention reads fp32 operands)
     EPI_SWIGLU_SPLIT = 7,   // fp32 regime: silu(gate) * up in fp32, stored as split-bf16 plane segments (out_map)
+    EPI_SWIGLU_F32 = 8,     // C[M,N/2] fp32 = silu(gate) * up (accurate exp, true division)
+    // fp32 regime on fp16 planes: operands are [rows, 3K] fp16 plane segments of rows scaled by a power of two, the MFMA is
+    // v_mfma_f32_16x16x32_f16 and the accumulators are multiplied by a_scale[m] * w_scale[n] (the inverse scales) before the
+    // epilogue of the base behaviour runs
+    EPI_H_FIRST = 9,
+    EPI_QKV_ROPE_F32_H = 9, EPI_RESID_F32_H = 10, EPI_SWIGLU_F32_H = 11, EPI_SEGMAX_H = 12,
 };
 
 // ---- fp32 regime: fp32 operands as sums of bf16 planes ---------------------------------------------------
@@ -27,12 +33,15 @@ struct SplitMap {
     int n_seg;
     int plane[SR_MAX_SEG];
 };
+//   fp16 planes (SR_FP32_PLANES_F16 = 16): two fp16 planes of power-of-two scaled rows, the same 3-product maps; 11 + 11
+//   significand bits: truncation 3 * 2^-22, below the fp32 accumulation's own rounding - an fp32 GEMM's error at half the work
+#define SR_FP32_PLANES_F16 16
 inline SplitMap split_map_a(int planes) {
-    if (planes >= 3) return SplitMap{6, {2, 0, 1, 1, 0, 0}};
+    if (planes == 3) return SplitMap{6, {2, 0, 1, 1, 0, 0}};
     return SplitMap{3, {1, 0, 0, 0, 0, 0}};
 }
 inline SplitMap split_map_w(int planes) {
-    if (planes >= 3) return SplitMap{6, {0, 2, 1, 0, 1, 0}};
+    if (planes == 3) return SplitMap{6, {0, 2, 1, 0, 1, 0}};
     return SplitMap{3, {0, 1, 0, 0, 0, 0}};
 }
 
@@ -50,6 +59,8 @@ struct GemmArgs {
     int n_rope;             // features [0, n_rope) are rotated (q heads then k heads), the rest (v) stored as is
     int head_dim;           // 64 or 128
     unsigned long long* stamps;  // diagnostics only (tools/micro): 4 s_memrealtime stamps (100 MHz) per workgroup-tile, else null
+    const float* a_scale;   // _H epilogues: [M] inverse scale of each activation row (a power of two)
+    const float* w_scale;   // _H epilogues: [N] inverse scale of each weight row
     SplitMap out_map;  // EPI_SWIGLU_SPLIT: plane of each output segment; C is [M, n_seg * N/2] bf16
     int m_fastest;     // tile order, chosen by launch_gemm_bf16: 1 = token tiles fastest (W far larger than the caches)
 };
@@ -78,7 +89,8 @@ int launch_attention(const AttnArgs& a, hipStream_t s);
 // rotated), fp32 scores, softmax and P.V; the output is written as split-bf16 plane segments for the o_proj GEMM.
 struct AttnF32Args {
     const float* qkv;       // [T, (nh + 2*nkv) * hd]
-    bf16_t* out;            // [T, n_seg * nh * hd]
+    float* out_f32;         // if set: plain fp32 output [T, nh * hd] (the fp16-plane regime splits whole rows afterwards)
+    bf16_t* out;            // else [T, n_seg * nh * hd] bf16 plane segments
     const int* cu_seqlens;  // [B + 1]
     const unsigned char* key_valid;  // [T]
     int B, nh, nkv, hd;

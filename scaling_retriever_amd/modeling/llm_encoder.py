@@ -129,15 +129,16 @@ class HipLlamaBackbone(torch.nn.Module):
         #                     queries (indexer.py:46-52, :255-256, :390-391) - fp32 regime otherwise - dense queries
         #                     (eval_dense.py:94-106) and examples/quick_start.py;
         #   "bf16" / "fp32"   force one regime.
-        # fp32_planes: bf16 planes per fp32 operand in the fp32 regime (3 = full significand, 2 = faster, 0 = no fp32
-        # regime and no extra weight copies); default 3, or the SR_FP32_PLANES environment variable.
+        # fp32_planes: how the fp32 regime represents an fp32 operand: 16 (default) = two fp16 planes of power-of-two scaled
+        # rows, 3 plane products per GEMM - the error of an fp32 GEMM; 3 = three bf16 planes, 6 products; 2 = two bf16
+        # planes, 3 products (~2^-17); 0 = no fp32 regime and no extra weight copies.  Default 16, or SR_FP32_PLANES.
         if precision not in ("auto", "bf16", "fp32"):
             raise ValueError(f"precision must be 'auto', 'bf16' or 'fp32', got {precision!r}")
         self.precision = precision
         if fp32_planes is None:
-            fp32_planes = int(os.environ.get("SR_FP32_PLANES", "3"))
-        if fp32_planes not in (0, 2, 3):
-            raise ValueError(f"fp32_planes must be 0, 2 or 3, got {fp32_planes}")
+            fp32_planes = int(os.environ.get("SR_FP32_PLANES", "16"))
+        if fp32_planes not in (0, 2, 3, 16):
+            raise ValueError(f"fp32_planes must be 0, 2, 3 or 16, got {fp32_planes}")
         self.fp32_planes = int(fp32_planes)
         self.config = config if isinstance(config, LlamaConfigLite) else LlamaConfigLite.from_dict(config)
         self._weights = weights            # name -> tensor (host or device), dropped after upload

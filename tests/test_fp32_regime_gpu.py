@@ -7,8 +7,8 @@ significand, 6 plane products, fp32 accumulation in the MFMA) and an fp32 attent
 follows torch.autocast, as it does for the reference's nn.Linear.
 
 Tolerance (floating point): relative L2 <= 2e-4 against the fp32 golden vectors of the reference's own head classes
-(tests/golden/enc_*.npz; the bf16 regime sits at 3-6e-3).  Measured values are printed; with 3 planes they are ~1e-6,
-i.e. the size of an fp32 summation-order change.
+(tests/golden/enc_*.npz; the bf16 regime sits at 3-6e-3).  Measured values are printed; with the default fp16 planes (and
+with three bf16 planes) they are below 1e-6, i.e. the size of an fp32 summation-order change.
 """
 import json
 import os
@@ -78,19 +78,55 @@ def test_split_gemm_is_fp32_class(planes, tol):
         assert err < 4 * err_fp32 + 1e-7      # the error class of an fp32 GEMM
 
 
+def test_fp16_plane_gemm_has_the_error_of_an_fp32_gemm():
+    """The default representation of the fp32 regime: rows scaled by a power of two, two fp16 planes (22 significand bits), three
+    plane products, the MFMA's fp32 accumulation, inverse scales applied in the epilogue (sr_gemm_f16_scaled) - vs float64, next
+    to torch's own fp32 matmul.  Includes outlier columns (x50) and rows of very different magnitude."""
+    from scaling_retriever_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M, N, K = 900, 640, 2048
+    A = torch.randn((M, K), device="cuda", generator=g) * 3.0
+    A[:, :5] *= 50.0
+    A *= torch.exp(torch.empty((M, 1), device="cuda").uniform_(-6, 6, generator=g))
+    W = torch.randn((N, K), device="cuda", generator=g) / K ** 0.5
+    W *= torch.exp(torch.empty((N, 1), device="cuda").uniform_(-6, 6, generator=g))
+
+    def planes(x):
+        mx = x.abs().amax(1, keepdim=True)
+        sc = torch.pow(2.0, 15 - torch.frexp(mx).exponent.float())            # row_scale_pow2 (csrc/common.h)
+        xs = x * sc
+        f0 = xs.half()
+        f1 = (xs - f0.float()).half()
+        return f0, f1, (1.0 / sc).reshape(-1).contiguous()
+    a0, a1, ai = planes(A)
+    w0, w1, wi = planes(W)
+    A2 = torch.cat([a1, a0, a0], dim=1).contiguous()
+    W2 = torch.cat([w0, w1, w0], dim=1).contiguous()
+    C = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    L.check(lib.sr_gemm_f16_scaled(A2.data_ptr(), W2.data_ptr(), M, N, 3 * K, ai.data_ptr(), wi.data_ptr(), C.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T
+    rowwise = lambda X: float(((X.double() - ref).norm(dim=1) / ref.norm(dim=1)).max())     # noqa: E731
+    err, err_fp32 = rowwise(C), rowwise(A @ W.T)
+    print(f"fp16-plane GEMM: worst row rel err {err:.2e}; torch fp32 matmul {err_fp32:.2e}")
+    assert err < 2e-6 and err < 3 * err_fp32 + 2e-7
+
+
 # ---------------------------------------------------------------- heads vs the fp32 golden
+@pytest.mark.parametrize("planes", [16, 3])
 @pytest.mark.parametrize("name", ["enc_tiny_a", "enc_hd64", "enc_hd128", "enc_toy_q", "enc_toy_d"])
 @pytest.mark.parametrize("side", ["left", "right"])
-def test_dense_fp32_matches_reference_fp32_golden(golden_dir, name, side):
+def test_dense_fp32_matches_reference_fp32_golden(golden_dir, name, side, planes):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     z, cfg, w = _case(golden_dir, name)
-    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiDense.from_weights(cfg, w, fp32_planes=planes).to("cuda").eval()
     ids, mask = _t(z, side)
     assert model.base_model.resolve_precision() == "fp32"          # no autocast active: the reference's query regime
     with torch.no_grad():                                           # eval_dense.py:101
         out = model.query_encode(input_ids=ids, attention_mask=mask).cpu().numpy()
     e = rel(out, z[f"{side}:dense"])
-    print(f"{name}/{side}: fp32-regime dense rel L2 {e:.2e} (reference's own bf16-autocast: "
+    print(f"{name}/{side}/planes {planes}: fp32-regime dense rel L2 {e:.2e} (reference's own bf16-autocast: "
           f"{rel(z[f'{side}:dense_bf16autocast'], z[f'{side}:dense']):.2e})")
     assert e < FP32_TOL_3PLANES < FP32_TOL
     hs = model.base_model.last_hidden_state_packed().cpu().numpy()
@@ -99,17 +135,18 @@ def test_dense_fp32_matches_reference_fp32_golden(golden_dir, name, side):
         assert rel(hs, z[f"{side}:last_hidden_state"][m]) < FP32_TOL_3PLANES
 
 
+@pytest.mark.parametrize("planes", [16, 3])
 @pytest.mark.parametrize("name", ["enc_tiny_a", "enc_hd64", "enc_hd128"])
 @pytest.mark.parametrize("side", ["left", "right"])
-def test_sparse_fp32_matches_reference_fp32_golden(golden_dir, name, side):
+def test_sparse_fp32_matches_reference_fp32_golden(golden_dir, name, side, planes):
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiSparse
     z, cfg, w = _case(golden_dir, name)
-    model = LlamaBiSparse.from_weights(cfg, w).to("cuda").eval()
+    model = LlamaBiSparse.from_weights(cfg, w, fp32_planes=planes).to("cuda").eval()
     ids, mask = _t(z, side)
     out = model.encode(input_ids=ids, attention_mask=mask).cpu().numpy()
     gold = z[f"{side}:sparse"]
     e = rel(out, gold)
-    print(f"{name}/{side}: fp32-regime sparse rel L2 {e:.2e}")
+    print(f"{name}/{side}/planes {planes}: fp32-regime sparse rel L2 {e:.2e}")
     assert e < FP32_TOL_3PLANES
     # the support (which terms are non-zero) must agree except where the max logit is within rounding of zero
     flip = (out > 0) != (gold > 0)

@@ -27,7 +27,7 @@ for planes in [int(a) for a in sys.argv[1:]] or [3, 2]:
                     model.query_encode(input_ids=i, attention_mask=m)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t
-            nseg = {3: 6, 2: 3}[planes] if prec == "fp32" else 1
+            nseg = {3: 6, 2: 3, 16: 3}[planes] if prec == "fp32" else 1
             tf = lens.sum() * bench.FLOP_PER_TOKEN_1B * nseg / dt / 1e12
             print(f"planes {planes} batch {qb:5d} {prec}: {dt * 1e3:8.1f} ms  ({int(lens.sum())} tokens, {tf:7.1f} TFLOP/s of bf16 MFMA work)", flush=True)
     del model
