@@ -72,12 +72,13 @@ int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int
  *                       the error class of an fp32 dot product (measured vs float64 like the exact
  *                       path), ~1.7x faster than fp32 MFMA; keeps three bf16 planes per segment.  */
 #define SR_PRECISION_BF16X6 2
-/*   SR_PRECISION_FP32_FILTERED  the SAME results as SR_PRECISION_FP32, bit for bit, ~3x faster for batches > 64
- *                       queries: the two-plane score picks ~2k candidates per query, a certificate (error bound
- *                       c|q|max|d| against the margin between the k-th and the last candidate) proves that they
- *                       contain the exact top-k, and only they are re-scored with the exact fp32 fmaf chain.  A
- *                       batch that cannot be certified is redone by the exact kernel.  Keeps two bf16 planes per
- *                       segment (same bytes as the fp32 rows); without room for them the exact kernel is used. */
+/*   SR_PRECISION_FP32_FILTERED  the SAME results as SR_PRECISION_FP32, bit for bit, several times faster for batches
+ *                       > 64 queries: a bf16 score (two planes of the query x one plane of the document) picks 3k
+ *                       candidates per query, only they are re-scored with the exact fp32 fmaf chain, and a
+ *                       certificate (every outsider's exact score <= its bf16 score + c|q|max|d| < the k-th exact
+ *                       score found) proves that the result is the exact top-k.  A batch that cannot be certified
+ *                       is redone by the exact kernel.  Keeps one bf16 plane per segment (half the bytes of the
+ *                       fp32 rows); without room for it the exact kernel is used.                            */
 #define SR_PRECISION_FP32_FILTERED 3
 int sr_dense_index_set_precision(sr_dense_index* idx, int mode);
 /* searches of more than 64 queries answered through the filter / redone by the exact kernel so far */

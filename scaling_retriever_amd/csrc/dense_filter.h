@@ -10,19 +10,20 @@ struct FilterSegs {                 // where a global doc index lives: row = (gi
     int count;
 };
 
-// |S_a - S_x| <= sr_filter_c(H) * |q| * |d| for the two-plane (bf16x3) score S_a against the fp32 fmaf chain S_x
+// |S_a - S_x| <= sr_filter_c(H) * |q| * |d| for the filter's score S_a = (q0 + q1) . d0 against the fp32 fmaf chain S_x
 double sr_filter_c(int H);
 // *d_max2 = max(*d_max2, max over rows of |row|^2)   (non-negative floats order as their bit patterns)
 int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s);
 // qnorm[q] = |Q[q]|
 int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStream_t s);
 // Candidates = the kp best approximate scores per query, sorted descending (a_scores / a_ids [nq, kp], pads id < 0).
-// Certifies that they contain the exact top-k (flags[q] = 0) and rescoring keys go to cand_keys [nq, cand_cap]:
-//   exact score = fp32 fmaf chain in the k order of dense_score_pipe_kernel, key = (score desc, doc index asc).
-// flags[q] != 0: not certified (too many approximate scores inside the error margin of the k-th one), or a candidate's
-// two scores differ by more than the bound - the caller falls back to the exact kernel.
-int launch_filter_certify(const float* a_scores, const float* qnorm, const float* d_max2, int64_t nq, int k, int kp, double c,
-                          int* flags, hipStream_t s);
+// launch_filter_rescore: exact score of every candidate = fp32 fmaf chain in the k order of dense_score_pipe_kernel, key =
+// (score desc, doc index asc) into cand_keys [nq, cand_cap]; flags[q] |= 2 if a candidate's two scores differ by more than
+// the bound.  launch_filter_certify (after the exact top-k x_scores [nq, k] is known): flags[q] |= 1 unless every document
+// outside the candidates is provably below the k-th exact score.  flags must be zeroed first; non-zero -> the caller falls
+// back to the exact kernel.
+int launch_filter_certify(const float* a_scores, const float* x_scores, const float* qnorm, const float* d_max2, int64_t nq, int k,
+                          int kp, double c, int* flags, hipStream_t s);
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
                           const float* d_max2, int64_t nq, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
                           int64_t cand_cap, int* flags, hipStream_t s);

@@ -1,34 +1,35 @@
-// Exact dense top-k at split-bf16 speed: a certified filter in front of an exact re-score (gfx950).
+// Exact dense top-k at bf16 speed: a certified filter in front of an exact re-score (gfx950).
 //
 // sr_dense_search must return what faiss.IndexFlatIP.search returns (scaling_retriever/indexer.py:210-214): the k largest
 // fp32 inner products.  dense_score_pipe_kernel computes every one of the nq x N products on the fp32 MFMA pipe (157 TF
-// peak).  The bf16 MFMA pipe is 16x faster, and the two-plane split score S_a = q0.d0 + q0.d1 + q1.d0 (dense_split.hip)
-// differs from the fp32 chain S_x by a PROVABLY small amount, so it can decide which few documents need the exact
-// arithmetic at all:
+// peak).  The bf16 MFMA pipe is 16x faster, and the score S_a = (q0 + q1) . d0 - two bf16 planes of the query against ONE
+// bf16 plane of the document, 2 plane products (dense_split.hip) - differs from the fp32 chain S_x by a PROVABLY bounded
+// amount, so it can decide which few documents need the exact arithmetic at all:
 //
-//   1. approximate pass: the kp = ~2k best documents by S_a per query (dense_split_kernel + the fused top-k, unchanged);
-//   2. certificate: with E = c |q| max|d| >= |S_a - S_x| for every document, a document whose S_a is below a_k - 2E
-//      (a_k = k-th best S_a) has k documents strictly above it in S_x, so it is not in the exact top-k; if the kp-th best
-//      S_a is itself below a_k - 2E, the kp candidates CONTAIN the exact top-k;
-//   3. exact pass: S_x for the kp candidates only - the same fp32 fmaf chain, in the same k order, as
-//      dense_score_pipe_kernel (oracle: scoring.mfma_korder) - then the top-k by (S_x desc, doc index asc).
-// The result is bit-identical to the exact kernel's (tests/test_dense_filtered_gpu.py).  A query whose certificate fails
-// (more than kp - k approximate scores inside the margin: near-duplicate documents, a zero query) or for which any
-// candidate's |S_a - S_x| exceeds E (the bound is checked on every pair that is re-scored) makes sr_dense_search redo the
-// batch with the exact kernel - correctness never rests on the filter.
+//   1. approximate pass: the kp = 3k best documents by S_a per query (dense_split_kernel + the fused top-k, unchanged);
+//   2. exact pass: S_x for those kp candidates only - the same fp32 fmaf chain, in the same k order, as
+//      dense_score_pipe_kernel (oracle: scoring.mfma_korder) - then the top-k by (S_x desc, doc index asc);
+//   3. certificate: with E = c |q| max|d| >= |S_a - S_x| for every document, a document that is NOT a candidate has
+//      S_x <= S_a + E <= a_kp + E (a_kp = the kp-th best S_a).  If a_kp + E is strictly below the k-th best exact score
+//      found among the candidates, no outsider can enter the top-k or tie with its last member: the result IS the exact
+//      top-k.
+// The result is bit-identical to the exact kernel's (tests/test_dense_filtered_gpu.py, and every bench.py run on the whole
+// problem).  A query whose certificate fails (more than kp - k documents inside the margin: near-duplicates, a zero query)
+// or for which any candidate's |S_a - S_x| exceeds E (the bound is checked on every pair that is re-scored) makes
+// sr_dense_search redo the batch with the exact kernel - correctness never rests on the filter.
 //
-// The bound.  B = sum |q_i||d_i| <= |q||d|.
-//   fp32 chain of H fmaf:                |S_x - q.d| <= gamma_H B,    gamma_n = n u / (1 - n u), u = 2^-24
-//   planes: x0 = bf16(x), x1 = bf16(x - x0): |x - x0 - x1| <= 2^-18 |x|, |x1| <= 2^-9 |x| (1 + 2^-9)
-//     dropped q1.d1 + (q - q0 - q1).d + (q0 + q1).(d - d0 - d1):       <= 3.02 * 2^-18 B
-//   3H bf16 products (exact in fp32) summed in fp32 by the MFMA, 32 per instruction, modelled as no better than a plain
-//     fp32 summation of 3H terms:                                      <= gamma_3H * 1.008 B
-//   c(H) = 1.25 * (4 H 2^-24) + 1.5e-5   (6.3e-4 at H = 2048, 1.24e-3 at 4096) covers the sum with 25 % to spare;
-//   measured max |S_a - S_x| / (|q||d|) is 1e-6.
+// The bound.  B = sum |q_i||d_i| <= |q||d|;  u = 2^-24, gamma_n = n u / (1 - n u).
+//   fp32 chain of H fmaf:                          |S_x - q.d| <= gamma_H B
+//   planes: x0 = bf16(x): |x - x0| <= 2^-9 |x|;  x1 = bf16(x - x0): |x - x0 - x1| <= 2^-18 |x|
+//     q.d - (q0 + q1).d0 = q.(d - d0) + (q - q0 - q1).d0:      <= (2^-9 + 2^-18 (1 + 2^-9)) B
+//   2H bf16 products (exact in fp32) summed in fp32 by the MFMA, 32 per instruction, modelled as no better than a plain
+//     fp32 summation of 2H terms:                                <= gamma_2H * 1.004 B
+//   c(H) = 2^-9 * 1.004 + 1.25 * (3 H 2^-24) + 1e-5   (2.43e-3 at H = 2048, 2.89e-3 at 4096) covers the sum with room to
+//   spare; the measured maximum is ~1e-3 (the 2^-9 plane truncation dominates).
 #include "dense_filter.h"
 #include <math.h>
 
-double sr_filter_c(int H) { return 1.25 * (4.0 * (double)H * ldexp(1.0, -24)) + 1.5e-5; }
+double sr_filter_c(int H) { return ldexp(1.0, -9) * 1.004 + 1.25 * (3.0 * (double)H * ldexp(1.0, -24)) + 1.0e-5; }
 
 __global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ rows, int64_t n, int H, float* __restrict__ d_max2) {
     const int lane = threadIdx.x & 63;
@@ -76,24 +77,25 @@ int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStrea
     return SR_OK;
 }
 
-__global__ void filter_certify_kernel(const float* __restrict__ a_scores, const float* __restrict__ qnorm,
-                                      const float* __restrict__ d_max2, int64_t nq, int k, int kp, double c, int* __restrict__ flags) {
+__global__ void filter_certify_kernel(const float* __restrict__ a_scores, const float* __restrict__ x_scores,
+                                      const float* __restrict__ qnorm, const float* __restrict__ d_max2, int64_t nq, int k, int kp,
+                                      double c, int* __restrict__ flags) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
-    const double ak = (double)a_scores[q * kp + (k - 1)];      // -FLT_MAX pads when fewer than k documents exist
-    const double akp = (double)a_scores[q * kp + (kp - 1)];
-    // fewer than kp documents: every document is a candidate.  Otherwise the kp-th approximate score must be clear of
-    // the margin.  NaN / inf anywhere -> not certified.
+    const double akp = (double)a_scores[q * kp + (kp - 1)];   // kp-th best approximate score; -FLT_MAX pad when fewer documents exist
+    const double xk = (double)x_scores[q * k + (k - 1)];      // k-th best EXACT score among the candidates (pad when fewer than k)
+    // fewer than kp documents: every document was re-scored.  Otherwise every outsider's exact score is <= akp + E, which
+    // must stay strictly below the k-th exact score.  NaN / inf anywhere -> not certified.
     const bool all_docs = akp <= -3.0e38;
-    const bool ok = all_docs || (E < INFINITY && ak > -3.0e38 && akp < ak - 2.0 * E);
-    flags[q] = ok ? 0 : 1;
+    const bool ok = all_docs || (E < INFINITY && xk > -3.0e38 && akp + E < xk);
+    if (!ok) atomicOr(&flags[q], 1);
 }
 
-int launch_filter_certify(const float* a_scores, const float* qnorm, const float* d_max2, int64_t nq, int k, int kp, double c,
-                          int* flags, hipStream_t s) {
-    hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, a_scores, qnorm, d_max2, nq, k,
-                       kp, c, flags);
+int launch_filter_certify(const float* a_scores, const float* x_scores, const float* qnorm, const float* d_max2, int64_t nq, int k,
+                          int kp, double c, int* flags, hipStream_t s) {
+    hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, a_scores, x_scores, qnorm, d_max2,
+                       nq, k, kp, c, flags);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

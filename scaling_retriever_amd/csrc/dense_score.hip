@@ -404,9 +404,11 @@ struct sr_dense_index {
     int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter / redone by the exact kernel
 };
 
+// bf16 planes of every segment a precision needs (the certified filter scores against plane 0 only)
 static int planes_of(int precision) {
-    return precision == SR_PRECISION_BF16X6 ? 3 : ((precision == SR_PRECISION_BF16X3 || precision == SR_PRECISION_FP32_FILTERED) ? 2 : 0);
+    return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : (precision == SR_PRECISION_FP32_FILTERED ? 1 : 0));
 }
+#define SR_PASS_FILTER 100   // dense_search_pass: the filter's 2-product pass, (q0 + q1) . d0
 
 static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
     if (seg.n_planes >= want) return SR_OK;
@@ -421,7 +423,7 @@ static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
         }
     }
     // (re)compute all planes: cheap next to one search, and keeps the planes consistent
-    SR_TRY(launch_split_bf16(seg.rows, seg.pl[0], seg.pl[1], want == 3 ? seg.pl[2] : nullptr, seg.n * (int64_t)idx->dim, nullptr));
+    SR_TRY(launch_split_bf16(seg.rows, seg.pl[0], want >= 2 ? seg.pl[1] : nullptr, want == 3 ? seg.pl[2] : nullptr, seg.n * (int64_t)idx->dim, nullptr));
     SR_CHECK_HIP(hipStreamSynchronize(nullptr));
     seg.n_planes = want;
     return SR_OK;
@@ -542,9 +544,9 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if (planes_of(precision) && nq > 64) {
-        // fp32-class scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
-        const int np = planes_of(precision);
+    if ((planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64) {
+        // scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
+        const int np = precision == SR_PASS_FILTER ? 1 : planes_of(precision);
         if (idx->q_cap < nq) {
             for (int p = 0; p < 3; ++p) {
                 if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
@@ -567,7 +569,11 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                 step = step * 2 < chunk ? step * 2 : chunk;
                 DenseSplitArgs a;
                 for (int p = 0; p < 3; ++p) { a.D[p] = seg.pl[p]; a.Q[p] = idx->qpl[p]; }
-                if (np == 2) {            // (d plane, q plane), smallest products first
+                if (np == 1) {            // the certified filter: one doc plane against two query planes
+                    a.n_pairs = 2;
+                    a.pair_d[0] = 0; a.pair_q[0] = 1;
+                    a.pair_d[1] = 0; a.pair_q[1] = 0;
+                } else if (np == 2) {     // (d plane, q plane), smallest products first
                     a.n_pairs = 3;
                     const int pd[3] = {1, 0, 0}, pq[3] = {0, 1, 0};
                     for (int i = 0; i < 3; ++i) { a.pair_d[i] = pd[i]; a.pair_q[i] = pq[i]; }
@@ -676,11 +682,11 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
 static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
                                  int64_t* d_out_ids, hipStream_t s, bool* done) {
     *done = false;
-    int kp = 2 * k > k + 1048 ? 2 * k : k + 1048;            // candidates per query: k = 1000 -> 2048
+    int kp = 3 * k > k + 2048 ? 3 * k : k + 2048;            // candidates per query: k = 1000 -> 3072
     if (kp > SR_MAX_TOPK) kp = SR_MAX_TOPK;
     if (nq <= 64 || kp < k + 64 || idx->dim % 64 != 0 || (int)idx->segs.size() > SR_FILTER_MAX_SEGS) return SR_OK;
     for (const DenseSegment& seg : idx->segs)
-        if (seg.n_planes < 2) return SR_OK;                   // planes could not be allocated: exact kernel
+        if (seg.n_planes < 1) return SR_OK;                   // the plane could not be allocated: exact kernel
     if (!idx->d_max2) {
         SR_CHECK_HIP(hipMalloc((void**)&idx->d_max2, 4));
         SR_CHECK_HIP(hipMemsetAsync(idx->d_max2, 0, 4, s));
@@ -705,10 +711,10 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
     }
     const double c = sr_filter_c(idx->dim);
     SR_TRY(launch_query_norms(d_queries, nq, idx->dim, idx->qnorm, s));
-    // 1. the kp best documents by the two-plane score
-    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PRECISION_BF16X3, s));
-    // 2. certificate, 3. exact scores of the candidates -> exact top-k
-    SR_TRY(launch_filter_certify(idx->a_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
+    SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
+    // 1. the kp best documents by S_a = (q0 + q1) . d0
+    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s));
+    // 2. exact scores of the candidates -> exact top-k
     SR_TRY(idx->ws2.ensure(nq, k, kp));
     SR_TRY(topk_reset(idx->ws2, nq, s));
     FilterSegs fs;
@@ -721,6 +727,8 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
                                  idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
     SR_TRY(topk_compact(idx->ws2, nq, k, s));
     SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    // 3. certificate against the k-th exact score
+    SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
     // any query not certified -> the whole batch goes through the exact kernel (one small D2H per search)
     std::vector<int> h((size_t)nq);
     SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
