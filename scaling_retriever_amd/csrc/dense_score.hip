@@ -539,7 +539,9 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     int64_t g = 256, t = qtiles;
     while (t) { const int64_t r = g % t; g = t; t = r; }     // g = gcd(256, qtiles)
     const int64_t unit = 256 / g;
-    int64_t chunk = TM * unit * ceil_div64(2048, unit * qtiles);
+    const char* env_wgs = sr_dev_getenv("SR_DENSE_LAUNCH_WGS");      // A/B switch: workgroups per launch (default 2048)
+    const int64_t launch_wgs = env_wgs ? atoll(env_wgs) : 2048;
+    int64_t chunk = TM * unit * ceil_div64(launch_wgs, unit * qtiles);
     int64_t max_cap = idx->ws_limit / (8 * nq);
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
