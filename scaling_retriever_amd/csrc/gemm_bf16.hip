@@ -655,6 +655,17 @@ static int plan_big_rows(const GemmArgs& g, bool small_allowed) {
 
 template <int EPI>
 static int launch_big(const GemmArgs& g, hipStream_t s) {
+    if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_QKV_ROPE) {
+        // A/B switch: SR_GEMM_BIG=s3 -> 256 x 128 tile, 8 waves, THREE 48 KB LDS stages (LDS-DMA issued three k-steps ahead)
+        const char* big = sr_dev_getenv("SR_GEMM_BIG");
+        if (big && big[0] == 's' && big[1] == '3' && g.K / G_BK >= 4) {
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                if (g.head_dim == 64) return launch_cfg<EPI, 2, 4, 8, 2, true, 3>(g, s);
+            } else {
+                return launch_cfg<EPI, 2, 4, 8, 2, true, 3>(g, s);
+            }
+        }
+    }
     const char* env = sr_dev_getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
     if (g.K / G_BK >= 4 && !(env && *env == '0')) return launch_cfg<EPI, 2, 4, 8, 4, true>(g, s);
     return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);
