@@ -13,9 +13,13 @@
 // them and an unfused multiply-add, so every per-doc sum is bit-identical to the
 // reference's term-serial fp32 accumulation.
 #include "common.h"
+#include <algorithm>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #define SP_TILE 8192
+#define SP_SUB 4096     // skip-table granularity (the query-block kernel's tile); SP_TILE is a multiple of it
 #define SP_TERMS 64   // query terms staged per batch (one wave builds the batch's work list)
 #define SP_U 4        // postings per thread and group
 #define SP_GROUP (SP_U * 256)                              // postings per group
@@ -30,7 +34,7 @@ struct SparseArgs {
     const int64_t* indptr;
     const int32_t* doc_ids;
     const float* vals;
-    const int32_t* skip;  // [n_terms, n_tiles + 1] offsets relative to indptr[t]
+    const int32_t* skip;  // [n_terms, n_tiles * (SP_TILE / SP_SUB) + 1] offsets relative to indptr[t], one per SP_SUB docs
     int n_tiles;
     int64_t n_docs;
     int64_t n_terms;
@@ -45,6 +49,7 @@ struct SparseArgs {
     int* cand_count;
     int64_t cand_cap;
     uint32_t id_base, id_stride;
+    const uint8_t* blk_done;   // optional: blocks of 4 queries the query-block kernel handles (skipped here)
 };
 
 // The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term.  The run of
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
     const int lane = tid & 63;
     const int ql = blockIdx.x;                 // query within batch
     const int64_t q = a.q_base + ql;
+    if (a.blk_done && a.blk_done[q >> 2]) return;
     const int tile = a.tile_begin + blockIdx.y;
     const int64_t doc0 = (int64_t)tile * SP_TILE;
     const int n_here = (int)((a.n_docs - doc0) < SP_TILE ? (a.n_docs - doc0) : SP_TILE);
@@ -92,8 +98,8 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
             // an empty array for every vocabulary id, indexer.py:364-370)
             const int term = a.q_cols[t0 + lane];
             const bool known = term >= 0 && (int64_t)term < a.n_terms;
-            const int32_t* sk = a.skip + (int64_t)(known ? term : 0) * (a.n_tiles + 1) + tile;
-            const int b = sk[0], e = sk[1];
+            const int32_t* sk = a.skip + (int64_t)(known ? term : 0) * (a.n_tiles * (SP_TILE / SP_SUB) + 1) + tile * (SP_TILE / SP_SUB);
+            const int b = sk[0], e = sk[SP_TILE / SP_SUB];
             seg_n = known ? e - b : 0;
             seg_b = a.indptr[known ? term : 0] + b;
             seg_w = a.q_vals[t0 + lane];
@@ -247,15 +253,401 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
     }
 }
 
+// ---- query-block kernel: 4 queries per workgroup, heavy terms as dense columns in registers ----------------------------
+// What bounds sparse_score_kernel is one LDS read-modify-write and 8 B of loads per posting, and two thirds of the postings a
+// query touches belong to a handful of terms that occur in more than half of all docs.  Those terms are ALSO stored as dense
+// columns (value per doc, 0 where the doc lacks the term: 4 B per doc, no doc ids), and a workgroup of 4 waves owns
+// (4 consecutive queries, sub-tile of SPB_TILE docs); two workgroups share a CU.  A run of consecutive dense terms is applied
+// in REGISTERS - thread t owns 16 docs of each query's slice - from coalesced 16-byte column loads that serve all 4 queries.
+// The other terms go through the LDS scatter, wave q walking query q's terms on slice q: no barrier between terms at all,
+// because the LDS operations of ONE wave execute in program order (term t's writes precede term t + 1's reads) and a slice is
+// touched by one wave only.  The slices move registers <-> LDS (with a workgroup barrier) only where the term order switches
+// between the two kinds.  Exactness: the plan lists the union of the 4 queries' terms in ascending term id with a weight per
+// query (0 = the query lacks the term = skipped), which is each query's own term order when its terms ascend strictly (the plan
+// kernel checks; other blocks go to sparse_score_kernel); s + w * 0 == s, so a dense column's zeros change nothing; products and
+// sums are unfused.  Per-doc sums are therefore the reference's term-serial fp32 sums, bit for bit.
+#define SPB_Q 4
+#define SPB_THREADS 256
+#define SPB_TILE SP_SUB
+#ifndef SPB_U
+#define SPB_U 4       // postings per lane and group
+#endif
+#ifndef SPB_RING
+#define SPB_RING 6    // register sets of a wave's group walk: SPB_RING - 1 groups of loads in flight per wave
+#endif
+#define SPB_GROUP (SPB_U * 64)                       // postings per wave and group
+#define SPB_TSTRIDE (SPB_TILE + 64)
+#define SPB_XCD 8
+#define SPB_DESC 256
+#ifndef SPB_SUBS
+#define SPB_SUBS 1     // consecutive sub-tiles per workgroup: the plan fetch and the launch cost amortise, the next sub-tile's
+#endif                 // runs are looked up while this one is scored
+#define SPB_DV (SPB_TILE / (4 * SPB_THREADS))        // float4 column loads per thread and dense term (4)
+
+struct SparseBlockArgs {
+    SparseArgs a;
+    const float* dense;          // [n_dense][dense_stride]
+    const int32_t* dense_slot;   // [n_terms]: column of a dense term, -1 otherwise
+    int64_t dense_stride;        // n_tiles * SP_TILE
+    const int32_t* plan_term;    // union term lists, block b at q_indptr[4 b] - nnz_base
+    const float* plan_w;         // [.][SPB_Q]
+    const int32_t* plan_n;       // entries of block b
+    const uint8_t* plan_ok;      // 0: block goes to sparse_score_kernel
+    int64_t nnz_base;
+    int64_t q_end;               // one past the last query of this batch
+    int n_sub;                   // sub-tiles of this launch
+    int xcd;                     // XCD-aware block order
+    int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): 1 = skip the scatter runs, 2 = skip the dense runs
+};
+
+__global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockArgs b) {
+#pragma clang fp contract(off)
+    extern __shared__ float sc[];              // [SPB_Q][SPB_TSTRIDE]: score slices + one dummy slot per lane
+    __shared__ int wave_tot[SPB_Q][SPB_THREADS / 64];
+    __shared__ int s_base[SPB_Q];
+    __shared__ int desc_all[SPB_THREADS / 64][SPB_DESC];    // per wave: (term lane << 8 | group) of the scatter walk
+    const SparseArgs& a = b.a;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // workgroups are dealt to the 8 XCDs round-robin in launch order: blockIdx.x % 8 picks the sub-tile group, so that all the
+    // query blocks of one sub-tile run on ONE XCD and its posting runs are fetched into one L2 only
+    const int bx = b.xcd ? (int)(blockIdx.x / SPB_XCD) : (int)blockIdx.x;
+    const int by = b.xcd ? (int)(blockIdx.y * SPB_XCD + blockIdx.x % SPB_XCD) : (int)blockIdx.y;
+    const int64_t q0 = a.q_base + (int64_t)bx * SPB_Q;
+    const int64_t gblk = q0 / SPB_Q;
+    if (!b.plan_ok[gblk]) return;
+    const int64_t pe0 = a.q_indptr[q0] - b.nnz_base;
+    const int ne = b.plan_n[gblk];
+    const int skip_stride = a.n_tiles * (SP_TILE / SP_SUB) + 1;
+    const float thr = a.threshold;
+    const int nqs = (int)((b.q_end - q0) < SPB_Q ? (b.q_end - q0) : SPB_Q);
+    const int ql0 = (int)(q0 - a.q_base);
+    float tq[SPB_Q];
+#pragma unroll
+    for (int qi = 0; qi < SPB_Q; ++qi) tq[qi] = qi < nqs ? a.tau[ql0 + qi] : 0.f;
+    float* const my_slice = sc + wave * SPB_TSTRIDE;           // scatter phase: wave q owns slice q
+
+    // lane j: plan entry j of a batch of 64 (every wave holds the same entries); the next batch's entries - of this sub-tile
+    // or the first of the next one - are fetched while this one is applied
+    struct Ent { int64_t seg_b; int seg_n, slot; f32x4 w; };
+    auto fetch = [&](int sub, int e0) -> Ent {
+        Ent en;
+        en.seg_b = 0; en.seg_n = 0; en.slot = -1; en.w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e0 + lane < ne) {
+            const int term = b.plan_term[pe0 + e0 + lane];     // known terms only (plan kernel)
+            en.slot = b.dense_slot[term];
+            en.w = *reinterpret_cast<const f32x4*>(b.plan_w + (pe0 + e0 + lane) * SPB_Q);
+            const int32_t* sk = a.skip + (int64_t)term * skip_stride + sub;
+            const int sb = sk[0], se = sk[1];
+            en.seg_n = se - sb;
+            en.seg_b = a.indptr[term] + sb;
+        }
+        return en;
+    };
+    // SPB_SUBS consecutive sub-tiles of SPB_TILE docs per workgroup
+    const int sub_first = a.tile_begin * (SP_TILE / SPB_TILE) + by * SPB_SUBS;
+    int sub_end = a.tile_begin * (SP_TILE / SPB_TILE) + b.n_sub;
+    if (sub_first + SPB_SUBS < sub_end) sub_end = sub_first + SPB_SUBS;
+    if ((int64_t)(sub_end - 1) * SPB_TILE >= a.n_docs) sub_end = (int)((a.n_docs + SPB_TILE - 1) / SPB_TILE);
+    if (sub_first >= sub_end) return;
+    Ent nxt = fetch(sub_first, 0);
+  for (int sub = sub_first; sub < sub_end; ++sub) {
+    const int64_t doc0 = (int64_t)sub * SPB_TILE;
+    const int n_here = (int)((a.n_docs - doc0) < SPB_TILE ? (a.n_docs - doc0) : SPB_TILE);
+
+    // thread t owns docs 4 t + 1024 i + e (i < SPB_DV, e < 4) of every query while the slices are in registers
+    f32x4 acc[SPB_Q][SPB_DV];
+#pragma unroll
+    for (int q = 0; q < SPB_Q; ++q)
+#pragma unroll
+        for (int i = 0; i < SPB_DV; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool in_regs = true;
+    const float* dcol = b.dense + doc0 + 4 * tid;
+    auto to_lds = [&]() {
+#pragma unroll
+        for (int q = 0; q < SPB_Q; ++q)
+#pragma unroll
+            for (int i = 0; i < SPB_DV; ++i)
+                *reinterpret_cast<f32x4*>(sc + q * SPB_TSTRIDE + 4 * SPB_THREADS * i + 4 * tid) = acc[q][i];
+        __syncthreads();
+    };
+    auto to_regs = [&]() {
+        __syncthreads();         // every wave is through with its slice
+#pragma unroll
+        for (int q = 0; q < SPB_Q; ++q)
+#pragma unroll
+            for (int i = 0; i < SPB_DV; ++i)
+                acc[q][i] = *reinterpret_cast<const f32x4*>(sc + q * SPB_TSTRIDE + 4 * SPB_THREADS * i + 4 * tid);
+    };
+
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        const Ent en = nxt;
+        if (e0 + 64 < ne) nxt = fetch(sub, e0 + 64);
+        else if (sub + 1 < sub_end) nxt = fetch(sub + 1, 0);
+        const int64_t seg_b = en.seg_b;
+        const int seg_n = en.seg_n, slot = en.slot;
+        const f32x4 seg_w = en.w;
+        const float my_w = wave == 0 ? seg_w[0] : wave == 1 ? seg_w[1] : wave == 2 ? seg_w[2] : seg_w[3];
+        const uint64_t dmask = __ballot(slot >= 0 && seg_n > 0);
+        const uint64_t smask = __ballot(slot < 0 && seg_n > 0);
+        uint64_t rem = dmask | smask;
+        while (rem) {
+            const int j_first = __builtin_ctzll(rem);
+            const bool dense_run = (dmask >> j_first) & 1;
+            const uint64_t other = (dense_run ? smask : dmask) & rem;           // all above j_first
+            const uint64_t below = other ? ((1ull << __builtin_ctzll(other)) - 1ull) : ~0ull;
+            uint64_t run = (dense_run ? dmask : smask) & rem & below;
+            rem &= ~run;
+            if (b.diag & (dense_run ? 2 : 1)) continue;
+            if (dense_run) {
+                if (!in_regs) { to_regs(); in_regs = true; }
+                // two register sets: the next term's column loads fly while this one is applied (always issued: past the
+                // run's end they re-read the last term)
+                auto dload = [&](int j, f32x4 (&v)[SPB_DV]) {
+                    const float* p = dcol + (int64_t)__builtin_amdgcn_readlane(slot, j) * b.dense_stride;
+#pragma unroll
+                    for (int i = 0; i < SPB_DV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * SPB_THREADS * i);
+                };
+                auto dapply = [&](int j, const f32x4 (&v)[SPB_DV]) {
+#pragma unroll
+                    for (int q = 0; q < SPB_Q; ++q) {
+                        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(seg_w[q]), j));
+                        if (w != 0.f) {              // wave-uniform
+#pragma unroll
+                            for (int i = 0; i < SPB_DV; ++i) {
+                                const f32x4 prod = v[i] * w;
+                                acc[q][i] = acc[q][i] + prod;
+                            }
+                        }
+                    }
+                };
+                f32x4 vA[SPB_DV], vB[SPB_DV];
+                int jA = __builtin_ctzll(run);
+                run &= run - 1;
+                dload(jA, vA);
+                for (;;) {
+                    const bool moreB = run != 0;
+                    const int jB = moreB ? __builtin_ctzll(run) : jA;
+                    run &= run - 1;
+                    dload(jB, vB);
+                    dapply(jA, vA);
+                    if (!moreB) break;
+                    const bool moreA = run != 0;
+                    jA = moreA ? __builtin_ctzll(run) : jB;
+                    run &= run - 1;
+                    dload(jA, vA);
+                    dapply(jB, vB);
+                    if (!moreA) break;
+                }
+            } else {
+                if (in_regs) { to_lds(); in_regs = false; }
+                // This wave's query.  Its terms' runs are cut into groups of SPB_GROUP postings; the (term, group) pairs are
+                // flattened into per-lane descriptors (lane l = l-th group of the run: first posting, postings left, weight),
+                // so that the walk itself is a counted loop over lanes - no per-term cursor, no branches on run lengths:
+                // per group 3 v_readlane, SPB_U clamped load pairs (always issued, SPB_RING - 1 groups in flight) and
+                // SPB_U LDS read-modify-writes; lanes beyond a run's end use their dummy slot.  No barriers: one wave, one slice.
+                const bool has = ((run >> lane) & 1) && my_w != 0.f;
+                const int ngr = has ? (seg_n + SPB_GROUP - 1) / SPB_GROUP : 0;
+                int incl_g = ngr;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl_g, off);
+                    if (lane >= off) incl_g += o;
+                }
+                const int off_j = incl_g - ngr;
+                const int G = __builtin_amdgcn_readlane(incl_g, 63);
+                int* const desc = desc_all[wave];
+                for (int c0 = 0; c0 < G; c0 += SPB_DESC) {
+                    for (int i = 0; i < ngr; ++i) {
+                        const int pos = off_j + i - c0;
+                        if (pos >= 0 && pos < SPB_DESC) desc[pos] = (lane << 8) | i;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int Gc = (G - c0) < SPB_DESC ? (G - c0) : SPB_DESC;
+                    for (int g0 = 0; g0 < Gc; g0 += 64) {
+                        const int ng = (Gc - g0) < 64 ? (Gc - g0) : 64;
+                        const int e = lane < ng ? desc[g0 + lane] : 0;
+                        const int j = e >> 8, gi = e & 255;
+                        const int n_j = __shfl(seg_n, j);
+                        const int64_t fb = (((int64_t)__shfl((int)(seg_b >> 32), j) << 32) | (uint32_t)__shfl((int)(seg_b & 0xffffffffll), j)) +
+                                           (int64_t)gi * SPB_GROUP;
+                        const float w_l = __shfl(my_w, j);
+                        const int left_l = n_j - gi * SPB_GROUP;
+                        auto gload = [&](int l, int (&dd)[SPB_U], float (&vv)[SPB_U]) {
+                            const int64_t sb = readlane64(fb, l);
+                            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane(left_l, l) - 1u;
+                            const int32_t* ib = a.doc_ids + sb;
+                            const float* vb = a.vals + sb;
+#pragma unroll
+                            for (int u = 0; u < SPB_U; ++u) {
+                                const uint32_t pp = (uint32_t)lane + 64u * u;
+                                const uint32_t pc = pp < last ? pp : last;
+                                dd[u] = ib[pc];
+                                vv[u] = vb[pc];
+                            }
+                            // compiler barrier: without it hipcc recognises the re-read of the last group past the end of the
+                            // walk, replaces those loads by copies of the earlier registers - and waits for them right there
+                            asm volatile("" ::: "memory");
+                        };
+                        auto gapply = [&](int l, const int (&dd)[SPB_U], const float (&vv)[SPB_U]) {
+                            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane(left_l, l);
+                            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_l), l));
+                            int d[SPB_U];
+                            float cur[SPB_U];
+#pragma unroll
+                            for (int u = 0; u < SPB_U; ++u) {
+                                d[u] = ((uint32_t)lane + 64u * u < lf) ? dd[u] - (int)doc0 : SPB_TILE + lane;
+                                cur[u] = my_slice[d[u]];
+                            }
+#pragma unroll
+                            for (int u = 0; u < SPB_U; ++u) {
+                                const float prod = w * vv[u];
+                                my_slice[d[u]] = cur[u] + prod;
+                            }
+                        };
+                        int dR[SPB_RING][SPB_U];
+                        float vR[SPB_RING][SPB_U];
+#pragma unroll
+                        for (int s2 = 0; s2 < SPB_RING - 1; ++s2) gload(s2 < ng ? s2 : ng - 1, dR[s2], vR[s2]);
+                        for (int l0 = 0; l0 < ng; l0 += SPB_RING) {
+#pragma unroll
+                            for (int s2 = 0; s2 < SPB_RING; ++s2) {
+                                const int ln = l0 + s2 + SPB_RING - 1;
+                                gload(ln < ng ? ln : ng - 1, dR[(s2 + SPB_RING - 1) % SPB_RING], vR[(s2 + SPB_RING - 1) % SPB_RING]);
+                                if (l0 + s2 >= ng) break;
+                                gapply(l0 + s2, dR[s2], vR[s2]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- filter the 4 slices, from registers: score > threshold and score >= tau ---------------
+    if (!in_regs) to_regs();
+    int cnt[SPB_Q];
+    int any = 0;
+#pragma unroll
+    for (int qi = 0; qi < SPB_Q; ++qi) {
+        cnt[qi] = 0;
+        if (qi < nqs) {
+#pragma unroll
+            for (int i = 0; i < SPB_DV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sv = acc[qi][i][e];
+                    cnt[qi] += (4 * SPB_THREADS * i + 4 * tid + e < n_here && sv > thr && sv >= tq[qi]) ? 1 : 0;
+                }
+        }
+        any |= cnt[qi];
+    }
+    if (__syncthreads_or(any)) {            // most (block, sub-tile) pairs keep nothing once tau has tightened
+        int incl[SPB_Q];
+#pragma unroll
+        for (int qi = 0; qi < SPB_Q; ++qi) {
+            incl[qi] = cnt[qi];
+            for (int off = 1; off < 64; off <<= 1) {
+                int o = __shfl_up(incl[qi], off);
+                if (lane >= off) incl[qi] += o;
+            }
+            if (lane == 63) wave_tot[qi][wave] = incl[qi];
+        }
+        __syncthreads();
+        if (tid < nqs) {
+            int total = 0;
+            for (int w = 0; w < SPB_THREADS / 64; ++w) total += wave_tot[tid][w];
+            s_base[tid] = total ? atomicAdd(&a.cand_count[ql0 + tid], total) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < SPB_Q; ++qi) {
+            if (qi >= nqs || cnt[qi] == 0) continue;
+            int wbase = 0;
+            for (int w = 0; w < wave; ++w) wbase += wave_tot[qi][w];
+            int pos = s_base[qi] + wbase + incl[qi] - cnt[qi];
+            uint64_t* dst = a.cand_keys + (int64_t)(ql0 + qi) * a.cand_cap;
+#pragma unroll
+            for (int i = 0; i < SPB_DV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sv = acc[qi][i][e];
+                    const int d = 4 * SPB_THREADS * i + 4 * tid + e;
+                    if (d < n_here && sv > thr && sv >= tq[qi]) {
+                        if (pos < a.cand_cap) dst[pos] = sr_make_key(sv, a.id_base + (uint32_t)(doc0 + d) * a.id_stride);
+                        ++pos;
+                    }
+                }
+        }
+    }
+    __syncthreads();       // the slices are re-used by the next sub-tile
+  }
+}
+
+// Plan of a block of SPB_Q queries: the union of their known terms in ascending term id, one weight per query (0 where the
+// query lacks the term).  ok = every query of the block lists its terms in strictly ascending id, i.e. the union's order is
+// each query's own accumulation order.  One thread per block.
+__global__ void sparse_block_plan_kernel(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_cols,
+                                         const float* __restrict__ q_vals, int64_t nq, int64_t n_terms,
+                                         int32_t* __restrict__ plan_term, float* __restrict__ plan_w,
+                                         int32_t* __restrict__ plan_n, uint8_t* __restrict__ plan_ok, int* __restrict__ any_bad) {
+    const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t q0 = blk * SPB_Q;
+    if (q0 >= nq) return;
+    const int64_t base = q_indptr[0];
+    int64_t p[SPB_Q], e[SPB_Q];
+    bool ok = true;
+    for (int i = 0; i < SPB_Q; ++i) {
+        if (q0 + i < nq) { p[i] = q_indptr[q0 + i]; e[i] = q_indptr[q0 + i + 1]; } else { p[i] = e[i] = 0; }
+        for (int64_t j = p[i] + 1; j < e[i]; ++j) ok = ok && q_cols[j] > q_cols[j - 1];
+    }
+    int n = 0;
+    if (ok) {
+        int64_t out = q_indptr[q0] - base;
+        for (;;) {
+            int64_t t = INT64_MAX;
+            for (int i = 0; i < SPB_Q; ++i)
+                if (p[i] < e[i] && (int64_t)q_cols[p[i]] < t) t = q_cols[p[i]];
+            if (t == INT64_MAX) break;
+            float w[SPB_Q];
+            for (int i = 0; i < SPB_Q; ++i) {
+                w[i] = 0.f;
+                if (p[i] < e[i] && (int64_t)q_cols[p[i]] == t) w[i] = q_vals[p[i]++];
+            }
+            if (t < 0 || t >= n_terms) continue;   // unknown term: empty posting list
+            plan_term[out + n] = (int32_t)t;
+            for (int i = 0; i < SPB_Q; ++i) plan_w[(out + n) * SPB_Q + i] = w[i];
+            ++n;
+        }
+    } else {
+        atomicOr(any_bad, 1);
+    }
+    plan_n[blk] = n;
+    plan_ok[blk] = ok ? 1 : 0;
+}
+
+// dense column of a heavy term: column[slot][doc] = value (the buffer is zero-filled first)
+__global__ void sparse_dense_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
+                                         const float* __restrict__ vals, const int32_t* __restrict__ slot_term,
+                                         int64_t stride, float* __restrict__ dense) {
+    const int slot = blockIdx.y;
+    const int64_t t = slot_term[slot];
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    float* col = dense + (int64_t)slot * stride;
+    for (int64_t pp = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pp < e; pp += (int64_t)gridDim.x * blockDim.x)
+        col[doc_ids[pp]] = vals[pp];
+}
+
 // ---- index build: skip table + validation -----------------------------------
-// skip[t][b] = number of postings of term t with doc id < b * SP_TILE  (lower bound)
+// skip[t][b] = number of postings of term t with doc id < b * SP_SUB  (lower bound); n_sub entries + 1 per term
 __global__ void sparse_skip_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
-                                   int64_t n_terms, int n_tiles, int32_t* __restrict__ skip) {
+                                   int64_t n_terms, int n_sub, int32_t* __restrict__ skip) {
     const int64_t t = blockIdx.x;
     const int64_t b = indptr[t], e = indptr[t + 1];
     const int64_t len = e - b;
+    const int n_tiles = n_sub;
     for (int tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x) {
-        const int64_t bound = (int64_t)tile * SP_TILE;
+        const int64_t bound = (int64_t)tile * SP_SUB;
         int64_t lo = 0, hi = len;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
@@ -288,6 +680,19 @@ struct sr_sparse_index {
     int64_t n_terms = 0, n_docs = 0;
     int n_tiles = 0;
     int32_t* skip = nullptr;
+    // heavy terms as dense columns (query-block kernel)
+    int n_dense = 0;
+    int64_t dense_stride = 0;
+    float* dense = nullptr;
+    int32_t* dense_slot = nullptr;
+    // per-call plan of the query blocks
+    int64_t plan_cap = 0, plan_blocks_cap = 0;
+    int32_t* plan_term = nullptr;
+    float* plan_w = nullptr;
+    int32_t* plan_n = nullptr;
+    uint8_t* plan_ok = nullptr;
+    int* plan_bad = nullptr;
+    int64_t n_block_calls = 0, n_fallback_calls = 0;
     int64_t ws_limit = 4ll << 30;
     TopkWS ws;
     StreamOrder order;
@@ -304,11 +709,90 @@ __global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, i
     const int64_t t = q_indptr[q_begin] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long n = 0;
     if (t < q_indptr[q_end] && q_cols[t] >= 0 && (int64_t)q_cols[t] < n_terms) {
-        const int32_t* sk = skip + (int64_t)q_cols[t] * (n_tiles + 1);
-        n = (unsigned long long)(sk[tile_begin + n_t] - sk[tile_begin]);
+        const int32_t* sk = skip + (int64_t)q_cols[t] * (n_tiles * (SP_TILE / SP_SUB) + 1);
+        n = (unsigned long long)(sk[(tile_begin + n_t) * (SP_TILE / SP_SUB)] - sk[tile_begin * (SP_TILE / SP_SUB)]);
     }
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+}
+
+static void sparse_free_device(sr_sparse_index* idx) {
+    void* ptrs[] = {idx->skip, idx->dense, idx->dense_slot, idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_bad};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->skip = nullptr;
+    idx->dense = nullptr;
+    idx->dense_slot = nullptr;
+    idx->plan_term = nullptr;
+    idx->plan_w = nullptr;
+    idx->plan_n = nullptr;
+    idx->plan_ok = nullptr;
+    idx->plan_bad = nullptr;
+}
+
+// Terms present in at least 1 / SP_DENSE_DIV of the docs get a dense column: the longest lists first, at most SP_DENSE_MAX of
+// them and never more than a quarter of the free device memory (a column costs 4 B per doc, the list it shadows 8 B per
+// posting, so above half the docs the column is also the smaller of the two).  No such term: the query-block kernel is not used.
+#define SP_DENSE_DIV 2
+#define SP_DENSE_MAX 64
+static int sparse_build_dense(sr_sparse_index* idx, hipStream_t s) {
+    int div = SP_DENSE_DIV, max_slots = SP_DENSE_MAX;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_DENSE_DIV")) div = atoi(e);
+    if (const char* e = sr_dev_getenv("SR_SPARSE_DENSE_MAX")) max_slots = atoi(e);
+    if (div <= 0 || max_slots <= 0) return SR_OK;
+    std::vector<int64_t> h_indptr((size_t)idx->n_terms + 1);
+    SR_CHECK_HIP(hipMemcpyAsync(h_indptr.data(), idx->indptr, sizeof(int64_t) * h_indptr.size(), hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<std::pair<int64_t, int32_t>> heavy;   // (-length, term)
+    for (int64_t t = 0; t < idx->n_terms; ++t) {
+        const int64_t len = h_indptr[(size_t)t + 1] - h_indptr[(size_t)t];
+        if (len > 0 && len * div >= idx->n_docs) heavy.emplace_back(-len, (int32_t)t);
+    }
+    if (heavy.empty()) return SR_OK;
+    std::sort(heavy.begin(), heavy.end());
+    const int64_t stride = (int64_t)idx->n_tiles * SP_TILE;
+    size_t free_b = 0, total_b = 0;
+    SR_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    int64_t fit = (int64_t)(free_b / 4) / (stride * 4);       // at most a quarter of what is free
+    int n = (int)heavy.size();
+    if (n > max_slots) n = max_slots;
+    if (n > fit) n = (int)fit;
+    if (n <= 0) return SR_OK;
+    std::vector<int32_t> h_slot((size_t)idx->n_terms, -1), h_terms((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        h_slot[(size_t)heavy[(size_t)i].second] = i;
+        h_terms[(size_t)i] = heavy[(size_t)i].second;
+    }
+    int32_t* d_terms = nullptr;
+    if (hipMalloc(&idx->dense, sizeof(float) * (size_t)stride * (size_t)n) != hipSuccess ||
+        hipMalloc(&idx->dense_slot, sizeof(int32_t) * (size_t)idx->n_terms) != hipSuccess ||
+        hipMalloc(&d_terms, sizeof(int32_t) * (size_t)n) != hipSuccess) {
+        (void)hipGetLastError();      // columns are an optimisation: without them the per-query kernel serves every block
+        if (idx->dense) (void)hipFree(idx->dense);
+        if (idx->dense_slot) (void)hipFree(idx->dense_slot);
+        if (d_terms) (void)hipFree(d_terms);
+        idx->dense = nullptr;
+        idx->dense_slot = nullptr;
+        return SR_OK;
+    }
+    int rc = SR_OK;
+    if (hipMemsetAsync(idx->dense, 0, sizeof(float) * (size_t)stride * (size_t)n, s) != hipSuccess ||
+        hipMemcpyAsync(idx->dense_slot, h_slot.data(), sizeof(int32_t) * h_slot.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_terms, h_terms.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess) {
+        rc = SR_ERR_HIP;
+    } else {
+        hipLaunchKernelGGL(sparse_dense_fill_kernel, dim3(256, (unsigned)n), dim3(256), 0, s, idx->indptr, idx->doc_ids, idx->vals,
+                           d_terms, stride, idx->dense);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = SR_ERR_HIP;
+    }
+    (void)hipFree(d_terms);
+    if (rc != SR_OK) {
+        sr_set_error("sr_sparse_index_create: building the dense columns failed: %s", hipGetErrorString(hipGetLastError()));
+        return rc;
+    }
+    idx->n_dense = n;
+    idx->dense_stride = stride;
+    return SR_OK;
 }
 
 extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_indptr, const int32_t* d_doc_ids,
@@ -329,7 +813,8 @@ extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_in
     int h_flags = 0;
     int rc = SR_OK;
     do {
-        if (hipMalloc(&idx->skip, sizeof(int32_t) * (size_t)n_terms * (size_t)(idx->n_tiles + 1)) != hipSuccess ||
+        const int n_sub = idx->n_tiles * (SP_TILE / SP_SUB);
+        if (hipMalloc(&idx->skip, sizeof(int32_t) * (size_t)n_terms * (size_t)(n_sub + 1)) != hipSuccess ||
             hipMalloc(&d_flags, sizeof(int)) != hipSuccess) {
             sr_set_error("sr_sparse_index_create: out of device memory for the skip table (%lld x %d)",
                          (long long)n_terms, idx->n_tiles + 1);
@@ -340,7 +825,7 @@ extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_in
         hipLaunchKernelGGL(sparse_validate_kernel, dim3((unsigned)n_terms), dim3(256), 0, s, d_indptr, d_doc_ids,
                            n_terms, n_docs, d_flags);
         hipLaunchKernelGGL(sparse_skip_kernel, dim3((unsigned)n_terms), dim3(64), 0, s, d_indptr, d_doc_ids, n_terms,
-                           idx->n_tiles, idx->skip);
+                           n_sub, idx->skip);
         if (hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) {
             sr_set_error("sr_sparse_index_create: %s", hipGetErrorString(hipGetLastError()));
@@ -355,8 +840,9 @@ extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_in
         }
     } while (0);
     if (d_flags) (void)hipFree(d_flags);
+    if (rc == SR_OK) rc = sparse_build_dense(idx, s);
     if (rc != SR_OK) {
-        if (idx->skip) (void)hipFree(idx->skip);
+        sparse_free_device(idx);
         delete idx;
         return rc;
     }
@@ -374,9 +860,19 @@ extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
     idx->order.release();
-    if (idx->skip) (void)hipFree(idx->skip);
+    sparse_free_device(idx);
     if (idx->d_postings) (void)hipFree(idx->d_postings);
     delete idx;
+    return SR_OK;
+}
+
+extern "C" int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, int64_t* n_block_calls,
+                                           int64_t* n_fallback_calls) {
+    SR_REQUIRE(idx && n_dense_terms && n_block_calls && n_fallback_calls, "sr_sparse_index_block_stats: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *n_dense_terms = idx->n_dense;
+    *n_block_calls = idx->n_block_calls;
+    *n_fallback_calls = idx->n_fallback_calls;
     return SR_OK;
 }
 
@@ -420,8 +916,57 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
     std::lock_guard<std::mutex> lock(idx->mu);
     StreamOrder::Scope in_order(idx->order, s);
 
+    // query-block path: plan the blocks of 4 queries once per call
+    bool use_blocks = idx->n_dense > 0;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_BLOCKS")) use_blocks = use_blocks && atoi(e) != 0;
+    bool any_fallback = !use_blocks;
+    int64_t nnz_base = 0;
+    if (use_blocks) {
+        int64_t h[2];
+        SR_CHECK_HIP(hipMemcpyAsync(h, d_q_indptr, 8, hipMemcpyDeviceToHost, s));
+        SR_CHECK_HIP(hipMemcpyAsync(h + 1, d_q_indptr + nq, 8, hipMemcpyDeviceToHost, s));
+        SR_CHECK_HIP(hipStreamSynchronize(s));
+        nnz_base = h[0];
+        const int64_t nnz = h[1] - h[0];
+        SR_REQUIRE(nnz >= 0, "sr_sparse_search: query indptr not monotone");
+        const int64_t n_blocks = ceil_div64(nq, SPB_Q);
+        if (nnz > idx->plan_cap || n_blocks > idx->plan_blocks_cap) {
+            void* old[] = {idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok};
+            for (void* p : old)
+                if (p) (void)hipFree(p);
+            idx->plan_term = nullptr; idx->plan_w = nullptr; idx->plan_n = nullptr; idx->plan_ok = nullptr;
+            idx->plan_cap = idx->plan_blocks_cap = 0;
+            const int64_t cap = nnz > 0 ? nnz : 1;
+            SR_CHECK_HIP(hipMalloc(&idx->plan_term, sizeof(int32_t) * (size_t)cap));
+            SR_CHECK_HIP(hipMalloc(&idx->plan_w, sizeof(float) * SPB_Q * (size_t)cap));
+            SR_CHECK_HIP(hipMalloc(&idx->plan_n, sizeof(int32_t) * (size_t)n_blocks));
+            SR_CHECK_HIP(hipMalloc(&idx->plan_ok, (size_t)n_blocks));
+            idx->plan_cap = cap;
+            idx->plan_blocks_cap = n_blocks;
+        }
+        if (!idx->plan_bad) SR_CHECK_HIP(hipMalloc(&idx->plan_bad, sizeof(int)));
+        SR_CHECK_HIP(hipMemsetAsync(idx->plan_bad, 0, sizeof(int), s));
+        hipLaunchKernelGGL(sparse_block_plan_kernel, dim3((unsigned)ceil_div64(n_blocks, 64)), dim3(64), 0, s, d_q_indptr, d_q_cols,
+                           d_q_vals, nq, idx->n_terms, idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_bad);
+        SR_CHECK_LAUNCH();
+        int h_bad = 0;
+        SR_CHECK_HIP(hipMemcpyAsync(&h_bad, idx->plan_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+        SR_CHECK_HIP(hipStreamSynchronize(s));
+        any_fallback = h_bad != 0;        // a query whose terms do not ascend: its block goes through the per-query kernel
+        static DeviceOnce lds_set;
+        if (bool* slot = lds_set.pending()) {
+            SR_CHECK_HIP(hipFuncSetAttribute((const void*)sparse_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(float) * SPB_Q * SPB_TSTRIDE)));
+            *slot = true;
+        }
+        ++idx->n_block_calls;
+        if (any_fallback) ++idx->n_fallback_calls;
+    }
+
     // query batches bound the candidate workspace: cap (slots per query) = docs per launch
-    const int64_t q_batch = nq < 1024 ? nq : 1024;
+    int64_t q_batch_max = 1024;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_QBATCH")) q_batch_max = atoll(e) >= 4 ? atoll(e) / 4 * 4 : 4;
+    const int64_t q_batch = nq < q_batch_max ? nq : q_batch_max;
     int64_t max_tiles = idx->ws_limit / (8 * q_batch * SP_TILE);
     if (max_tiles < 1) max_tiles = 1;
     if (max_tiles > 64) max_tiles = 64;
@@ -455,9 +1000,36 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             a.cand_cap = idx->ws.cand_cap;
             a.id_base = (uint32_t)id_base;
             a.id_stride = (uint32_t)id_stride;
+            a.blk_done = use_blocks ? idx->plan_ok : nullptr;
             idx->prof.begin(s);
-            hipLaunchKernelGGL(sparse_score_kernel, dim3((unsigned)nqb, (unsigned)nt), dim3(256), 0, s, a);
-            SR_CHECK_LAUNCH();
+            if (use_blocks) {
+                SparseBlockArgs b;
+                b.a = a;
+                b.dense = idx->dense;
+                b.dense_slot = idx->dense_slot;
+                b.dense_stride = idx->dense_stride;
+                b.plan_term = idx->plan_term;
+                b.plan_w = idx->plan_w;
+                b.plan_n = idx->plan_n;
+                b.plan_ok = idx->plan_ok;
+                b.nnz_base = nnz_base;
+                b.q_end = qb + nqb;
+                b.diag = 0;
+                if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
+                b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));
+                b.xcd = 1;
+                if (const char* e = sr_dev_getenv("SR_SPARSE_XCD")) b.xcd = atoi(e);
+                const int64_t gy = ceil_div64(b.n_sub, SPB_SUBS);
+                const dim3 grid = b.xcd ? dim3((unsigned)(ceil_div64(nqb, SPB_Q) * SPB_XCD), (unsigned)ceil_div64(gy, SPB_XCD))
+                                        : dim3((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)gy);
+                hipLaunchKernelGGL(sparse_block_kernel, grid, dim3(SPB_THREADS),
+                                   sizeof(float) * SPB_Q * SPB_TSTRIDE, s, b);
+                SR_CHECK_LAUNCH();
+            }
+            if (any_fallback) {
+                hipLaunchKernelGGL(sparse_score_kernel, dim3((unsigned)nqb, (unsigned)nt), dim3(256), 0, s, a);
+                SR_CHECK_LAUNCH();
+            }
             idx->prof.end(s, 0, 0);
             if (idx->prof.enabled && idx->d_postings) {
                 int64_t h[2];

@@ -222,6 +222,12 @@ class SparseIndexHIP:
     def set_workspace_limit(self, nbytes):
         _lib.check(self.lib.sr_sparse_index_set_workspace_limit(self._h, int(nbytes)))
 
+    def block_stats(self):
+        """{"dense_terms", "block_calls", "fallback_calls"}: which of the two bit-identical scoring paths ran."""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.sr_sparse_index_block_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"dense_terms": a.value, "block_calls": b.value, "fallback_calls": c.value}
+
     def search(self, q_indptr, q_cols, q_vals, k, threshold=0.0, id_base=0, id_stride=1):
         """Queries as CSR tensors. Returns (scores [nq,k], ids [nq,k], counts [nq]) cuda tensors."""
         def to_dev(x, dt):
