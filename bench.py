@@ -247,14 +247,17 @@ def sparse_leg(args, device):
            "ms_per_pass": round(dt * 1e3, 1), "dtype": "f32", "data": "synthetic",
            "config": {"workload": "Lion-SP-1B sparse scoring (BASELINE.json configs[2]), synthetic Zipf(1.0) index", "V": V, "N": N, "L0_d": L0_d,
                       "L0_q": L0_q, "nq": nq, "k": k, "postings": nnz, "mean_postings_touched_per_query": float(touched.mean().item())},
-           "roofline": {"kernel": "sparse_score_kernel", "bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+           "roofline": {"kernel": "sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel",
+                        "dense_column_terms": idx.block_stats()["dense_terms"],
+                        "bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / PEAK_HBM_GBPS, 4), "traffic": None, "launches": int(n_l.value),
                         "kernel_ms_per_pass": round(kernel_s * 1e3, 1), "unique_index_bytes_per_pass": unique_bytes,
                         "hbm_floor_ms_per_pass": round(unique_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3, 2),
                         "note": "achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per posting) / "
                                 "kernel time: the HBM floor is a small fraction of the kernel time, i.e. this kernel is NOT HBM-bound - the posting "
-                                "lists are re-read per (query, doc tile) from L2 / Infinity Cache and every touched posting costs one LDS "
-                                "read-modify-write, which is what `lds_rmw` prices"},
+                                "lists and the dense columns of the heavy terms are re-read per (4 queries, 4096-doc tile) from L2 / Infinity "
+                                "Cache; `lds_rmw` prices every touched posting as one LDS read-modify-write (the per-query kernel's model; the "
+                                "query-block kernel applies the dense-column terms - most of the touched postings - in registers instead)"},
            "lds_rmw": {"bound": "lds", "achieved": rmw_rate, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",
                        "frac": round(rmw_rate / lds_peak, 4) if lds_peak else None, "rmw_per_pass": rmw, "peak_source": lds_src}}
     from oracle import scoring as SC

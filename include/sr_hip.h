@@ -127,7 +127,7 @@ int sr_sparse_index_profile(sr_sparse_index* idx, int enable);
 int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_launches, double* total_ms,
                                  double* total_posting_bytes);
 /* Which scoring path served the searches so far (both return the same bits): n_dense_terms = heavy
- * terms (present in at least half of the docs) that also have a dense column; n_block_calls =
+ * terms (present in at least a quarter of the docs) that also have a dense column; n_block_calls =
  * sr_sparse_search calls that ran the 4-queries-per-workgroup kernel; n_fallback_calls = those of them
  * in which at least one block of 4 queries went through the per-query kernel because a query listed
  * its terms in non-ascending order (the accumulation order the reference follows,

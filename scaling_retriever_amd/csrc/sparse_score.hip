@@ -19,7 +19,12 @@
 #include <vector>
 
 #define SP_TILE 8192
+#ifndef SPB_Q
+#define SPB_Q 4         // queries per workgroup of the query-block kernel (4 or 8), one wave each
+#endif
+#ifndef SP_SUB
 #define SP_SUB 4096     // skip-table granularity (the query-block kernel's tile); SP_TILE is a multiple of it
+#endif
 #define SP_TERMS 64   // query terms staged per batch (one wave builds the batch's work list)
 #define SP_U 4        // postings per thread and group
 #define SP_GROUP (SP_U * 256)                              // postings per group
@@ -49,7 +54,7 @@ struct SparseArgs {
     int* cand_count;
     int64_t cand_cap;
     uint32_t id_base, id_stride;
-    const uint8_t* blk_done;   // optional: blocks of 4 queries the query-block kernel handles (skipped here)
+    const uint8_t* blk_done;   // optional: blocks of SPB_Q queries the query-block kernel handles (skipped here)
 };
 
 // The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term.  The run of
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
     const int lane = tid & 63;
     const int ql = blockIdx.x;                 // query within batch
     const int64_t q = a.q_base + ql;
-    if (a.blk_done && a.blk_done[q >> 2]) return;
+    if (a.blk_done && a.blk_done[q / SPB_Q]) return;
     const int tile = a.tile_begin + blockIdx.y;
     const int64_t doc0 = (int64_t)tile * SP_TILE;
     const int n_here = (int)((a.n_docs - doc0) < SP_TILE ? (a.n_docs - doc0) : SP_TILE);
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 
 // ---- query-block kernel: 4 queries per workgroup, heavy terms as dense columns in registers ----------------------------
 // What bounds sparse_score_kernel is one LDS read-modify-write and 8 B of loads per posting, and two thirds of the postings a
-// query touches belong to a handful of terms that occur in more than half of all docs.  Those terms are ALSO stored as dense
+// query touches belong to a few dozen terms that occur in a quarter or more of all docs.  Those terms are ALSO stored as dense
 // columns (value per doc, 0 where the doc lacks the term: 4 B per doc, no doc ids), and a workgroup of 4 waves owns
 // (4 consecutive queries, sub-tile of SPB_TILE docs); two workgroups share a CU.  A run of consecutive dense terms is applied
 // in REGISTERS - thread t owns 16 docs of each query's slice - from coalesced 16-byte column loads that serve all 4 queries.
@@ -266,8 +271,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 // query (0 = the query lacks the term = skipped), which is each query's own term order when its terms ascend strictly (the plan
 // kernel checks; other blocks go to sparse_score_kernel); s + w * 0 == s, so a dense column's zeros change nothing; products and
 // sums are unfused.  Per-doc sums are therefore the reference's term-serial fp32 sums, bit for bit.
-#define SPB_Q 4
-#define SPB_THREADS 256
+#define SPB_THREADS (64 * SPB_Q)
 #define SPB_TILE SP_SUB
 #ifndef SPB_U
 #define SPB_U 4       // postings per lane and group
@@ -275,10 +279,16 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 #ifndef SPB_RING
 #define SPB_RING 6    // register sets of a wave's group walk: SPB_RING - 1 groups of loads in flight per wave
 #endif
-#define SPB_GROUP (SPB_U * 64)                       // postings per wave and group
+#define SPB_GROUP (SPB_U * 64)                       // postings per wave and group of the longer runs
 #define SPB_TSTRIDE (SPB_TILE + 64)
-#define SPB_XCD 8
 #define SPB_DESC 256
+#define SPB_LIGHT 64      // runs up to this many postings take the one-step path
+#ifndef SPB_DRING
+#define SPB_DRING 3     // register sets of the dense-column walk
+#endif
+#ifndef SPB_LRING
+#define SPB_LRING 8
+#endif
 #ifndef SPB_SUBS
 #define SPB_SUBS 1     // consecutive sub-tiles per workgroup: the plan fetch and the launch cost amortise, the next sub-tile's
 #endif                 // runs are looked up while this one is scored
@@ -296,11 +306,13 @@ struct SparseBlockArgs {
     int64_t nnz_base;
     int64_t q_end;               // one past the last query of this batch
     int n_sub;                   // sub-tiles of this launch
-    int xcd;                     // XCD-aware block order
-    int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): 1 = skip the scatter runs, 2 = skip the dense runs
+    int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): bit mask of skipped run kinds, 2 = dense, 4 = light scatter, 8 = big scatter
 };
 
-__global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockArgs b) {
+#ifndef SPB_WAVES_PER_SIMD
+#define SPB_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_kernel(SparseBlockArgs b) {
 #pragma clang fp contract(off)
     extern __shared__ float sc[];              // [SPB_Q][SPB_TSTRIDE]: score slices + one dummy slot per lane
     __shared__ int wave_tot[SPB_Q][SPB_THREADS / 64];
@@ -310,10 +322,7 @@ __global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    // workgroups are dealt to the 8 XCDs round-robin in launch order: blockIdx.x % 8 picks the sub-tile group, so that all the
-    // query blocks of one sub-tile run on ONE XCD and its posting runs are fetched into one L2 only
-    const int bx = b.xcd ? (int)(blockIdx.x / SPB_XCD) : (int)blockIdx.x;
-    const int by = b.xcd ? (int)(blockIdx.y * SPB_XCD + blockIdx.x % SPB_XCD) : (int)blockIdx.y;
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     const int64_t q0 = a.q_base + (int64_t)bx * SPB_Q;
     const int64_t gblk = q0 / SPB_Q;
     if (!b.plan_ok[gblk]) return;
@@ -330,14 +339,18 @@ __global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockAr
 
     // lane j: plan entry j of a batch of 64 (every wave holds the same entries); the next batch's entries - of this sub-tile
     // or the first of the next one - are fetched while this one is applied
-    struct Ent { int64_t seg_b; int seg_n, slot; f32x4 w; };
+    struct Ent { int64_t seg_b; int seg_n, slot; f32x4 w[SPB_Q / 4]; };
     auto fetch = [&](int sub, int e0) -> Ent {
         Ent en;
-        en.seg_b = 0; en.seg_n = 0; en.slot = -1; en.w = f32x4{0.f, 0.f, 0.f, 0.f};
+        en.seg_b = 0; en.seg_n = 0; en.slot = -1;
+#pragma unroll
+        for (int h = 0; h < SPB_Q / 4; ++h) en.w[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (e0 + lane < ne) {
             const int term = b.plan_term[pe0 + e0 + lane];     // known terms only (plan kernel)
             en.slot = b.dense_slot[term];
-            en.w = *reinterpret_cast<const f32x4*>(b.plan_w + (pe0 + e0 + lane) * SPB_Q);
+#pragma unroll
+            for (int h = 0; h < SPB_Q / 4; ++h)
+                en.w[h] = *reinterpret_cast<const f32x4*>(b.plan_w + (pe0 + e0 + lane) * SPB_Q + 4 * h);
             const int32_t* sk = a.skip + (int64_t)term * skip_stride + sub;
             const int sb = sk[0], se = sk[1];
             en.seg_n = se - sb;
@@ -387,23 +400,28 @@ __global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockAr
         else if (sub + 1 < sub_end) nxt = fetch(sub + 1, 0);
         const int64_t seg_b = en.seg_b;
         const int seg_n = en.seg_n, slot = en.slot;
-        const f32x4 seg_w = en.w;
-        const float my_w = wave == 0 ? seg_w[0] : wave == 1 ? seg_w[1] : wave == 2 ? seg_w[2] : seg_w[3];
+        float seg_w[SPB_Q];
+#pragma unroll
+        for (int q = 0; q < SPB_Q; ++q) seg_w[q] = en.w[q / 4][q % 4];
+        float my_w = seg_w[0];
+#pragma unroll
+        for (int q = 1; q < SPB_Q; ++q) my_w = wave == q ? seg_w[q] : my_w;
         const uint64_t dmask = __ballot(slot >= 0 && seg_n > 0);
-        const uint64_t smask = __ballot(slot < 0 && seg_n > 0);
-        uint64_t rem = dmask | smask;
+        const uint64_t bmask = __ballot(slot < 0 && seg_n > SPB_LIGHT);                    // scatter runs walked in groups
+        const uint64_t lmask = __ballot(slot < 0 && seg_n > 0 && seg_n <= SPB_LIGHT);      // one wave step per run
+        uint64_t rem = dmask | bmask | lmask;
         while (rem) {
             const int j_first = __builtin_ctzll(rem);
             const bool dense_run = (dmask >> j_first) & 1;
-            const uint64_t other = (dense_run ? smask : dmask) & rem;           // all above j_first
+            const bool light_run = (lmask >> j_first) & 1;
+            const uint64_t same = dense_run ? dmask : light_run ? lmask : bmask;
+            const uint64_t other = (dmask | bmask | lmask) & ~same & rem;       // all above j_first
             const uint64_t below = other ? ((1ull << __builtin_ctzll(other)) - 1ull) : ~0ull;
-            uint64_t run = (dense_run ? dmask : smask) & rem & below;
+            uint64_t run = same & rem & below;
             rem &= ~run;
-            if (b.diag & (dense_run ? 2 : 1)) continue;
+            if (b.diag & (dense_run ? 2 : light_run ? 4 : 8)) continue;      // 2: dense, 4: light, 8: big runs skipped
             if (dense_run) {
                 if (!in_regs) { to_regs(); in_regs = true; }
-                // two register sets: the next term's column loads fly while this one is applied (always issued: past the
-                // run's end they re-read the last term)
                 auto dload = [&](int j, f32x4 (&v)[SPB_DV]) {
                     const float* p = dcol + (int64_t)__builtin_amdgcn_readlane(slot, j) * b.dense_stride;
 #pragma unroll
@@ -422,23 +440,80 @@ __global__ __launch_bounds__(SPB_THREADS) void sparse_block_kernel(SparseBlockAr
                         }
                     }
                 };
-                f32x4 vA[SPB_DV], vB[SPB_DV];
-                int jA = __builtin_ctzll(run);
+                // SPB_DRING register sets: the column loads of the next SPB_DRING - 1 terms fly while one is applied (always
+                // issued: past the run's end they re-read the last term)
+                f32x4 vD[SPB_DRING][SPB_DV];
+                int jD[SPB_DRING];
+                bool liveD[SPB_DRING];
+                int jn = __builtin_ctzll(run);
                 run &= run - 1;
-                dload(jA, vA);
-                for (;;) {
-                    const bool moreB = run != 0;
-                    const int jB = moreB ? __builtin_ctzll(run) : jA;
-                    run &= run - 1;
-                    dload(jB, vB);
-                    dapply(jA, vA);
-                    if (!moreB) break;
-                    const bool moreA = run != 0;
-                    jA = moreA ? __builtin_ctzll(run) : jB;
-                    run &= run - 1;
-                    dload(jA, vA);
-                    dapply(jB, vB);
-                    if (!moreA) break;
+                bool more = true;
+#pragma unroll
+                for (int s2 = 0; s2 < SPB_DRING - 1; ++s2) {
+                    dload(jn, vD[s2]);
+                    asm volatile("" ::: "memory");
+                    jD[s2] = jn; liveD[s2] = more;
+                    more = more && run != 0;
+                    if (more) { jn = __builtin_ctzll(run); run &= run - 1; }
+                }
+                for (bool done = false; !done;) {
+#pragma unroll
+                    for (int s2 = 0; s2 < SPB_DRING; ++s2) {
+                        const int ld = (s2 + SPB_DRING - 1) % SPB_DRING;
+                        dload(jn, vD[ld]);
+                        asm volatile("" ::: "memory");
+                        jD[ld] = jn; liveD[ld] = more;
+                        more = more && run != 0;
+                        if (more) { jn = __builtin_ctzll(run); run &= run - 1; }
+                        if (!liveD[s2]) { done = true; break; }
+                        dapply(jD[s2], vD[s2]);
+                    }
+                }
+            } else if (light_run) {
+                if (in_regs) { to_lds(); in_regs = false; }
+                // This wave's query, runs of at most 64 postings (most of a query's terms): one posting per lane, one load
+                // pair and one LDS read-modify-write per term, SPB_LRING - 1 terms of loads in flight.  No barriers.
+                uint64_t todo = run & __ballot(my_w != 0.f);
+                if (todo == 0) continue;
+                auto lload = [&](int j, int& dd, float& vv) {
+                    const int64_t sb = readlane64(seg_b, j);
+                    const uint32_t last = (uint32_t)__builtin_amdgcn_readlane(seg_n, j) - 1u;
+                    const uint32_t pc = (uint32_t)lane < last ? (uint32_t)lane : last;
+                    dd = a.doc_ids[sb + pc];
+                    vv = a.vals[sb + pc];
+                    asm volatile("" ::: "memory");      // see gload below
+                };
+                auto lapply = [&](int j, int dd, float vv) {
+                    const int n = __builtin_amdgcn_readlane(seg_n, j);
+                    const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+                    const int d = lane < n ? dd - (int)doc0 : SPB_TILE + lane;
+                    const float prod = w * vv;
+                    my_slice[d] = my_slice[d] + prod;
+                };
+                int jL[SPB_LRING], dL[SPB_LRING];
+                float vL[SPB_LRING];
+                bool liveL[SPB_LRING];
+                int jn = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                bool more = true;
+#pragma unroll
+                for (int s2 = 0; s2 < SPB_LRING - 1; ++s2) {
+                    lload(jn, dL[s2], vL[s2]);
+                    jL[s2] = jn; liveL[s2] = more;
+                    more = more && todo != 0;
+                    if (more) { jn = __builtin_ctzll(todo); todo &= todo - 1; }
+                }
+                for (bool done = false; !done;) {
+#pragma unroll
+                    for (int s2 = 0; s2 < SPB_LRING; ++s2) {
+                        const int ld = (s2 + SPB_LRING - 1) % SPB_LRING;
+                        lload(jn, dL[ld], vL[ld]);
+                        jL[ld] = jn; liveL[ld] = more;
+                        more = more && todo != 0;
+                        if (more) { jn = __builtin_ctzll(todo); todo &= todo - 1; }
+                        if (!liveL[s2]) { done = true; break; }
+                        lapply(jL[s2], dL[s2], vL[s2]);
+                    }
                 }
             } else {
                 if (in_regs) { to_lds(); in_regs = false; }
@@ -732,8 +807,9 @@ static void sparse_free_device(sr_sparse_index* idx) {
 
 // Terms present in at least 1 / SP_DENSE_DIV of the docs get a dense column: the longest lists first, at most SP_DENSE_MAX of
 // them and never more than a quarter of the free device memory (a column costs 4 B per doc, the list it shadows 8 B per
-// posting, so above half the docs the column is also the smaller of the two).  No such term: the query-block kernel is not used.
-#define SP_DENSE_DIV 2
+// posting; measured at MSMARCO shape, thresholds of 1/3 .. 1/8 of the docs are within 2 % of each other, 1/2 is 5 % slower).
+// No such term: the query-block kernel is not used.
+#define SP_DENSE_DIV 4
 #define SP_DENSE_MAX 64
 static int sparse_build_dense(sr_sparse_index* idx, hipStream_t s) {
     int div = SP_DENSE_DIV, max_slots = SP_DENSE_MAX;
@@ -1017,11 +1093,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 b.diag = 0;
                 if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
                 b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));
-                b.xcd = 1;
-                if (const char* e = sr_dev_getenv("SR_SPARSE_XCD")) b.xcd = atoi(e);
-                const int64_t gy = ceil_div64(b.n_sub, SPB_SUBS);
-                const dim3 grid = b.xcd ? dim3((unsigned)(ceil_div64(nqb, SPB_Q) * SPB_XCD), (unsigned)ceil_div64(gy, SPB_XCD))
-                                        : dim3((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)gy);
+                const dim3 grid((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)ceil_div64(b.n_sub, SPB_SUBS));
                 hipLaunchKernelGGL(sparse_block_kernel, grid, dim3(SPB_THREADS),
                                    sizeof(float) * SPB_Q * SPB_TSTRIDE, s, b);
                 SR_CHECK_LAUNCH();

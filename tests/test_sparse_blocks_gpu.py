@@ -48,9 +48,20 @@ def _queries(rng, V, nq, max_terms, always=(), order="asc"):
     return np.array(qi, np.int64), np.concatenate(qc), np.concatenate(qv)
 
 
+DENSE_DIV, DENSE_MAX = 4, 64      # csrc/sparse_score.hip SP_DENSE_DIV / SP_DENSE_MAX
+
+
+def _n_dense(indptr, N):
+    lens = np.diff(indptr)
+    return int(min(DENSE_MAX, ((lens > 0) & (lens * DENSE_DIV >= N)).sum()))
+
+
 def _check(indptr, ids, vals, N, qi, qc, qv, k, thr, expect_dense=None, expect_fallback=None):
     from scaling_retriever_amd.scoring import SparseIndexHIP
     idx = SparseIndexHIP(indptr, ids, vals, N)
+    if expect_dense == "auto":
+        expect_dense = _n_dense(indptr, N)
+        assert expect_dense > 0
     s, i, c = idx.search(qi, qc, qv, k, threshold=thr)
     torch.cuda.synchronize()
     st = idx.block_stats()
@@ -83,7 +94,7 @@ def test_block_kernel_bit_exact(V, N, heavy, nq, max_terms, k, thr):
     rng = np.random.default_rng(V * 7 + N)
     indptr, ids, vals = _index(rng, V, N, heavy, N // 4, max(2, N // 50))
     qi, qc, qv = _queries(rng, V, nq, min(max_terms, V), always=tuple(heavy))
-    _check(indptr, ids, vals, N, qi, qc, qv, k, thr, expect_dense=len(heavy), expect_fallback=0)
+    _check(indptr, ids, vals, N, qi, qc, qv, k, thr, expect_dense="auto", expect_fallback=0)
 
 
 def test_block_kernel_zero_weights_unknown_terms_and_empty_queries():
@@ -98,7 +109,7 @@ def test_block_kernel_zero_weights_unknown_terms_and_empty_queries():
     qc = np.concatenate([qc, np.array([V, V + 5], np.int32), np.array([1, 30, V + 2], np.int32)])
     qv = np.concatenate([qv, np.array([1.0, 2.0], np.float32), np.array([0.5, 1.5, 3.0], np.float32)])
     qi = np.concatenate([qi, [qi[-1] + 2, qi[-1] + 5]])
-    _check(indptr, ids, vals, N, qi, qc, qv, 25, 0.0, expect_dense=3, expect_fallback=0)
+    _check(indptr, ids, vals, N, qi, qc, qv, 25, 0.0, expect_dense="auto", expect_fallback=0)
 
 
 @pytest.mark.parametrize("order", ["desc", "mixed"])
@@ -110,19 +121,21 @@ def test_non_ascending_queries_take_the_per_query_kernel(order):
     heavy = {0: 1.0, 20: 0.7, 50: 0.55}
     indptr, ids, vals = _index(rng, V, N, heavy, 4000, 300)
     qi, qc, qv = _queries(rng, V, 23, 16, always=tuple(heavy), order=order)
-    _check(indptr, ids, vals, N, qi, qc, qv, 40, 0.0, expect_dense=3, expect_fallback=1)
+    _check(indptr, ids, vals, N, qi, qc, qv, 40, 0.0, expect_dense="auto", expect_fallback=1)
 
 
 def test_no_heavy_term_means_no_block_path():
     rng = np.random.default_rng(2)
     V, N = 50, 9000
     indptr, ids, vals = _index(rng, V, N, {}, 2000, 100)
+    assert _n_dense(indptr, N) == 0
     qi, qc, qv = _queries(rng, V, 9, 10)
     _check(indptr, ids, vals, N, qi, qc, qv, 30, 0.0, expect_dense=0)
 
 
 def test_more_heavy_terms_than_columns_and_many_queries():
-    """Over 64 heavy terms: the longest 64 get columns, the others stay posting lists; > 1024 queries: two query batches."""
+    """Over 64 heavy terms: the longest 64 get columns, the others stay posting lists (some walked in groups, some in one
+    step); > 1024 queries: two query batches."""
     rng = np.random.default_rng(8)
     V, N = 100, 10000
     heavy = {t: 0.5 + 0.005 * t for t in range(0, 80)}
