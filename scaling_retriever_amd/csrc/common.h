@@ -122,7 +122,7 @@ struct TopkWS {
     int64_t nq_cap = 0;      // allocated queries
     int k = 0;               // allocated k
     int64_t cand_cap = 0;    // allocated candidate slots per query
-    uint64_t* run_keys = nullptr;   // [nq_cap, k]   running top-k, unsorted
+    uint64_t* run_keys = nullptr;   // [nq_cap, 2k]  running set, unsorted: a superset of the top-k, cut back to k when full
     int* run_count = nullptr;       // [nq_cap]
     float* tau = nullptr;           // [nq_cap]     score of the current k-th best (-inf until k kept)
     uint64_t* cand_keys = nullptr;  // [nq_cap, cand_cap]

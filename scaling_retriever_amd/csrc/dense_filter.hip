@@ -107,7 +107,7 @@ int launch_filter_certify(const float* a_scores, const float* x_scores, const fl
 #define RS_KC 64
 __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, const float* __restrict__ Q, const float* __restrict__ a_scores,
                                                             const int64_t* __restrict__ a_ids, const float* __restrict__ qnorm,
-                                                            const float* __restrict__ d_max2, int kp, int H, double c,
+                                                            const float* __restrict__ d_max2, int k, int kp, int H, double c,
                                                             uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
                                                             int64_t cand_cap, int* __restrict__ flags) {
 #pragma clang fp contract(off)
@@ -118,7 +118,14 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     const int64_t q = blockIdx.x;
     const int j0 = blockIdx.y * 64;
     const int j = j0 + lane;
-    const int64_t gid = j < kp ? a_ids[q * kp + j] : -1;
+    // A candidate whose approximate score lies more than 2E below the k-th best approximate score cannot be in the exact
+    // top-k: its exact score is < a_k - E, and the k candidates with approximate scores >= a_k all have exact scores >= a_k - E.
+    // The approximate list is sorted, so what has to be re-scored is a prefix of it.
+    const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
+    const double need = (double)a_scores[q * kp + (k < kp ? k : kp) - 1] - 2.0 * E;
+    if ((double)a_scores[q * kp + j0] < need) return;           // the whole wave
+    int64_t gid = j < kp ? a_ids[q * kp + j] : -1;
+    if (gid >= 0 && (double)a_scores[q * kp + j] < need) gid = -1;
     const float* row = nullptr;
     if (gid >= 0) {
         for (int sgi = 0; sgi < segs.count; ++sgi) {
@@ -155,7 +162,6 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     }
     if (row) {
         // the bound, checked on every pair that is re-scored
-        const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
         if (!(fabs((double)acc - (double)a_scores[q * kp + j]) <= E)) atomicOr(&flags[q], 2);
         const int pos = atomicAdd(&cand_count[q], 1);
         if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
@@ -163,12 +169,12 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
 }
 
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
-                          const float* d_max2, int64_t nq, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
+                          const float* d_max2, int64_t nq, int k, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
                           int64_t cand_cap, int* flags, hipStream_t s) {
     SR_REQUIRE(H % RS_KC == 0, "filter(rescore): dim %d must be a multiple of %d", H, RS_KC);
     SR_REQUIRE(nq <= 0x7fffffff && ceil_div64(kp, 64) <= 65535, "filter(rescore): grid too large");
     hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp, 64)), dim3(64), 0, s, segs, Q, a_scores, a_ids,
-                       qnorm, d_max2, kp, H, c, cand_keys, cand_count, cand_cap, flags);
+                       qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -725,7 +725,7 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
         fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
     }
-    SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, kp, idx->dim, c,
+    SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, k, kp, idx->dim, c,
                                  idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
     SR_TRY(topk_compact(idx->ws2, nq, k, s));
     SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));

@@ -4,8 +4,12 @@
 // tile against a per-query threshold tau (score of the current k-th best) and
 // appends survivors as 64-bit keys (ordered score bits << 32 | ~doc index) to a
 // per-query candidate buffer.  After every doc chunk, topk_compact_kernel folds
-// the candidates into the running (unsorted) top-k with an LDS radix select and
-// raises tau.  topk_sort_kernel sorts the k survivors once at the end.
+// the candidates into the running (unsorted) set.  The set has room for 2k keys:
+// once tau is finite, candidates are only APPENDED (they all beat tau, so the set
+// stays a superset of the top-k) and the LDS radix select that cuts it back to k
+// and raises tau runs only when the 2k slots overflow - about every 30th chunk of
+// a long scan instead of every chunk.  topk_sort_kernel sorts what is left once at
+// the end and emits the best k.
 //
 // Result = top-k by (score desc, doc index asc): deterministic, independent of
 // tile scheduling.  Stands in for faiss' heap top-k (indexer.py:211) and for
@@ -24,7 +28,7 @@ __global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, i
 }
 
 // ---------------------------------------------------------------- compact ---
-// One workgroup (256 threads) per query.
+// One workgroup (256 threads) per query.  run_keys has 2k slots per query.
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
                                                            int* __restrict__ cand_count, int k, int64_t cand_cap) {
@@ -40,11 +44,14 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
     if (nc == 0) return;
     if ((int64_t)nc > cand_cap) nc = (int)cand_cap;  // unreachable by construction (cap >= docs per chunk)
     const int nr = run_count[q];
-    uint64_t* run = run_keys + (int64_t)q * k;
+    const int cap = 2 * k;
+    uint64_t* run = run_keys + (int64_t)q * cap;
     const uint64_t* cand = cand_keys + (int64_t)q * cand_cap;
     const int n = nr + nc;
 
-    if (n <= k) {
+    // append only: below k keys there is nothing to cut; with k or more already held tau is finite and every candidate
+    // beats it, so the set stays a superset of the top-k until its 2k slots overflow
+    if (n <= k || (nr >= k && n <= cap)) {
         for (int i = tid; i < nc; i += 256) run[nr + i] = cand[i];
         if (n == k) {
             // tau = smallest kept score
@@ -113,16 +120,25 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
         ctrl[3] = 0;
     }
     __syncthreads();
+    // the k keys >= T end up in run[0, k): slots there that are empty or hold a smaller key are holes, filled from the
+    // kept keys of run[k, nr) and of the candidates
+    const int extra = nr > k ? nr - k : 0;
     for (int i = tid; i < k; i += 256) {
         const bool hole = (i >= nr) || (run[i] < T);
         if (hole) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;
     }
+    for (int i = tid; i < extra; i += 256) {
+        if (run[k + i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)i;
+    }
     for (int i = tid; i < nc; i += 256) {
-        if (cand[i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)i;
+        if (cand[i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(extra + i);
     }
     __syncthreads();
     const int nf = ctrl[3] < ctrl[2] ? ctrl[3] : ctrl[2];  // equal by construction
-    for (int j = tid; j < nf; j += 256) run[hole_pos[j]] = cand[filler_idx[j]];
+    for (int j = tid; j < nf; j += 256) {
+        const uint32_t f = filler_idx[j];
+        run[hole_pos[j]] = f < (uint32_t)extra ? run[k + f] : cand[f - (uint32_t)extra];
+    }
     if (tid == 0) {
         run_count[q] = k;
         cand_count[q] = 0;
@@ -131,16 +147,17 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
 }
 
 // ------------------------------------------------------------------- sort ---
-// Bitonic sort (descending) of the running top-k in LDS; P = next pow2 >= k.
+// Bitonic sort (descending) of the running set (up to 2k keys) in LDS; P = next pow2 >= 2k; the best k are written.
 __global__ __launch_bounds__(256) void topk_sort_kernel(const uint64_t* __restrict__ run_keys, const int* __restrict__ run_count,
                                                         int k, int P, float pad_score, float* __restrict__ out_scores,
                                                         int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int cnt = run_count[q];
-    const uint64_t* run = run_keys + (int64_t)q * k;
-    for (int i = tid; i < P; i += 256) keys[i] = i < cnt ? run[i] : 0ull;
+    const int held = run_count[q];
+    const int cnt = held < k ? held : k;
+    const uint64_t* run = run_keys + (int64_t)q * (2 * k);
+    for (int i = tid; i < P; i += 256) keys[i] = i < held ? run[i] : 0ull;
     __syncthreads();
     for (int size = 2; size <= P; size <<= 1) {
         for (int j = size >> 1; j > 0; j >>= 1) {
@@ -207,7 +224,7 @@ int TopkWS::ensure(int64_t nq, int kk, int64_t cc) {
     nq_cap = nq;
     k = kk;
     cand_cap = cc;
-    SR_CHECK_HIP(hipMalloc(&run_keys, sizeof(uint64_t) * (size_t)nq * (size_t)kk));
+    SR_CHECK_HIP(hipMalloc(&run_keys, sizeof(uint64_t) * (size_t)nq * 2 * (size_t)kk));
     SR_CHECK_HIP(hipMalloc(&run_count, sizeof(int) * (size_t)nq));
     SR_CHECK_HIP(hipMalloc(&tau, sizeof(float) * (size_t)nq));
     SR_CHECK_HIP(hipMalloc(&cand_keys, sizeof(uint64_t) * (size_t)nq * (size_t)cc));
@@ -237,8 +254,8 @@ int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s) {
     return SR_OK;
 }
 
-// NOTE: kernels index run_keys with stride ws.k and cand_keys with stride ws.cand_cap
-// (the ALLOCATED sizes); `k` below is the logical k of this search and must equal ws.k.
+// NOTE: kernels index run_keys with stride 2 * k (k = the logical k of this search, at most the allocated ws.k) and
+// cand_keys with stride ws.cand_cap.
 int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
     if (nq == 0) return SR_OK;
     const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
@@ -251,7 +268,13 @@ int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
 int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_scores, int64_t* d_out_ids,
                   int32_t* d_out_counts, hipStream_t s) {
     if (nq == 0) return SR_OK;
-    const int P = next_pow2(k < 2 ? 2 : k);
+    const int P = next_pow2(2 * k);
+    static DeviceOnce lds_set;      // k = 4096: 8192 keys = the whole 64 KB
+    if (bool* slot = lds_set.pending()) {
+        SR_CHECK_HIP(hipFuncSetAttribute((const void*)topk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(sizeof(uint64_t) * 2 * SR_MAX_TOPK)));
+        *slot = true;
+    }
     hipLaunchKernelGGL(topk_sort_kernel, dim3((unsigned)nq), dim3(256), sizeof(uint64_t) * (size_t)P, s, ws.run_keys,
                        ws.run_count, k, P, pad_score, d_out_scores, d_out_ids, d_out_counts);
     SR_CHECK_LAUNCH();
