@@ -410,7 +410,7 @@ def main():
     index = DenseIndexHIP(H, device=device)
     index.add_device_rows(D, id_base=rank, id_stride=world)
     # exact results through the certified bf16 filter + exact re-score (bit-identical to the exact fp32 kernel, checked below);
-    # without room for the two bf16 planes of D the library uses the exact kernel by itself
+    # without room for the bf16 plane of D the library uses the exact kernel by itself
     index.set_precision("fp32" if args.exact_kernel else "fp32_filtered")
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s: {n_local} docs x {H} fp32 = {n_local * H * 4 / 1e9:.1f} GB resident; "
@@ -469,11 +469,15 @@ def main():
     n_filtered, n_fallback = index.filter_stats()
     filtered = (not args.exact_kernel) and n_filtered > 0
     if filtered:
-        # dominant kernel: dense_split_kernel - 2 bf16 plane products per algorithmic multiply-add on the bf16 MFMA pipe
+        # dominant kernel: dense_split_kernel - `prods` bf16 plane products per algorithmic multiply-add on the bf16 MFMA pipe
+        prods, raised = index.filter_products()
         roofline = {"kernel": "dense_split_kernel (bf16 MFMA 16x16x32, 256 docs x 256 queries per workgroup; the certified filter's "
-                              "approximate pass: (q0 + q1) . d0, 2 plane products per fp32 multiply-add)",
-                    "bound": "mfma", "achieved": round(2 * achieved_tf, 1), "peak": PEAK_BF16_MFMA_TF,
-                    "unit": "TFLOP/s (bf16 MFMA work = 2 x algorithmic 2 nq N H)", "frac": round(2 * achieved_tf / PEAK_BF16_MFMA_TF, 4),
+                              "approximate pass: " + ("q0 . d0, 1 plane product" if prods == 1 else "(q0 + q1) . d0, 2 plane products") +
+                              " per fp32 multiply-add)",
+                    "bound": "mfma", "achieved": round(prods * achieved_tf, 1), "peak": PEAK_BF16_MFMA_TF,
+                    "unit": "TFLOP/s (bf16 MFMA work = %d x algorithmic 2 nq N H)" % prods,
+                    "frac": round(prods * achieved_tf / PEAK_BF16_MFMA_TF, 4), "filter_plane_products": prods,
+                    "filter_products_raised": int(raised),
                     "algorithmic_TFLOPs": round(achieved_tf, 1), "traffic": None,
                     "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4),
                     "flop_per_launch": fl.value / max(1, n_l.value), "kernel_share_of_step": round(ms.value * 1e-3 / dt, 3),

@@ -10,8 +10,9 @@ struct FilterSegs {                 // where a global doc index lives: row = (gi
     int count;
 };
 
-// |S_a - S_x| <= sr_filter_c(H) * |q| * |d| for the filter's score S_a = (q0 + q1) . d0 against the fp32 fmaf chain S_x
-double sr_filter_c(int H);
+// |S_a - S_x| <= sr_filter_c(H, products) * |q| * |d| for the filter's score S_a = q0 . d0 (products = 1) or
+// (q0 + q1) . d0 (products = 2) against the fp32 fmaf chain S_x
+double sr_filter_c(int H, int products);
 // *d_max2 = max(*d_max2, max over rows of |row|^2)   (non-negative floats order as their bit patterns)
 int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s);
 // qnorm[q] = |Q[q]|

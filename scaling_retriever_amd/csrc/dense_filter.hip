@@ -26,10 +26,15 @@
 //     fp32 summation of 2H terms:                                <= gamma_2H * 1.004 B
 //   c(H) = 2^-9 * 1.004 + 1.25 * (3 H 2^-24) + 1e-5   (2.43e-3 at H = 2048, 2.89e-3 at 4096) covers the sum with room to
 //   spare; the measured maximum is ~1e-3 (the 2^-9 plane truncation dominates).
+//   One product, S_a = q0 . d0:   q.d - q0.d0 = q.(d - d0) + (q - q0).d0 <= (2^-9 + 2^-9 (1 + 2^-9)) B, H products summed:
+//   c1(H) = 2^-8 * 1.004 + the same summation terms (4.38e-3 at H = 2048).  Half the MFMA work of the two-product pass; it
+//   needs twice the gap between the k-th and the kp-th score, which sr_dense_search tries first (dense_score.hip).
 #include "dense_filter.h"
 #include <math.h>
 
-double sr_filter_c(int H) { return ldexp(1.0, -9) * 1.004 + 1.25 * (3.0 * (double)H * ldexp(1.0, -24)) + 1.0e-5; }
+double sr_filter_c(int H, int products) {
+    return ldexp(1.0, products == 1 ? -8 : -9) * 1.004 + 1.25 * (3.0 * (double)H * ldexp(1.0, -24)) + 1.0e-5;
+}
 
 __global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ rows, int64_t n, int H, float* __restrict__ d_max2) {
     const int lane = threadIdx.x & 63;

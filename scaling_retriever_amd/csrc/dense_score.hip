@@ -402,6 +402,8 @@ struct sr_dense_index {
     int64_t fq_cap = 0;
     int fkp = 0;
     int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter / redone by the exact kernel
+    int filter_products = 1;                  // plane products of the filter's approximate pass (1, or 2 after a failed certificate)
+    int64_t n_downgrade = 0;
 };
 
 // bf16 planes of every segment a precision needs (the certified filter scores against plane 0 only)
@@ -409,6 +411,7 @@ static int planes_of(int precision) {
     return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : (precision == SR_PRECISION_FP32_FILTERED ? 1 : 0));
 }
 #define SR_PASS_FILTER 100   // dense_search_pass: the filter's 2-product pass, (q0 + q1) . d0
+#define SR_PASS_FILTER1 101  // the filter's 1-product pass, q0 . d0
 
 static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
     if (seg.n_planes >= want) return SR_OK;
@@ -546,9 +549,9 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if ((planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64) {
+    if ((planes_of(precision) || precision == SR_PASS_FILTER || precision == SR_PASS_FILTER1) && nq > 64) {
         // scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
-        const int np = precision == SR_PASS_FILTER ? 1 : planes_of(precision);
+        const int np = precision == SR_PASS_FILTER ? 1 : precision == SR_PASS_FILTER1 ? 0 : planes_of(precision);
         if (idx->q_cap < nq) {
             for (int p = 0; p < 3; ++p) {
                 if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
@@ -571,7 +574,10 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                 step = step * 2 < chunk ? step * 2 : chunk;
                 DenseSplitArgs a;
                 for (int p = 0; p < 3; ++p) { a.D[p] = seg.pl[p]; a.Q[p] = idx->qpl[p]; }
-                if (np == 1) {            // the certified filter: one doc plane against two query planes
+                if (np == 0) {            // the certified filter, cheapest form: one doc plane against one query plane
+                    a.n_pairs = 1;
+                    a.pair_d[0] = 0; a.pair_q[0] = 0;
+                } else if (np == 1) {     // the certified filter: one doc plane against two query planes
                     a.n_pairs = 2;
                     a.pair_d[0] = 0; a.pair_q[0] = 1;
                     a.pair_d[1] = 0; a.pair_q[1] = 0;
@@ -711,32 +717,42 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         idx->fq_cap = nq;
         idx->fkp = kp;
     }
-    const double c = sr_filter_c(idx->dim);
     SR_TRY(launch_query_norms(d_queries, nq, idx->dim, idx->qnorm, s));
-    SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
-    // 1. the kp best documents by S_a = (q0 + q1) . d0
-    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s));
-    // 2. exact scores of the candidates -> exact top-k
-    SR_TRY(idx->ws2.ensure(nq, k, kp));
-    SR_TRY(topk_reset(idx->ws2, nq, s));
     FilterSegs fs;
     fs.count = (int)idx->segs.size();
     for (int i = 0; i < fs.count; ++i) {
         fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
         fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
     }
-    SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, k, kp, idx->dim, c,
-                                 idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
-    SR_TRY(topk_compact(idx->ws2, nq, k, s));
-    SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
-    // 3. certificate against the k-th exact score
-    SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
-    // any query not certified -> the whole batch goes through the exact kernel (one small D2H per search)
+    // The approximate pass starts with ONE plane product, q0 . d0 (error bound 2^-8 |q| |d|); an index whose score gaps are
+    // too tight for that bound is switched - for good - to two products, (q0 + q1) . d0 (2^-9), and a batch that cannot be
+    // certified with those goes through the exact kernel.
+    if (const char* e = sr_dev_getenv("SR_FILTER_PRODUCTS")) idx->filter_products = atoi(e) >= 2 ? 2 : 1;
     std::vector<int> h((size_t)nq);
-    SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    SR_CHECK_HIP(hipStreamSynchronize(s));
-    for (int64_t q = 0; q < nq; ++q)
-        if (h[(size_t)q]) return SR_OK;
+    for (;;) {
+        const int products = idx->filter_products;
+        const double c = sr_filter_c(idx->dim, products);
+        SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
+        // 1. the kp best documents by the approximate score
+        SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, products == 1 ? SR_PASS_FILTER1 : SR_PASS_FILTER, s));
+        // 2. exact scores of the candidates -> exact top-k
+        SR_TRY(idx->ws2.ensure(nq, k, kp));
+        SR_TRY(topk_reset(idx->ws2, nq, s));
+        SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, k, kp, idx->dim, c,
+                                     idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
+        SR_TRY(topk_compact(idx->ws2, nq, k, s));
+        SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+        // 3. certificate against the k-th exact score
+        SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
+        // any query not certified -> the whole batch is redone (one small D2H per search)
+        SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        SR_CHECK_HIP(hipStreamSynchronize(s));
+        bool ok = true;
+        for (int64_t q = 0; q < nq && ok; ++q) ok = h[(size_t)q] == 0;
+        if (ok) break;
+        if (products == 1) { idx->filter_products = 2; ++idx->n_downgrade; continue; }
+        return SR_OK;
+    }
     *done = true;
     return SR_OK;
 }
@@ -760,6 +776,14 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
         return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, SR_PRECISION_FP32, s);
     }
     return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, idx->precision, s);
+}
+
+extern "C" int sr_dense_index_filter_products(sr_dense_index* idx, int* products, int64_t* n_raised) {
+    SR_REQUIRE(idx && products && n_raised, "sr_dense_index_filter_products: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *products = idx->filter_products;
+    *n_raised = idx->n_downgrade;
+    return SR_OK;
 }
 
 extern "C" int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback) {

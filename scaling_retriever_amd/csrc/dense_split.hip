@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int nkt = a.n_pairs * nk;      // >= 2 * (H / 64) >= 2
+    const int nkt = a.n_pairs * nk;      // >= 2 (checked at launch)
     mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
     auto load_w = [&](int st, int kk, int h, mfma_bf16x8 (&wf)[HB]) {
         const unsigned char* wt = smem + st * STAGE_BYTES;
@@ -248,7 +248,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     const int64_t rows = a.row_end - a.row_begin;
     if (rows <= 0) return SR_OK;
     SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
-    SR_REQUIRE(a.n_pairs >= 2 && a.n_pairs <= 6, "dense_split: bad plane-pair count %d", a.n_pairs);
+    SR_REQUIRE(a.n_pairs >= 1 && a.n_pairs <= 6 && a.n_pairs * (a.H / 64) >= 2, "dense_split: bad plane-pair count %d", a.n_pairs);
     constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128;
     static DeviceOnce attr_once;
     bool* attr_slot = attr_once.pending();

@@ -147,7 +147,7 @@ class DenseIndexHIP:
 
     def set_precision(self, mode):
         """"fp32" (default: the exact kernel), "fp32_filtered" (the same results bit for bit through a certified bf16 filter +
-        exact re-score, ~3x faster for batches > 64 queries, two bf16 planes of the corpus in HBM), "bf16x3" / "bf16x6"
+        exact re-score, ~7x faster for batches > 64 queries, one bf16 plane of the corpus in HBM), "bf16x3" / "bf16x6"
         (split-bf16 scores, not bit-identical)."""
         code = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp32_filtered": 3}[mode]
         with torch.cuda.device(self.device):
@@ -157,6 +157,12 @@ class DenseIndexHIP:
         """(searches answered through the certified filter, searches redone by the exact kernel)."""
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(self.lib.sr_dense_index_filter_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def filter_products(self):
+        """(plane products of the filter's approximate pass now: 1 or 2, times a failed certificate raised it)."""
+        a, b = ctypes.c_int(0), ctypes.c_int64(0)
+        _lib.check(self.lib.sr_dense_index_filter_products(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def search(self, queries, k):

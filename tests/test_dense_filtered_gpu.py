@@ -81,6 +81,44 @@ def test_filtered_falls_back_when_it_cannot_certify():
     assert filt.filter_stats() == (0, 1)
 
 
+def test_filter_raises_its_plane_products_when_one_is_not_enough():
+    """Score gaps between rank k and rank kp that the one-product bound (2^-8 |q||d|) cannot separate but the two-product
+    bound (2^-9) can: the first search fails its certificate once, switches the index to two products for good, and is
+    answered by the filter - identical to the exact kernel - without the exact kernel running."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(21)
+    H, N, nq, k = 256, 30000, 100, 100                       # kp = k + 2048
+    c = 2.0 ** -9 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
+    c1 = c + 2.0 ** -9 * 1.004
+    # every document = s_i * u + small noise, queries = u: scores = s_i |u|^2 (+ noise), descending in i with a relative step
+    # chosen so that the gap between rank k and rank kp is 1.5 c |q|: above E = c |q| (two products certify), below
+    # E1 = c1 |q| ~ 2 c |q| (one product does not)
+    u = rng.standard_normal(H).astype(np.float32)
+    u /= np.linalg.norm(u)
+    kp = k + 2048
+    assert c < 1.5 * c < c1
+    step = 1.5 * c / (kp - k)
+    s = (1.0 - step * np.arange(N)).astype(np.float32)
+    s[s < 0.2] = 0.2
+    D = (s[:, None] * u[None, :]).astype(np.float32)
+    Q = np.repeat(u[None, :], nq, axis=0).astype(np.float32) * rng.uniform(0.5, 2.0, size=(nq, 1)).astype(np.float32)
+    exact = DenseIndexHIP(H)
+    exact.add_host_rows(D)
+    filt = DenseIndexHIP(H)
+    filt.set_precision("fp32_filtered")
+    filt.add_host_rows(D)
+    q = torch.from_numpy(Q).cuda()
+    es, ei = exact.search(q, k)
+    assert filt.filter_products() == (1, 0)
+    fs, fi = filt.search(q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_products() == (2, 1), filt.filter_products()
+    assert filt.filter_stats() == (1, 0)
+    fs, fi = filt.search(q, k)                                # stays on two products
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_products() == (2, 1) and filt.filter_stats() == (2, 0)
+
+
 def test_filtered_small_index_and_small_batches():
     """Fewer documents than candidates (every document is re-scored), fewer than k documents (padding), and batches of <= 64
     queries, which the streaming kernel answers in its own k order whatever the mode."""
@@ -101,13 +139,14 @@ def test_filtered_small_index_and_small_batches():
 
 def test_filter_error_bound_dominates_the_filter_score():
     """The certificate's E = c(H) |q| |d| must dominate |S_a - S_x| for S_a = (q0 + q1) . d0 (two bf16 planes of the query, one
-    of the document).  S_a is restated in float64 from the planes (the MFMA's fp32 accumulation adds at most what the bound
+    of the document) and, with c1(H), for S_a = q0 . d0 (the one-product pass tried first).  S_a is restated in float64 from the planes (the MFMA's fp32 accumulation adds at most what the bound
     reserves for it and is checked on the device for every re-scored pair), S_x comes from the exact kernel; Gaussian,
     same-sign and adversarially aligned data (every rounding error pushed the same way)."""
     from scaling_retriever_amd.scoring import DenseIndexHIP
     rng = np.random.default_rng(11)
     for H in (256, 2048):
         c = 2.0 ** -9 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
+        c1 = 2.0 ** -8 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
         for kind in ("gauss", "same_sign", "aligned"):
             D = rng.standard_normal((2000, H), dtype=np.float32)
             Q = rng.standard_normal((128, H), dtype=np.float32)
@@ -126,5 +165,6 @@ def test_filter_error_bound_dominates_the_filter_score():
             sa = (q0.double() + q1.double()) @ d0.T
             bound = torch.from_numpy(np.linalg.norm(Q, axis=1)[:, None] * np.linalg.norm(D, axis=1)[None, :]).cuda()
             worst = float(((ex - sa).abs() / bound).max())
-            print(f"H {H} {kind}: max |S_a - S_x| / (|q||d|) = {worst:.2e}, bound c = {c:.2e}")
-            assert worst < c
+            worst1 = float(((ex - q0.double() @ d0.T).abs() / bound).max())
+            print(f"H {H} {kind}: max |S_a - S_x| / (|q||d|) = {worst:.2e} (bound c = {c:.2e}); one product {worst1:.2e} (c1 = {c1:.2e})")
+            assert worst < c and worst1 < c1
