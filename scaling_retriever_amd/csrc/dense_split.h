@@ -13,6 +13,8 @@ struct DenseSplitArgs {
     int* cand_count;
     int64_t cand_cap;
     uint32_t id_base, id_stride;
+    // filled by launch_dense_split: workgroup -> tile mapping (dense_split.hip split_tile_of)
+    int xcd_order, grid_qt, grid_dt, grid_bq, grid_bd, grid_nbq;
 };
 // p1 and p2 may be null (fewer planes)
 int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, unsigned short* p2, int64_t n_elems, hipStream_t s);

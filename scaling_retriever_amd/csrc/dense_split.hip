@@ -52,30 +52,88 @@ int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, 
     return SR_OK;
 }
 
-// ---- scoring kernel ----------------------------------------------------------------------------------
-#ifndef SP_ORDER
-#define SP_ORDER 1
-#endif
 #define SP_BN 256   // docs per workgroup
 #define SP_BM 256   // queries per workgroup
+// ---- epilogue: lane = query (frow + 16 j), registers = docs (16 i + 4 fg + r): tau filter, survivors as 64-bit keys ----
+template <int NB, int MB>
+__device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, const f32x4 (&acc)[NB][MB], int64_t row0, int q0, int wn, int wm,
+                                               int frow, int fg) {
+    const int64_t left = a.row_end - row0;
+    const int rows_valid = left < SP_BN ? (int)left : SP_BN;
+    const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int q = q0 + wm * MB * 16 + j * 16 + frow;
+        if (q >= a.nq) continue;
+        const float tq = a.tau[q];
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
+                cnt += (lr < rows_valid && acc[i][j][r] >= tq) ? 1 : 0;
+            }
+        if (cnt == 0) continue;
+        int pos = atomicAdd(&a.cand_count[q], cnt);
+        uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
+                const float sc = acc[i][j][r];
+                if (lr < rows_valid && sc >= tq) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
+                    ++pos;
+                }
+            }
+    }
+}
+
+// Workgroup -> (doc tile, query tile).  1-D grid; workgroups are dealt to the 8 XCDs round-robin by their linear id, every XCD
+// has its own 4 MB L2, and 256 workgroups are resident at a time (one per CU), 32 per XCD.  xcd_order: the 32 workgroups an XCD
+// runs together form a block of 8 doc tiles x 4 query tiles (12 operand tiles behind 32 output tiles - in query-tile-fastest
+// linear order they touch ~9 doc tiles and most of the query tiles), blocks walked query-block fastest so that a doc tile is
+// fetched from HBM once and the query planes stay in the Infinity Cache.  Without it: query tile fastest.
+struct SplitGrid { int qt, dt, bq, bd, nbq, total; };
+static inline SplitGrid split_grid(int64_t rows, int nq, int xcd_order) {
+    SplitGrid g;
+    g.qt = (int)ceil_div64(nq, SP_BM);
+    g.dt = (int)ceil_div64(rows, SP_BN);
+    g.bq = !xcd_order ? 1 : (g.qt % 4 == 0 ? 4 : g.qt % 2 == 0 ? 2 : 1);
+    g.bd = 32 / g.bq;
+    g.nbq = g.qt / g.bq;
+    g.total = !xcd_order ? g.qt * g.dt : (int)(ceil_div64((int64_t)g.nbq * ceil_div64(g.dt, g.bd) * 32, 256) * 256);
+    return g;
+}
+__device__ __forceinline__ bool split_tile_of(const DenseSplitArgs& a, int& d_tile, int& q_tile) {
+    const int lin = (int)blockIdx.x;
+    if (!a.xcd_order) {
+        q_tile = lin % a.grid_qt;
+        d_tile = lin / a.grid_qt;
+        return true;
+    }
+    const int s = lin >> 3;
+    const int c = (s >> 5) * 256 + (lin & 7) * 32 + (s & 31);      // XCD x of a round: compact indices [256 r + 32 x, + 32)
+    const int blk = c >> 5, w2 = c & 31;
+    const int bd_i = blk / a.grid_nbq, bq_i = blk - bd_i * a.grid_nbq;
+    d_tile = bd_i * a.grid_bd + w2 / a.grid_bq;
+    q_tile = bq_i * a.grid_bq + w2 % a.grid_bq;
+    return d_tile < a.grid_dt;
+}
+
+// ---- scoring kernel ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     constexpr int NB = 8, MB = 4, WAVES_M = 4, HB = NB / 2;   // wave tile: 128 docs x 64 queries
     constexpr int W_BYTES = SP_BN * 128, STAGE_BYTES = (SP_BN + SP_BM) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-    // Workgroup order.  SP_ORDER 1 (default): query tile fastest - the ~256 resident workgroups are all the query tiles of
-    // a handful of doc tiles, so a doc tile (3 MB of plane rows) is fetched from HBM once and then shared through L2 /
-    // Infinity Cache by its 28 query tiles, and the query planes (84 MB at 6 980 queries) stay in the Infinity Cache.
-    // SP_ORDER 0: doc tile fastest - every resident workgroup streams a doc tile of its own, each of which is read again
-    // by every other query tile later (28 x 268 MB per launch).
-#if SP_ORDER
-    const int64_t row0 = a.row_begin + (int64_t)blockIdx.y * SP_BN;
-    const int q0 = blockIdx.x * SP_BM;
-#else
-    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * SP_BN;
-    const int q0 = blockIdx.y * SP_BM;
-#endif
+    int d_tile, q_tile;
+    if (!split_tile_of(a, d_tile, q_tile)) return;
+    const int64_t row0 = a.row_begin + (int64_t)d_tile * SP_BN;
+    const int q0 = q_tile * SP_BM;
     const int H = a.H;
 
     const int srow = lane >> 3;
@@ -210,38 +268,125 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     }
 #undef SR_MFMA_HALF
 
-    // ---- epilogue: lane = query (frow + 16 j), registers = docs (16 i + 4 fg + r) --------------------
-    const int64_t left = a.row_end - row0;
-    const int rows_valid = left < SP_BN ? (int)left : SP_BN;
-    const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+    split_epilogue<NB, MB>(a, acc, row0, q0, wn, wm, frow, fg);
+}
+
+// ---- the same kernel with BK = 32 and FOUR LDS stages ----------------------------------------------------------------
+// 2 x 64 KB stages leave the LDS-DMA of k-step kt + 2 one k-step (~2 000 MFMA cycles) to land; here a stage is 32 KB, the DMA
+// of k-step kt + 3 is issued three (half-length) steps ahead, and the wait before the barrier is a counted vmcnt(4): only
+// the stage that is needed next has to be complete.  Tile rows are 64 B (32 bf16) with the 16-byte chunks XOR-swizzled by
+// (row >> 1) & 3 on the source side of the DMA, which makes the ds_read_b128 fragment reads conflict-free per 8 lanes.
+// Twice the barriers per K.  Dev switch SR_SPLIT_K32 (A/B against dense_split_kernel; same products in the same order,
+// bit-identical scores).
+__global__ __launch_bounds__(512, 2) void dense_split_kernel_k32(DenseSplitArgs a) {
+    constexpr int NB = 8, MB = 4, WAVES_M = 4, HB = NB / 2;   // wave tile: 128 docs x 64 queries
+    constexpr int ROWB = 64;
+    constexpr int W_BYTES = SP_BN * ROWB, STAGE_BYTES = (SP_BN + SP_BM) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+    int d_tile, q_tile;
+    if (!split_tile_of(a, d_tile, q_tile)) return;
+    const int64_t row0 = a.row_begin + (int64_t)d_tile * SP_BN;
+    const int q0 = q_tile * SP_BM;
+    const int H = a.H;
+    // one LDS-DMA instruction = 64 lanes x 16 B = 16 rows of 64 B; wave w stages rows [32 w, 32 w + 32) of both tiles
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((srow >> 1) & 3);
+    int64_t doff[2], qoff[2];
 #pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        const int q = q0 + wm * MB * 16 + j * 16 + frow;
-        if (q >= a.nq) continue;
-        const float tq = a.tau[q];
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
-                cnt += (lr < rows_valid && acc[i][j][r] >= tq) ? 1 : 0;
-            }
-        if (cnt == 0) continue;
-        int pos = atomicAdd(&a.cand_count[q], cnt);
-        uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
-                const float sc = acc[i][j][r];
-                if (lr < rows_valid && sc >= tq) {
-                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
-                    ++pos;
-                }
-            }
+    for (int i = 0; i < 2; ++i) {
+        int64_t rn = row0 + wave * 32 + i * 16 + srow;
+        rn = rn < a.row_end ? rn : a.row_end - 1;
+        doff[i] = rn * H + schunk * 8;
+        int rq = q0 + wave * 32 + i * 16 + srow;
+        rq = rq < a.nq ? rq : a.nq - 1;
+        qoff[i] = (int64_t)rq * H + schunk * 8;
     }
+    int st_pair = 0, st_k0 = 0;
+    const unsigned short* st_d = a.D[a.pair_d[0]];
+    const unsigned short* st_q = a.Q[a.pair_q[0]];
+    auto stage = [&](int st) {     // the next k-step in order
+        unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 2) * 1024;
+        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 2) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + doff[i] + st_k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + qoff[i] + st_k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+        st_k0 += 32;
+        if (st_k0 == H) {
+            st_k0 = 0;
+            ++st_pair;
+            if (st_pair < a.n_pairs) {
+                st_d = a.D[a.pair_d[st_pair]];
+                st_q = a.Q[a.pair_q[st_pair]];
+            }
+        }
+    };
+    f32x4 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fg = lane >> 4;
+    const int pos = (fg ^ ((frow >> 1) & 3)) * 16;
+    const int nkt = a.n_pairs * (H / 32);     // even, >= 2
+    mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
+    auto load_w = [&](int st, int h, mfma_bf16x8 (&wf)[HB]) {
+        const unsigned char* wt = smem + st * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+            wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + (h * HB + i) * 16 + frow) * ROWB + pos);
+    };
+    auto load_a = [&](int st, mfma_bf16x8 (&af)[MB]) {
+        const unsigned char* at = smem + st * STAGE_BYTES + W_BYTES;
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+            af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * ROWB + pos);
+    };
+#define SR_MFMA_HALF(HH, WF, AF)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                        \
+            acc[(HH) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(HH) * HB + i][j], 0, 0, 0);
+    // k-step kt: AC holds its query fragments, AN receives those of kt + 1.  WAIT: vmcnt count that leaves only younger
+    // stages outstanding.
+#define SR_K32_STEP(KT, AC, AN, WAIT)                                                                         \
+    {                                                                                                         \
+        const int kt_ = (KT);                                                                                 \
+        const int buf = kt_ & 3;                                                                              \
+        load_w(buf, 1, wy);                                                                                   \
+        SR_MFMA_HALF(0, wx, AC)                                                                               \
+        asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                              \
+        __syncthreads();                                                                                      \
+        if (kt_ + 1 < nkt) {                                                                                  \
+            load_w((kt_ + 1) & 3, 0, wx);                                                                     \
+            load_a((kt_ + 1) & 3, AN);                                                                        \
+        }                                                                                                     \
+        if (kt_ + 3 < nkt) stage((kt_ + 3) & 3);                                                              \
+        SR_MFMA_HALF(1, wy, AC)                                                                               \
+    }
+    stage(0);
+    stage(1);
+    if (nkt > 2) stage(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_w(0, 0, wx);
+    load_a(0, a0);
+    int kt = 0;
+    // steady state: at the wait, stages kt + 1 and kt + 2 are outstanding (4 DMA instructions per wave each)
+    for (; kt + 4 < nkt; kt += 2) {
+        SR_K32_STEP(kt, a0, a1, 4)
+        SR_K32_STEP(kt + 1, a1, a0, 4)
+    }
+    for (; kt < nkt; kt += 2) {           // nkt is even (H is a multiple of 64): the last 2 or 4 k-steps drain everything
+        SR_K32_STEP(kt, a0, a1, 0)
+        SR_K32_STEP(kt + 1, a1, a0, 0)
+    }
+#undef SR_K32_STEP
+#undef SR_MFMA_HALF
+    split_epilogue<NB, MB>(a, acc, row0, q0, wn, wm, frow, fg);
 }
 
 int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
@@ -257,13 +402,24 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         *attr_slot = true;
     }
-#if SP_ORDER
-    const dim3 grid((unsigned)ceil_div64(a.nq, SP_BM), (unsigned)ceil_div64(rows, SP_BN));
-#else
-    const dim3 grid((unsigned)ceil_div64(rows, SP_BN), (unsigned)ceil_div64(a.nq, SP_BM));
-#endif
-    SR_REQUIRE(grid.y <= 65535, "dense_split: launch of %lld rows x %d queries exceeds the grid", (long long)rows, a.nq);
-    hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, a);
+    DenseSplitArgs b = a;
+    b.xcd_order = 1;
+    if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
+    const SplitGrid sg = split_grid(rows, a.nq, b.xcd_order);
+    b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq;
+    const dim3 grid((unsigned)sg.total);
+    static const bool k32 = [] { const char* e = sr_dev_getenv("SR_SPLIT_K32"); return e && atoi(e) != 0; }();
+    if (k32) {
+        static DeviceOnce attr32;
+        if (bool* slot = attr32.pending()) {
+            SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel_k32),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            *slot = true;
+        }
+        hipLaunchKernelGGL(dense_split_kernel_k32, grid, dim3(512), lds, s, b);
+    } else {
+        hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, b);
+    }
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -66,8 +66,43 @@ void gemm_bf16_kernel(GemmArgs g) {
     const int schunk = (lane & 7) ^ (srow & 7);       // source 16-B chunk (swizzle on the source)
     const bf16_t* wsrc[W_INSTR];
     const bf16_t* asrc[A_INSTR];
+    // ---- slot -> tile.  A workgroup takes slots blockIdx.x, blockIdx.x + G, ...  Workgroups are dealt to the 8 XCDs
+    // round-robin (XCD = blockIdx.x % 8), and every XCD has its own 4 MB L2.  In the plain feature-tile-fastest order the G / 8
+    // tiles an XCD works on at a time are G / 8 DIFFERENT token tiles of one feature tile (N = 2048: 8 feature tiles, slot
+    // % 8 = XCD), so only the W half of the staged bytes can hit in its L2 and every token tile is fetched into all 8 L2s.
+    // xcd_order deals each XCD a compact block of bmt x bnt tiles (bmt * bnt = G / 8; 4 x 8 at G = 256): 12 operand tiles
+    // behind 32 output tiles instead of 33.  Only which workgroup computes which tile changes - not a bit of the result.
+    const int G = (int)gridDim.x;
+    const bool swz = g.xcd_order && !g.m_fastest && (G & 7) == 0;
+    auto fits = [&](int b) { return tiles_n % b == 0 && (G / 8) % b == 0; };
+    const int bnt = !swz ? 1 : (fits(8) ? 8 : fits(4) ? 4 : fits(2) ? 2 : 1);
+    const int bmt = !swz ? 1 : (G / 8) / bnt;
+    const int slot_limit = !swz ? n_tiles : ((((tiles_m + bmt - 1) / bmt) * bmt * tiles_n + G - 1) / G) * G;
+    auto slot_tile = [&](int slot, int& tn, int& tm) -> bool {
+        if (!swz) {
+            tn = g.m_fastest ? slot / tiles_m : slot % tiles_n;
+            tm = g.m_fastest ? slot % tiles_m : slot / tiles_n;
+            return true;
+        }
+        const int r = slot / G, w = slot - r * G;
+        const int c = r * G + (w & 7) * (G >> 3) + (w >> 3);      // XCD x of round r: compact indices [r G + x G/8, + G/8)
+        const int per = bmt * bnt, blk = c / per, w2 = c - blk * per;
+        const int nbn = tiles_n / bnt, bm = blk / nbn, bn = blk - bm * nbn;
+        tm = bm * bmt + w2 / bnt;
+        tn = bn * bnt + w2 % bnt;
+        return tm < tiles_m;
+    };
+    auto next_slot = [&](int slot) {      // first slot >= `slot` of this workgroup that holds a tile; slot_limit when none
+        for (; slot < slot_limit; slot += G) {
+            int tn, tm;
+            if (slot_tile(slot, tn, tm)) break;
+        }
+        return slot < slot_limit ? slot : slot_limit;
+    };
     auto set_tile = [&](int tile) {
-        const int tn0 = (g.m_fastest ? tile / tiles_m : tile % tiles_n) * BN, tm0 = (g.m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
+        int tn_i, tm_i;
+        (void)slot_tile(tile, tn_i, tm_i);
+        const int tn0 = tn_i * BN, tm0 = tm_i * BM;
 #pragma unroll
         for (int i = 0; i < W_INSTR; ++i) {
             int rn = tn0 + (wave * W_INSTR + i) * 8 + srow;
@@ -95,8 +130,8 @@ void gemm_bf16_kernel(GemmArgs g) {
     f32x4 acc[NB][MB];
     const int frow = lane & 15, fg = lane >> 4;
     const int nk = K / G_BK;
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+    int tile = next_slot((int)blockIdx.x);
+    if (tile >= slot_limit) return;
     const bool stamp = g.stamps != nullptr && tid == 0;
     unsigned long long* stp = g.stamps ? g.stamps + (size_t)blockIdx.x * 64 : nullptr;   // up to 16 tiles x 4 stamps
     int titer = 0;
@@ -130,9 +165,12 @@ void gemm_bf16_kernel(GemmArgs g) {
     };
     // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile(s) of the NEXT output tile are
     // prefetched during the last k-step(s) of the current one, so only the epilogue's stores stay exposed between tiles.
-    for (; tile < n_tiles; tile += gridDim.x) {
-    const int n0 = (g.m_fastest ? tile / tiles_m : tile % tiles_n) * BN, m0 = (g.m_fastest ? tile % tiles_m : tile / tiles_n) * BM;
-    const bool has_next = tile + (int)gridDim.x < n_tiles;
+    for (; tile < slot_limit;) {
+    int tn_i, tm_i;
+    (void)slot_tile(tile, tn_i, tm_i);
+    const int n0 = tn_i * BN, m0 = tm_i * BM;
+    const int tile_next = next_slot(tile + G);
+    const bool has_next = tile_next < slot_limit;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -313,7 +351,7 @@ void gemm_bf16_kernel(GemmArgs g) {
             if (kt + 2 < nk) {
                 stage(buf, (kt + 2) * G_BK);
             } else if (has_next) {
-                if (kt + 2 == nk) set_tile(tile + gridDim.x);
+                if (kt + 2 == nk) set_tile(tile_next);
                 stage(buf, (kt + 2 - nk) * G_BK);
             }
             if (kt + 1 < nk) {
@@ -329,7 +367,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         if (kt + 1 < nk) {
             stage(buf ^ 1, (kt + 1) * G_BK);
         } else if (CROSS_PREFETCH && has_next) {
-            set_tile(tile + gridDim.x);
+            set_tile(tile_next);
             stage(buf ^ 1, 0);
         }
         mfma_bf16x8 wf[NB], af[MB];
@@ -569,13 +607,14 @@ void gemm_bf16_kernel(GemmArgs g) {
     if constexpr (PIPE && NS > 2) {
         if (has_next) {                 // no cross-tile prefetch with NS stages: stage the next tile's first k-steps now
             __syncthreads();
-            set_tile(tile + gridDim.x);
+            set_tile(tile_next);
 #pragma unroll
             for (int st = 0; st < NS; ++st) stage(st, st * G_BK);
             __syncthreads();
             buf = 0;
         }
     }
+    tile = tile_next;
     }  // tile loop
 }
 
@@ -596,6 +635,8 @@ static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     // token tiles fastest instead, so that a W tile is used by all of them while it is hot and W is read once.
     g.m_fastest = ((int64_t)g.N * g.K * 2 > (128ll << 20) && (int64_t)g.N > 4 * (int64_t)g.M) ? 1 : 0;
     if (const char* e = sr_dev_getenv("SR_GEMM_MFAST")) g.m_fastest = atoi(e);     // A/B switch
+    g.xcd_order = 1;
+    if (const char* e = sr_dev_getenv("SR_GEMM_XCD")) g.xcd_order = atoi(e);       // A/B switch
     int64_t tiles = ceil_div64(g.N, BN) * ceil_div64(g.M, BM);
     const char* env = sr_dev_getenv("SR_GEMM_PERSIST");            // A/B switch: 0 = one workgroup per tile
     // resident workgroups on 256 CUs: one 8-wave workgroup, up to 3 of 4 waves, up to 8 single-wave ones (LDS permitting)

@@ -63,6 +63,8 @@ struct GemmArgs {
     const float* w_scale;   // _H epilogues: [N] inverse scale of each weight row
     SplitMap out_map;  // EPI_SWIGLU_SPLIT: plane of each output segment; C is [M, n_seg * N/2] bf16
     int m_fastest;     // tile order, chosen by launch_gemm_bf16: 1 = token tiles fastest (W far larger than the caches)
+    int xcd_order;     // 1: the workgroups of one XCD (blockIdx % 8) work on a compact block of tiles, so that its L2 serves
+                       // most operand rows (see gemm_bf16.hip); ignored with m_fastest
 };
 
 // y = A @ W^T with fused epilogue. Requirements: K % 64 == 0, N % 16 == 0 (N % 32 for SWIGLU),

@@ -445,6 +445,32 @@ def test_gemm_tile_plan_does_not_change_the_result(monkeypatch):
         assert torch.equal(_gemm(A, W, 4), auto), tile
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 512), (9600, 3072, 256), (5000, 768, 256), (70000, 2048, 128), (2048, 16384, 256)])
+def test_gemm_xcd_aware_tile_order_covers_every_tile_once(M, N, K, monkeypatch):
+    """The XCD-aware order only changes WHICH workgroup computes a tile (compact blocks of tiles per XCD, padded slots at the
+    ragged edge skipped): every output element must come out, bit for bit, as with the plain order - for tile grids whose
+    feature-tile count is a multiple of 8, of 4 (12), odd (3), and for more rounds than one."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    L, lib = _lib()
+
+    def run():       # into a NaN-filled buffer: a tile nobody computed cannot go unnoticed
+        C = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()), "sr_gemm_bf16")
+        torch.cuda.synchronize()
+        return C
+
+    for tile in ("256", "128", ""):
+        monkeypatch.setenv("SR_GEMM_TILE", tile)
+        monkeypatch.setenv("SR_GEMM_XCD", "0")
+        plain = run()
+        assert not torch.isnan(plain).any()
+        monkeypatch.setenv("SR_GEMM_XCD", "1")
+        assert torch.equal(run(), plain), tile
+    torch.testing.assert_close(plain[:512], A[:512].float() @ W.float().T, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("M", [1, 9, 16, 17, 33, 64])
 def test_gemm_few_token_rows_streaming_configuration(M, monkeypatch):
     """Up to 64 token rows (online queries) run single-wave workgroups that stream W; every output element is the same
