@@ -112,10 +112,131 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnF32Args a) {
     }
 }
 
+// The same attention with ONE workgroup per (sequence, KV head, block of 16 q rows): wave w serves q head kvh * G + w, all
+// 16 rows of the block four at a time, and the G waves share the staged K chunk; with head_dim 64 the V chunk is staged next
+// to it, so that P.V no longer waits for one dependent global load per key (the critical path of the kernel above on the
+// ~9-token sequences of the query side: query encode 362 -> 355 ms; grouping the heads alone changed nothing).  Same
+// arithmetic per (row, head) as the kernel above (same chunking, same summation order): bit-identical outputs.
+template <int HD, int G>
+__global__ __launch_bounds__(64 * G) void attention_f32_gqa_kernel(AttnF32Args a) {
+    constexpr int DPL = HD / 64;
+    constexpr bool V_LDS = HD <= 64;                 // the V chunk too, while both fit the 64 KB of static LDS
+    __shared__ float Ks[AF_KC][HD + 1];
+    __shared__ float Vs[V_LDS ? AF_KC : 1][V_LDS ? HD : 1];
+    __shared__ float qs[G][HD];
+    __shared__ float ps[G][AF_KC];
+    __shared__ unsigned char kval[AF_KC];
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = kvh * G + wave;
+    const int t0 = a.cu_seqlens[b];
+    const int S = a.cu_seqlens[b + 1] - t0;
+    const int r0 = blockIdx.z * AF_ROWS;
+    if (r0 >= S) return;
+    const int ld = (a.nh + 2 * a.nkv) * HD;
+    const int koff = a.nh * HD + kvh * HD, voff = (a.nh + a.nkv) * HD + kvh * HD;
+    const int nrows = (S - r0) < AF_ROWS ? (S - r0) : AF_ROWS;
+    const int64_t ldo = (int64_t)a.out_map.n_seg * a.nh * HD;
+    // four q rows at a time (their running max / sum / output stay in registers); the K chunk is staged again for every
+    // group of four - a few hundred floats for the sequences this kernel is for
+    for (int rq = 0; rq < nrows; rq += AF_RPW) {
+        float m[AF_RPW], l[AF_RPW], o[AF_RPW][DPL];
+#pragma unroll
+        for (int r = 0; r < AF_RPW; ++r) {
+            m[r] = -INFINITY;
+            l[r] = 0.f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) o[r][e] = 0.f;
+        }
+        for (int k0 = 0; k0 < S; k0 += AF_KC) {
+            const int nk = (S - k0) < AF_KC ? (S - k0) : AF_KC;
+            __syncthreads();                              // previous chunk fully consumed
+            for (int i = tid; i < nk * HD; i += 64 * G) {
+                const int k = i / HD, d = i % HD;
+                Ks[k][d] = a.qkv[(int64_t)(t0 + k0 + k) * ld + koff + d];
+                if constexpr (V_LDS) Vs[k][d] = a.qkv[(int64_t)(t0 + k0 + k) * ld + voff + d];
+            }
+            if (tid < AF_KC) kval[tid] = (tid < nk) ? a.key_valid[t0 + k0 + tid] : 0;
+            __syncthreads();
+            const bool valid = kval[lane] != 0;
+#pragma unroll
+            for (int r = 0; r < AF_RPW; ++r) {
+                const int row = rq + r;                 // workgroup-uniform
+                if (row >= nrows) break;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) qs[wave][lane + 64 * e] = a.qkv[(int64_t)(t0 + r0 + row) * ld + h * HD + lane + 64 * e];
+                __builtin_amdgcn_wave_barrier();        // the wave's own row: LDS operations of one wave execute in order
+                float s = 0.f;
+                for (int d = 0; d < HD; ++d) s += qs[wave][d] * Ks[lane][d];
+                s = valid ? s * a.scale : -INFINITY;
+                float mx = s;
+                for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                if (mx == -INFINITY) continue;          // every key of this chunk is masked
+                const float m_new = fmaxf(m[r], mx);
+                const float corr = expf(m[r] - m_new);
+                const float p = valid ? expf(s - m_new) : 0.f;
+                float sum = p;
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                l[r] = l[r] * corr + sum;
+                m[r] = m_new;
+                ps[wave][lane] = p;
+                __builtin_amdgcn_wave_barrier();
+                float acc[DPL];
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
+                for (int k = 0; k < nk; ++k) {
+                    const float pk = ps[wave][k];
+                    if constexpr (V_LDS) {               // one dependent global load per key was the kernel's critical path
+                        acc[0] += pk * Vs[k][lane];
+                    } else {
+                        const float* vrow = a.qkv + (int64_t)(t0 + k0 + k) * ld + voff;
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e) acc[e] += pk * vrow[lane + 64 * e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) o[r][e] = o[r][e] * corr + acc[e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < AF_RPW; ++r) {
+            const int row = rq + r;
+            if (row >= nrows) break;
+            const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+            if (a.out_f32) {
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) a.out_f32[(int64_t)(t0 + r0 + row) * a.nh * HD + h * HD + lane + 64 * e] = o[r][e] * inv;
+                continue;
+            }
+            bf16_t* orow = a.out + (int64_t)(t0 + r0 + row) * ldo;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) {
+                unsigned short p[3];
+                split_bf16x3(o[r][e] * inv, p[0], p[1], p[2]);
+                const int col = h * HD + lane + 64 * e;
+                for (int sg = 0; sg < a.out_map.n_seg; ++sg) orow[(int64_t)sg * a.nh * HD + col] = p[a.out_map.plane[sg]];
+            }
+        }
+    }
+}
+
 int launch_attention_f32(const AttnF32Args& a, hipStream_t s) {
     SR_REQUIRE(a.nh % a.nkv == 0, "attention(fp32): num_heads %d not a multiple of num_kv_heads %d", a.nh, a.nkv);
     SR_REQUIRE(a.out_f32 || (a.out_map.n_seg >= 1 && a.out_map.n_seg <= SR_MAX_SEG), "attention(fp32): bad segment map");
     if (a.B == 0 || a.max_seqlen <= 0) return SR_OK;
+    const int G = a.nh / a.nkv;
+    const char* env = sr_dev_getenv("SR_ATTN_F32_GQA");       // A/B switch: 0 = one workgroup per q head
+    if (G == 4 && !(env && *env == '0')) {
+        const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)ceil_div64(a.max_seqlen, AF_ROWS)), block(256);
+        SR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "attention(fp32): grid too large");
+        switch (a.hd) {
+            case 64: hipLaunchKernelGGL((attention_f32_gqa_kernel<64, 4>), grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL((attention_f32_gqa_kernel<128, 4>), grid, block, 0, s, a); break;
+            default: sr_set_error("attention(fp32): head_dim %d not supported (64 or 128)", a.hd); return SR_ERR_UNSUPPORTED;
+        }
+        SR_CHECK_LAUNCH();
+        return SR_OK;
+    }
     const dim3 grid((unsigned)a.B, (unsigned)a.nh, (unsigned)ceil_div64(a.max_seqlen, AF_ROWS)), block(256);
     SR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "attention(fp32): grid too large");
     switch (a.hd) {
