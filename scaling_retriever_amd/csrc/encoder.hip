@@ -419,6 +419,73 @@ __global__ __launch_bounds__(256) void rows_split_h_kernel(float* __restrict__ x
     }
 }
 
+// The same with the row held in registers between the passes (NV float4 per lane, K = 256 NV): one read of the row instead of
+// up to three (sum of squares, maximum, split) - the row-split passes were 10 % of a fp32-regime query encode.
+template <int NV>
+__global__ __launch_bounds__(256) void rows_split_h_reg_kernel(float* __restrict__ x, const float* __restrict__ embed,
+                                                               const int* __restrict__ tok_id, const float* __restrict__ w,
+                                                               bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, float eps) {
+    constexpr int K = 256 * NV;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float* xr = x + (int64_t)t * K;
+    const float* src = embed ? embed + (int64_t)tok_id[t] * K : xr;
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + lane * 4 + 256 * j);
+    if (w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+            if (embed) *reinterpret_cast<f32x4*>(xr + lane * 4 + 256 * j) = v[j];
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float rs = 1.0f / sqrtf(ss / (float)K + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(w + lane * 4 + 256 * j);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[j][c] = (v[j][c] * rs) * g[c];
+        }
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(v[j][c]));
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float sc = row_scale_pow2(mx);
+    if (lane == 0) a_inv[t] = 1.0f / sc;
+    bf16_t* orow = xs + (int64_t)t * K * 3;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        bf16x4 p0, p1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned short f0, f1;
+            split_f16x2(v[j][c] * sc, f0, f1);
+            p0[c] = (short)f0; p1[c] = (short)f1;
+        }
+        const int i = lane * 4 + 256 * j;
+        *reinterpret_cast<bf16x4*>(orow + i) = p1;
+        *reinterpret_cast<bf16x4*>(orow + K + i) = p0;
+        *reinterpret_cast<bf16x4*>(orow + 2 * K + i) = p0;
+    }
+}
+
+static void launch_rows_split_h(float* x, const float* embed, const int* tok, const float* w, bf16_t* xs, float* inv, int T, int K,
+                                float eps, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
+    switch (K) {
+        case 2048: hipLaunchKernelGGL(rows_split_h_reg_kernel<8>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
+        case 4096: hipLaunchKernelGGL(rows_split_h_reg_kernel<16>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
+        case 8192: hipLaunchKernelGGL(rows_split_h_reg_kernel<32>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
+        default: hipLaunchKernelGGL(rows_split_h_kernel, grid, block, 0, s, x, embed, tok, w, xs, inv, T, K, eps);
+    }
+}
+
 // ---- LoRA merge: W += scale * B @ A -----------------------------------------------------
 __global__ void lora_merge_kernel(float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
                                   int64_t out_f, int64_t in_f, int r, float scale) {
@@ -839,8 +906,7 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         // fp16 planes: every GEMM input is split by ONE kernel that sees whole rows (norm + split, or split of an fp32
         // buffer), because the power-of-two scale is per row; 3 plane products per GEMM
         auto split_rows = [&](float* src, const float* embed, const int* tok, const float* w, bf16_t* dst, float* inv, int K) {
-            hipLaunchKernelGGL(rows_split_h_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, src, embed, tok, w, dst, inv, T, K,
-                               c.rms_norm_eps);
+            launch_rows_split_h(src, embed, tok, w, dst, inv, T, K, c.rms_norm_eps, s);
         };
         for (int li = 0; li < c.num_layers; ++li) {
             LayerW& l = m->layers[li];
@@ -963,8 +1029,8 @@ static int head_sparse(sr_model* m, int B, int T, int prec, float* d_out, hipStr
     GemmArgs g{};
     GemmEpilogue epi = EPI_SEGMAX;
     if (prec == PREC_FP32 && m->cfg.fp32_planes == SR_FP32_PLANES_F16) {
-        hipLaunchKernelGGL(rows_split_h_kernel, dim3((unsigned)ceil_div64(T, 4)), dim3(256), 0, s, m->x, (const float*)nullptr,
-                           (const int*)nullptr, (const float*)m->norm_w, m->xs, m->xs_i, T, H, m->cfg.rms_norm_eps);
+        launch_rows_split_h(m->x, (const float*)nullptr, (const int*)nullptr, (const float*)m->norm_w, m->xs, m->xs_i, T, H,
+                            m->cfg.rms_norm_eps, s);
         g.A = m->xs; g.W = m->lm_head_s; g.K = 3 * H; g.a_scale = m->xs_i; g.w_scale = m->lm_head_i;
         epi = EPI_SEGMAX_H;
     } else if (prec == PREC_FP32) {
