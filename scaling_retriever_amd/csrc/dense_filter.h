@@ -19,7 +19,8 @@ int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hip
 int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStream_t s);
 // Candidates = the kp best approximate scores per query, sorted descending (a_scores / a_ids [nq, kp], pads id < 0).
 // launch_filter_rescore: exact score of every candidate that can still be in the top-k (approximate score within 2E of
-// the k-th best approximate score; the others are provably out) = fp32 fmaf chain in the k order of dense_score_pipe_kernel, key =
+// the k-th best approximate score, and - for the candidates beyond the k best - within E of the smallest exact score of
+// those k, xmin [nq] scratch; the others are provably out) = fp32 fmaf chain in the k order of dense_score_pipe_kernel, key =
 // (score desc, doc index asc) into cand_keys [nq, cand_cap]; flags[q] |= 2 if a candidate's two scores differ by more than
 // the bound.  launch_filter_certify (after the exact top-k x_scores [nq, k] is known): flags[q] |= 1 unless every document
 // outside the candidates is provably below the k-th exact score.  flags must be zeroed first; non-zero -> the caller falls
@@ -28,4 +29,4 @@ int launch_filter_certify(const float* a_scores, const float* x_scores, const fl
                           int kp, double c, int* flags, hipStream_t s);
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
                           const float* d_max2, int64_t nq, int k, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
-                          int64_t cand_cap, int* flags, hipStream_t s);
+                          int64_t cand_cap, int* flags, unsigned int* xmin, hipStream_t s);

@@ -114,22 +114,31 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
                                                             const int64_t* __restrict__ a_ids, const float* __restrict__ qnorm,
                                                             const float* __restrict__ d_max2, int k, int kp, int H, double c,
                                                             uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
-                                                            int64_t cand_cap, int* __restrict__ flags) {
+                                                            int64_t cand_cap, int* __restrict__ flags, int j_begin,
+                                                            unsigned int* __restrict__ xmin) {
 #pragma clang fp contract(off)
     __shared__ float tile[64][RS_KC + 1];
     __shared__ float qs[RS_KC];
     __shared__ const float* rowp[64];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
-    const int j0 = blockIdx.y * 64;
+    const int j0 = j_begin + blockIdx.y * 64;
     const int j = j0 + lane;
+    const int j_end = j_begin == 0 ? (k < kp ? k : kp) : kp;        // stage 1: the k best approximate scores; stage 2: the rest
+    if (j0 >= j_end) return;
     // A candidate whose approximate score lies more than 2E below the k-th best approximate score cannot be in the exact
     // top-k: its exact score is < a_k - E, and the k candidates with approximate scores >= a_k all have exact scores >= a_k - E.
     // The approximate list is sorted, so what has to be re-scored is a prefix of it.
     const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
-    const double need = (double)a_scores[q * kp + (k < kp ? k : kp) - 1] - 2.0 * E;
+    double need = (double)a_scores[q * kp + (k < kp ? k : kp) - 1] - 2.0 * E;
+    // stage 2 knows better: the smallest EXACT score among the k candidates of stage 1 is a lower bound of the exact k-th
+    // score, and a candidate with S_a + E strictly below it cannot reach the top-k
+    if (j_begin > 0) {
+        const double lo = (double)sr_ord2f(xmin[q]) - E;
+        need = lo > need ? lo : need;
+    }
     if ((double)a_scores[q * kp + j0] < need) return;           // the whole wave
-    int64_t gid = j < kp ? a_ids[q * kp + j] : -1;
+    int64_t gid = j < j_end ? a_ids[q * kp + j] : -1;
     if (gid >= 0 && (double)a_scores[q * kp + j] < need) gid = -1;
     const float* row = nullptr;
     if (gid >= 0) {
@@ -170,16 +179,26 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
         if (!(fabs((double)acc - (double)a_scores[q * kp + j]) <= E)) atomicOr(&flags[q], 2);
         const int pos = atomicAdd(&cand_count[q], 1);
         if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
+        if (j_begin == 0) atomicMin(&xmin[q], sr_f2ord(acc));
     }
 }
 
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
                           const float* d_max2, int64_t nq, int k, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
-                          int64_t cand_cap, int* flags, hipStream_t s) {
+                          int64_t cand_cap, int* flags, unsigned int* xmin, hipStream_t s) {
     SR_REQUIRE(H % RS_KC == 0, "filter(rescore): dim %d must be a multiple of %d", H, RS_KC);
     SR_REQUIRE(nq <= 0x7fffffff && ceil_div64(kp, 64) <= 65535, "filter(rescore): grid too large");
-    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp, 64)), dim3(64), 0, s, segs, Q, a_scores, a_ids,
-                       qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags);
+    // stage 1: the k best candidates by approximate score (and the smallest exact score among them, xmin); stage 2: the rest,
+    // pruned against xmin.  When stage 1 saw fewer than k documents there is nothing left for stage 2.
+    SR_CHECK_HIP(hipMemsetAsync(xmin, 0xff, (size_t)nq * 4, s));
+    const int k1 = k < kp ? k : kp;
+    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(k1, 64)), dim3(64), 0, s, segs, Q, a_scores, a_ids,
+                       qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags, 0, xmin);
     SR_CHECK_LAUNCH();
+    if (kp > k1) {
+        hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp - k1, 64)), dim3(64), 0, s, segs, Q, a_scores,
+                           a_ids, qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags, k1, xmin);
+        SR_CHECK_LAUNCH();
+    }
     return SR_OK;
 }

@@ -710,7 +710,7 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         idx->qnorm = nullptr; idx->a_scores = nullptr; idx->a_ids = nullptr; idx->flags = nullptr;
         idx->fq_cap = 0;
         if (hipMalloc((void**)&idx->qnorm, (size_t)nq * 4) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
-            hipMalloc((void**)&idx->a_ids, (size_t)nq * kp * 8) != hipSuccess || hipMalloc((void**)&idx->flags, (size_t)(nq + 1) * 4) != hipSuccess) {
+            hipMalloc((void**)&idx->a_ids, (size_t)nq * kp * 8) != hipSuccess || hipMalloc((void**)&idx->flags, (size_t)(2 * nq + 2) * 4) != hipSuccess) {
             (void)hipGetLastError();
             return SR_OK;                                     // no room for the candidate lists: exact kernel
         }
@@ -739,7 +739,8 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         SR_TRY(idx->ws2.ensure(nq, k, kp));
         SR_TRY(topk_reset(idx->ws2, nq, s));
         SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, k, kp, idx->dim, c,
-                                     idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, s));
+                                     idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags,
+                                     reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, s));
         SR_TRY(topk_compact(idx->ws2, nq, k, s));
         SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
         // 3. certificate against the k-th exact score
