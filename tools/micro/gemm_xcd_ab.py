@@ -11,7 +11,7 @@ Ms = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16384,38400").spli
 shapes = [("qkv", 3072, 2048, 0), ("o", 2048, 2048, 0), ("gate_up", 16384, 2048, 2), ("down", 2048, 8192, 0)]
 os.environ["SR_GEMM_TILE"] = ""
 for M in Ms:
-    for xcd in ("0", "1"):
+    for xcd in ("0", "1", "0", "1", "0", "1"):     # alternated and repeated: the first configuration measured runs on a cold part
         os.environ["SR_GEMM_XCD"] = xcd
         tot_ms, tot_fl, row = 0.0, 0.0, {}
         for name, N, K, epi in shapes:
