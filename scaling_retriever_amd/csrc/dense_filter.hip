@@ -153,18 +153,28 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     rowp[lane] = row;
     __syncthreads();
     float acc = 0.f;
-    for (int k0 = 0; k0 < H; k0 += RS_KC) {
-        __syncthreads();
-        // 64 rows x 256 B: 16 lanes per row, 4 rows per instruction
-        for (int r0 = 0; r0 < 64; r0 += 4) {
-            const int r = r0 + (lane >> 4);
-            const float* p = rowp[r];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p) v = *reinterpret_cast<const f32x4*>(p + k0 + (lane & 15) * 4);
-            float* t = &tile[r][(lane & 15) * 4];
-            t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    // 64 rows x 256 B per chunk: 16 lanes per row, 4 rows per instruction.  All 16 loads of a chunk are issued together
+    // (interleaved with the LDS stores each one was waited for before the next went out: one memory latency per 4 rows),
+    // and the loads of chunk k + 1 fly while chunk k goes through LDS and the fmaf chain.
+    const float* myp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) myp[i] = rowp[i * 4 + (lane >> 4)];
+    auto fetch = [&](int k0, f32x4 (&v)[16], float& qv) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (myp[i]) v[i] = *reinterpret_cast<const f32x4*>(myp[i] + k0 + (lane & 15) * 4);
         }
-        qs[lane] = Q[q * H + k0 + lane];
+        qv = Q[q * H + k0 + lane];
+    };
+    auto chunk = [&](const f32x4 (&v)[16], float qv) {
+        __syncthreads();                              // the previous chunk is consumed
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float* t = &tile[i * 4 + (lane >> 4)][(lane & 15) * 4];
+            t[0] = v[i][0]; t[1] = v[i][1]; t[2] = v[i][2]; t[3] = v[i][3];
+        }
+        qs[lane] = qv;
         __syncthreads();
 #pragma unroll
         for (int s8 = 0; s8 < RS_KC; s8 += 8)
@@ -173,6 +183,17 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
                 acc = __builtin_fmaf(qs[s8 + jj], tile[lane][s8 + jj], acc);
                 acc = __builtin_fmaf(qs[s8 + 4 + jj], tile[lane][s8 + 4 + jj], acc);
             }
+    };
+    f32x4 va[16], vb[16];
+    float qa, qb;
+    fetch(0, va, qa);
+    for (int k0 = 0; k0 < H; k0 += 2 * RS_KC) {       // H is a multiple of RS_KC; an odd chunk count ends in the first half
+        const bool has_b = k0 + RS_KC < H;
+        if (has_b) fetch(k0 + RS_KC, vb, qb);
+        chunk(va, qa);
+        if (!has_b) break;
+        if (k0 + 2 * RS_KC < H) fetch(k0 + 2 * RS_KC, va, qa);
+        chunk(vb, qb);
     }
     if (row) {
         // the bound, checked on every pair that is re-scored
