@@ -157,6 +157,10 @@ __global__ __launch_bounds__(256) void topk_sort_kernel(const uint64_t* __restri
     const int held = run_count[q];
     const int cnt = held < k ? held : k;
     const uint64_t* run = run_keys + (int64_t)q * (2 * k);
+    // sort only as many slots as this query holds (a power of two, at most the P the launch reserved LDS for)
+    int Pq = 2;
+    while (Pq < held && Pq < P) Pq <<= 1;
+    P = Pq;
     for (int i = tid; i < P; i += 256) keys[i] = i < held ? run[i] : 0ull;
     __syncthreads();
     for (int size = 2; size <= P; size <<= 1) {
