@@ -150,3 +150,36 @@ def test_more_heavy_terms_than_columns_and_many_queries():
     assert np.array_equal(c.cpu().numpy(), es_c)
     assert np.array_equal(i.cpu().numpy(), es_i)
     assert np.array_equal(s.cpu().numpy(), es_s)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_block_kernel_randomised(seed):
+    """Random shapes around the kernel's internal sizes (4096-doc sub-tiles, 64-entry plan batches, 64-posting short runs,
+    256-posting groups, blocks of 4 queries): index sizes just below / above tile multiples, heavy terms at random ids and
+    densities, run lengths straddling the short / long boundary, query sets that are not a multiple of 4, some queries in
+    non-ascending order (per-query kernel in the same call), thresholds of either sign, small candidate workspace."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.integers(40, 260))
+    N = int(rng.choice([4095, 4096, 4097, 8191, 8193, 12289, 20000, 33000]))
+    n_heavy = int(rng.integers(1, 12))
+    heavy = {int(t): float(rng.uniform(0.26, 1.0)) for t in rng.choice(V, size=n_heavy, replace=False)}
+    mid_df = max(3, int(N * rng.uniform(0.02, 0.24)))            # up to ~1000 postings per sub-tile: several groups
+    light_df = max(2, int(N * rng.uniform(0.001, 0.03)))           # around the 64-postings-per-sub-tile boundary
+    indptr, ids, vals = _index(rng, V, N, heavy, mid_df, light_df)
+    nq = int(rng.integers(1, 70))
+    order = "mixed" if seed % 2 else "asc"
+    qi, qc, qv = _queries(rng, V, nq, min(V, int(rng.integers(1, 90))), always=tuple(heavy), order=order)
+    if seed % 3 == 0 and len(qv):
+        qv[rng.integers(0, max(1, len(qv)), size=max(1, len(qv) // 7))] *= -1.0
+    thr = float(rng.choice([0.0, 0.0, 1.5, -0.5]))
+    k = int(rng.choice([1, 10, 100, 1000]))
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    if seed % 2 == 0:
+        idx.set_workspace_limit(8 << 20)
+    s, i, c = idx.search(qi, qc, qv, k, threshold=thr)
+    es_i, es_s, es_c = O.sparse_retrieve_c(indptr, ids, vals, qi, qc, qv, k, thr, N, q_threads=4)
+    assert idx.block_stats()["dense_terms"] == _n_dense(indptr, N)
+    assert np.array_equal(c.cpu().numpy(), es_c)
+    assert np.array_equal(i.cpu().numpy(), es_i)
+    assert np.array_equal(s.cpu().numpy(), es_s)
