@@ -730,7 +730,8 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
     if (const char* e = sr_dev_getenv("SR_FILTER_PRODUCTS")) idx->filter_products = atoi(e) >= 2 ? 2 : 1;
     std::vector<int> h((size_t)nq);
     for (;;) {
-        const int products = idx->filter_products;
+        // (the split kernel's pipelined k loop needs two 64-wide k-tiles: a 64-dim index starts with two products)
+        const int products = idx->dim < 128 ? 2 : idx->filter_products;
         const double c = sr_filter_c(idx->dim, products);
         SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
         // 1. the kp best documents by the approximate score
@@ -751,7 +752,7 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         bool ok = true;
         for (int64_t q = 0; q < nq && ok; ++q) ok = h[(size_t)q] == 0;
         if (ok) break;
-        if (products == 1) { idx->filter_products = 2; ++idx->n_downgrade; continue; }
+        if (products == 1) { idx->filter_products = 2; ++idx->n_downgrade; continue; }      // never taken at dim < 128
         return SR_OK;
     }
     *done = true;

@@ -57,6 +57,35 @@ def test_dense_search_bit_exact(nq, n, h, k):
     _check_dense_exact(Q, D, s, i, k)
 
 
+@pytest.mark.parametrize("k", [1, 100, 1000, 4096])
+def test_dense_topk_running_set_under_adversarial_doc_orders(k):
+    """The fused top-k keeps a running set of 2k keys and cuts it back to k only on overflow.  Doc orders that stress it: scores
+    ascending along the index (every chunk beats tau: the set overflows again and again), descending (nothing passes after the
+    first chunks), blocks of exact duplicates straddling chunk boundaries (ties by ascending doc index), plus random rows.
+    Several launches per search (small candidate workspace); bit-exact vs the oracle."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(k)
+    nq, n, h = 70, 40000, 64
+    D = rng.standard_normal((n, h), dtype=np.float32)
+    Q = rng.standard_normal((nq, h), dtype=np.float32)
+    u = np.zeros(h, np.float32); u[0] = 1.0
+    Q[0] = u; Q[1] = -u; Q[2] = u
+    D[:, 0] = np.linspace(-3.0, 3.0, n, dtype=np.float32)            # query 0: ascending along the index, query 1: descending
+    D[5000:5600] = D[5000]                                            # 600 exact duplicates
+    D[20000:26000] = D[39999]                                         # 6000 copies of the best row of query 0 (> 2k of them at k <= 1000)
+    idx = DenseIndexHIP(h)
+    idx.add_host_rows(D)
+    idx.set_workspace_limit(8 << 20)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    _check_dense_exact(Q, D, s.cpu().numpy(), i.cpu().numpy(), k)
+    filt = DenseIndexHIP(h)
+    filt.set_precision("fp32_filtered")
+    filt.add_host_rows(D)
+    filt.set_workspace_limit(8 << 20)
+    fs, fi = filt.search(torch.from_numpy(Q).cuda(), k)
+    assert torch.equal(fi, i) and torch.equal(fs, s)
+
+
 def test_dense_matches_sgemm_oracle():
     """Against the faiss-style restatement (BLAS sgemm): same ids except near-ties, scores to 1e-5 rel."""
     nq, n, h, k = 64, 20000, 256, 100
