@@ -40,6 +40,29 @@ def test_filtered_equals_exact_and_oracle(H, N, nq, k):
     assert np.array_equal(fi[:n_or].cpu().numpy(), oi) and np.array_equal(fs[:n_or].cpu().numpy(), os_)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_filtered_randomised_shapes(seed):
+    """Random dims (64 .. 1024, multiples of 64), doc counts around tile multiples, query counts just above the 64-query
+    threshold of the tiled kernels, k from 1 to 2000, 1-3 segments with strided ids, value scales from 1e-3 to 1e3: the
+    filter's answer equals the exact kernel's, bit for bit, whichever of its paths (1 or 2 products, fallback) ran."""
+    rng = np.random.default_rng(500 + seed)
+    H = 64 * int(rng.integers(1, 17))
+    N = int(rng.choice([255, 256, 257, 5000, 8191, 12289, 30001]))
+    nq = int(rng.choice([65, 66, 127, 129, 256, 300]))
+    k = int(rng.choice([1, 7, 100, 1000, 2000]))
+    scale = float(10.0 ** rng.uniform(-3, 3))
+    D = (rng.standard_normal((N, H), dtype=np.float32) * scale).astype(np.float32)
+    Q = (rng.standard_normal((nq, H), dtype=np.float32) / scale).astype(np.float32)
+    if seed % 2:
+        D[N // 2:N // 2 + min(50, N // 4)] = D[0]                 # duplicates
+    nseg = int(rng.integers(1, 4))
+    parts = [D[j::nseg] for j in range(nseg)]
+    (es, ei), (fs, fi), filt = _both(parts, Q, k, bases=[(j, nseg) for j in range(nseg)])
+    assert torch.equal(fi, ei) and torch.equal(fs, es), (H, N, nq, k, nseg)
+    os_, oi = O.topk_rows(O.dense_scores_fma(Q[:8], D, O.mfma_korder(H)), k)
+    assert np.array_equal(fi[:8].cpu().numpy(), oi) and np.array_equal(fs[:8].cpu().numpy(), os_)
+
+
 def test_filtered_adversarial_data_still_exact():
     """Same-sign vectors (no cancellation: the largest |S_a - S_x| per unit of |q||d|), a 1e6 dynamic range inside the rows,
     documents of very different norms, near-duplicate documents around the cut, strided global ids."""
