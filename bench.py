@@ -470,6 +470,16 @@ def main():
         traffic = None
     n_filtered, n_fallback = index.filter_stats()
     filtered = (not args.exact_kernel) and n_filtered > 0
+    split_traffic = None
+    try:      # the filter pass: committed round-2 PMC passes, same rule (same problem shape and launch count only)
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            pmc2 = json.load(f)
+        shape2 = pmc2["dense_split_launch"]
+        if (shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
+                and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
+            split_traffic = pmc2["kernels"]["dense_split_kernel"]["traffic_bytes"]
+    except Exception:
+        split_traffic = None
     if filtered:
         # dominant kernel: dense_split_kernel - `prods` bf16 plane products per algorithmic multiply-add on the bf16 MFMA pipe
         prods, raised = index.filter_products()
@@ -480,7 +490,8 @@ def main():
                     "unit": "TFLOP/s (bf16 MFMA work = %d x algorithmic 2 nq N H)" % prods,
                     "frac": round(prods * achieved_tf / PEAK_BF16_MFMA_TF, 4), "filter_plane_products": prods,
                     "filter_products_raised": int(raised),
-                    "algorithmic_TFLOPs": round(achieved_tf, 1), "traffic": None,
+                    "algorithmic_TFLOPs": round(achieved_tf, 1), "traffic": split_traffic,
+                    "traffic_note": "HBM / fabric bytes per launch beyond L2 (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); algorithmic = one bf16 plane of the launch's docs + the query plane, ~0.16 GB: a doc tile is re-read by the 28 query tiles, L2 absorbs about 60 % of that",
                     "launches": int(n_l.value), "avg_launch_ms": round(ms.value / max(1, n_l.value), 4),
                     "flop_per_launch": fl.value / max(1, n_l.value), "kernel_share_of_step": round(ms.value * 1e-3 / dt, 3),
                     "searches_through_filter": int(n_filtered), "searches_redone_by_exact_kernel": int(n_fallback)}
