@@ -325,7 +325,9 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
     const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     const int64_t q0 = a.q_base + (int64_t)bx * SPB_Q;
     const int64_t gblk = q0 / SPB_Q;
-    if (!b.plan_ok[gblk]) return;
+    // the block's flag, plan offset, entry count and the four tau values are independent loads: issue them together (a return on
+    // the flag first would put one more memory latency in front of every workgroup)
+    const uint8_t blk_ok = b.plan_ok[gblk];
     const int64_t pe0 = a.q_indptr[q0] - b.nnz_base;
     const int ne = b.plan_n[gblk];
     const int skip_stride = a.n_tiles * (SP_TILE / SP_SUB) + 1;
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
     float tq[SPB_Q];
 #pragma unroll
     for (int qi = 0; qi < SPB_Q; ++qi) tq[qi] = qi < nqs ? a.tau[ql0 + qi] : 0.f;
+    if (!blk_ok) return;
     float* const my_slice = sc + wave * SPB_TSTRIDE;           // scatter phase: wave q owns slice q
 
     // lane j: plan entry j of a batch of 64 (every wave holds the same entries); the next batch's entries - of this sub-tile
