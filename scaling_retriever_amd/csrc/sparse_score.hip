@@ -54,7 +54,7 @@ struct SparseArgs {
     int* cand_count;
     int64_t cand_cap;
     uint32_t id_base, id_stride;
-    const uint8_t* blk_done;   // optional: blocks of SPB_Q queries the query-block kernel handles (skipped here)
+    const uint8_t* q_done;     // optional: queries the query-block kernel handles (skipped here)
 };
 
 // The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term.  The run of
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
     const int lane = tid & 63;
     const int ql = blockIdx.x;                 // query within batch
     const int64_t q = a.q_base + ql;
-    if (a.blk_done && a.blk_done[q / SPB_Q]) return;
+    if (a.q_done && a.q_done[q]) return;
     const int tile = a.tile_begin + blockIdx.y;
     const int64_t doc0 = (int64_t)tile * SP_TILE;
     const int n_here = (int)((a.n_docs - doc0) < SP_TILE ? (a.n_docs - doc0) : SP_TILE);
@@ -299,12 +299,13 @@ struct SparseBlockArgs {
     const float* dense;          // [n_dense][dense_stride]
     const int32_t* dense_slot;   // [n_terms]: column of a dense term, -1 otherwise
     int64_t dense_stride;        // n_tiles * SP_TILE
-    const int32_t* plan_term;    // union term lists, block b at q_indptr[4 b] - nnz_base
+    const int32_t* plan_term;    // union term lists, block b at plan_off[b]
     const float* plan_w;         // [.][SPB_Q]
     const int32_t* plan_n;       // entries of block b
     const uint8_t* plan_ok;      // 0: block goes to sparse_score_kernel
-    int64_t nnz_base;
-    int64_t q_end;               // one past the last query of this batch
+    const int64_t* plan_off;
+    const int32_t* blk_q;        // this batch's queries in block order (batch-local indices, -1 = none): block j holds blk_q[SPB_Q j ..]
+    int64_t blk_base;            // global index of this batch's first block
     int n_sub;                   // sub-tiles of this launch
     int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): bit mask of skipped run kinds, 2 = dense, 4 = light scatter, 8 = big scatter
 };
@@ -323,20 +324,21 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
-    const int64_t q0 = a.q_base + (int64_t)bx * SPB_Q;
-    const int64_t gblk = q0 / SPB_Q;
-    // the block's flag, plan offset, entry count and the four tau values are independent loads: issue them together (a return on
-    // the flag first would put one more memory latency in front of every workgroup)
+    const int64_t gblk = b.blk_base + bx;
+    // the block's flag, plan offset, entry count, its queries and their tau values are independent loads: issue them together
+    // (a return on the flag first would put one more memory latency in front of every workgroup)
     const uint8_t blk_ok = b.plan_ok[gblk];
-    const int64_t pe0 = a.q_indptr[q0] - b.nnz_base;
+    const int64_t pe0 = b.plan_off[gblk];
     const int ne = b.plan_n[gblk];
     const int skip_stride = a.n_tiles * (SP_TILE / SP_SUB) + 1;
     const float thr = a.threshold;
-    const int nqs = (int)((b.q_end - q0) < SPB_Q ? (b.q_end - q0) : SPB_Q);
-    const int ql0 = (int)(q0 - a.q_base);
+    int qls[SPB_Q];            // batch-local query of every slice (the blocks are cut from a work-sorted order), -1 = none
     float tq[SPB_Q];
 #pragma unroll
-    for (int qi = 0; qi < SPB_Q; ++qi) tq[qi] = qi < nqs ? a.tau[ql0 + qi] : 0.f;
+    for (int qi = 0; qi < SPB_Q; ++qi) {
+        qls[qi] = b.blk_q[(int64_t)bx * SPB_Q + qi];
+        tq[qi] = qls[qi] >= 0 ? a.tau[qls[qi]] : 0.f;
+    }
     if (!blk_ok) return;
     float* const my_slice = sc + wave * SPB_TSTRIDE;           // scatter phase: wave q owns slice q
 
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
 #pragma unroll
     for (int qi = 0; qi < SPB_Q; ++qi) {
         cnt[qi] = 0;
-        if (qi < nqs) {
+        if (qls[qi] >= 0) {
 #pragma unroll
             for (int i = 0; i < SPB_DV; ++i)
 #pragma unroll
@@ -632,19 +634,20 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
             if (lane == 63) wave_tot[qi][wave] = incl[qi];
         }
         __syncthreads();
-        if (tid < nqs) {
+        if (tid < SPB_Q) {
             int total = 0;
             for (int w = 0; w < SPB_THREADS / 64; ++w) total += wave_tot[tid][w];
-            s_base[tid] = total ? atomicAdd(&a.cand_count[ql0 + tid], total) : 0;
+            const int ql = b.blk_q[(int64_t)bx * SPB_Q + tid];
+            s_base[tid] = (total && ql >= 0) ? atomicAdd(&a.cand_count[ql], total) : 0;
         }
         __syncthreads();
 #pragma unroll
         for (int qi = 0; qi < SPB_Q; ++qi) {
-            if (qi >= nqs || cnt[qi] == 0) continue;
+            if (qls[qi] < 0 || cnt[qi] == 0) continue;
             int wbase = 0;
             for (int w = 0; w < wave; ++w) wbase += wave_tot[qi][w];
             int pos = s_base[qi] + wbase + incl[qi] - cnt[qi];
-            uint64_t* dst = a.cand_keys + (int64_t)(ql0 + qi) * a.cand_cap;
+            uint64_t* dst = a.cand_keys + (int64_t)qls[qi] * a.cand_cap;
 #pragma unroll
             for (int i = 0; i < SPB_DV; ++i)
 #pragma unroll
@@ -662,26 +665,114 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
   }
 }
 
+// Order of a batch's queries before it is cut into blocks of SPB_Q.  Wave q of a workgroup walks query q's scatter terms
+// alone, so a block takes as long as its heaviest query (consecutive Dev-shaped queries: heaviest / mean = 1.4 for the longer
+// runs), and a dense column is loaded for a block if ANY of its queries carries the term (union of 4 consecutive queries: 23
+// columns for 9 per query).  Queries are therefore sorted by (scatter-work bucket, set of their rarer dense terms): a block's
+// queries then have about the same work and mostly the same columns: 242 -> 235 ms per pass at the MSMARCO shape (work only or
+// columns only: 238).  One workgroup per batch (<= SPB_SORT_MAX queries, bitonic sort in LDS; larger batches keep the caller's
+// order).  Also lays out the blocks' plan regions (plan_off).  Which queries share a block changes nothing in any query's result.
+#define SPB_SORT_MAX 1024
+__global__ __launch_bounds__(256) void sparse_block_order_kernel(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_cols,
+                                                                 int64_t nq, int64_t q_batch, int pad, int64_t n_terms,
+                                                                 const int64_t* __restrict__ indptr, const int32_t* __restrict__ dense_slot,
+                                                                 int n_sub, int do_sort, int32_t* __restrict__ perm,
+                                                                 int64_t* __restrict__ plan_off, int64_t blocks_per_batch) {
+    __shared__ unsigned long long keys[SPB_SORT_MAX];
+    __shared__ int red[4];
+    const int tid = threadIdx.x;
+    const int64_t qb = (int64_t)blockIdx.x * q_batch;
+    const int nqb = (int)((nq - qb) < q_batch ? (nq - qb) : q_batch);
+    int32_t* pm = perm + (int64_t)blockIdx.x * pad;
+    if (do_sort && pad <= SPB_SORT_MAX) {
+        unsigned long long mask[SPB_SORT_MAX / 256];
+        int work[SPB_SORT_MAX / 256];
+        int wmax = 0;
+#pragma unroll
+        for (int i = 0; i < SPB_SORT_MAX / 256; ++i) {
+            const int ql = tid + 256 * i;
+            mask[i] = 0;
+            work[i] = 0;
+            if (ql < nqb) {
+                for (int64_t j = q_indptr[qb + ql]; j < q_indptr[qb + ql + 1]; ++j) {
+                    const int64_t t = q_cols[j];
+                    if (t < 0 || t >= n_terms) continue;
+                    const int slot = dense_slot[t];
+                    if (slot >= 0) {
+                        mask[i] |= 1ull << (slot & 63);
+                    } else {                            // expected run per sub-tile: one step when short, groups otherwise
+                        const int64_t per = (indptr[t + 1] - indptr[t]) / n_sub;
+                        work[i] += per <= SPB_LIGHT ? 1 : 2 * (int)((per + SPB_GROUP - 1) / SPB_GROUP);
+                    }
+                }
+            }
+            wmax = work[i] > wmax ? work[i] : wmax;
+        }
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(wmax, off); wmax = o > wmax ? o : wmax; }
+        if ((tid & 63) == 0) red[tid >> 6] = wmax;
+        __syncthreads();
+        wmax = max(max(red[0], red[1]), max(red[2], red[3]));
+#pragma unroll
+        for (int i = 0; i < SPB_SORT_MAX / 256; ++i) {
+            const int ql = tid + 256 * i;
+            // [work bucket: 5 bits][dense slots 8..55, the rarer ones in the high bits: 48 bits][query: 10 bits]; pads sort last
+            const unsigned long long bucket = (unsigned long long)((int64_t)work[i] * 31 / (wmax > 0 ? wmax : 1));
+            keys[ql] = ql < nqb ? (bucket << 58) | (((mask[i] >> 8) & ((1ull << 48) - 1)) << 10) | (unsigned long long)ql : ~0ull;
+        }
+        __syncthreads();
+        for (int size = 2; size <= SPB_SORT_MAX; size <<= 1)
+            for (int j = size >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < SPB_SORT_MAX; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = (i & size) == 0;
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        if (up ? (x > y) : (x < y)) { keys[i] = y; keys[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < pad; i += 256) pm[i] = keys[i] == ~0ull ? -1 : (int32_t)(keys[i] & 1023);
+    } else {
+        for (int i = tid; i < pad; i += 256) pm[i] = i < nqb ? i : -1;
+    }
+    __syncthreads();
+    if (tid == 0) {       // plan regions in block order: a block's union list is at most the sum of its queries' term counts
+        int64_t off = q_indptr[qb] - q_indptr[0];
+        for (int64_t j = 0; j < blocks_per_batch; ++j) {
+            plan_off[(int64_t)blockIdx.x * blocks_per_batch + j] = off;
+            for (int i = 0; i < SPB_Q; ++i) {
+                const int ql = pm[j * SPB_Q + i];
+                if (ql >= 0) off += q_indptr[qb + ql + 1] - q_indptr[qb + ql];
+            }
+        }
+    }
+}
+
 // Plan of a block of SPB_Q queries: the union of their known terms in ascending term id, one weight per query (0 where the
 // query lacks the term).  ok = every query of the block lists its terms in strictly ascending id, i.e. the union's order is
 // each query's own accumulation order.  One thread per block.
 __global__ void sparse_block_plan_kernel(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_cols,
-                                         const float* __restrict__ q_vals, int64_t nq, int64_t n_terms,
-                                         int32_t* __restrict__ plan_term, float* __restrict__ plan_w,
-                                         int32_t* __restrict__ plan_n, uint8_t* __restrict__ plan_ok, int* __restrict__ any_bad) {
+                                         const float* __restrict__ q_vals, int64_t nq, int64_t n_terms, int64_t q_batch, int pad,
+                                         int64_t blocks_per_batch, int64_t n_blocks, const int32_t* __restrict__ perm,
+                                         const int64_t* __restrict__ plan_off, int32_t* __restrict__ plan_term,
+                                         float* __restrict__ plan_w, int32_t* __restrict__ plan_n, uint8_t* __restrict__ plan_ok,
+                                         uint8_t* __restrict__ q_done, int* __restrict__ any_bad) {
     const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t q0 = blk * SPB_Q;
-    if (q0 >= nq) return;
-    const int64_t base = q_indptr[0];
-    int64_t p[SPB_Q], e[SPB_Q];
-    bool ok = true;
+    if (blk >= n_blocks) return;
+    const int64_t bat = blk / blocks_per_batch, j = blk - bat * blocks_per_batch;
+    const int64_t qb = bat * q_batch;
+    int64_t q[SPB_Q], p[SPB_Q], e[SPB_Q];
+    bool ok = true, any = false;
     for (int i = 0; i < SPB_Q; ++i) {
-        if (q0 + i < nq) { p[i] = q_indptr[q0 + i]; e[i] = q_indptr[q0 + i + 1]; } else { p[i] = e[i] = 0; }
-        for (int64_t j = p[i] + 1; j < e[i]; ++j) ok = ok && q_cols[j] > q_cols[j - 1];
+        const int ql = perm[bat * pad + j * SPB_Q + i];
+        q[i] = ql >= 0 ? qb + ql : -1;
+        if (q[i] >= 0) { p[i] = q_indptr[q[i]]; e[i] = q_indptr[q[i] + 1]; any = true; } else { p[i] = e[i] = 0; }
+        for (int64_t c = p[i] + 1; c < e[i]; ++c) ok = ok && q_cols[c] > q_cols[c - 1];
     }
     int n = 0;
-    if (ok) {
-        int64_t out = q_indptr[q0] - base;
+    if (ok && any) {
+        const int64_t out = plan_off[blk];
         for (;;) {
             int64_t t = INT64_MAX;
             for (int i = 0; i < SPB_Q; ++i)
@@ -697,11 +788,13 @@ __global__ void sparse_block_plan_kernel(const int64_t* __restrict__ q_indptr, c
             for (int i = 0; i < SPB_Q; ++i) plan_w[(out + n) * SPB_Q + i] = w[i];
             ++n;
         }
-    } else {
+    } else if (!ok) {
         atomicOr(any_bad, 1);
     }
     plan_n[blk] = n;
-    plan_ok[blk] = ok ? 1 : 0;
+    plan_ok[blk] = (ok && any) ? 1 : 0;
+    for (int i = 0; i < SPB_Q; ++i)
+        if (q[i] >= 0) q_done[q[i]] = ok ? 1 : 0;
 }
 
 // dense column of a heavy term: column[slot][doc] = value (the buffer is zero-filled first)
@@ -769,6 +862,10 @@ struct sr_sparse_index {
     float* plan_w = nullptr;
     int32_t* plan_n = nullptr;
     uint8_t* plan_ok = nullptr;
+    int64_t* plan_off = nullptr;
+    int32_t* plan_perm = nullptr;     // every batch's queries in block order
+    uint8_t* q_done = nullptr;
+    int64_t plan_q_cap = 0;
     int* plan_bad = nullptr;
     int64_t n_block_calls = 0, n_fallback_calls = 0;
     int64_t ws_limit = 4ll << 30;
@@ -795,7 +892,8 @@ __global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, i
 }
 
 static void sparse_free_device(sr_sparse_index* idx) {
-    void* ptrs[] = {idx->skip, idx->dense, idx->dense_slot, idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_bad};
+    void* ptrs[] = {idx->skip, idx->dense, idx->dense_slot, idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_bad,
+                    idx->plan_off, idx->plan_perm, idx->q_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     idx->skip = nullptr;
@@ -806,6 +904,9 @@ static void sparse_free_device(sr_sparse_index* idx) {
     idx->plan_n = nullptr;
     idx->plan_ok = nullptr;
     idx->plan_bad = nullptr;
+    idx->plan_off = nullptr;
+    idx->plan_perm = nullptr;
+    idx->q_done = nullptr;
 }
 
 // Terms present in at least 1 / SP_DENSE_DIV of the docs get a dense column: the longest lists first, at most SP_DENSE_MAX of
@@ -995,38 +1096,61 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
     std::lock_guard<std::mutex> lock(idx->mu);
     StreamOrder::Scope in_order(idx->order, s);
 
-    // query-block path: plan the blocks of 4 queries once per call
+    // query batches bound the candidate workspace: cap (slots per query) = docs per launch
+    int64_t q_batch_max = 1024;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_QBATCH")) q_batch_max = atoll(e) >= 4 ? atoll(e) / 4 * 4 : 4;
+    const int64_t q_batch = nq < q_batch_max ? nq : q_batch_max;
+    int64_t max_tiles = idx->ws_limit / (8 * q_batch * SP_TILE);
+    if (max_tiles < 1) max_tiles = 1;
+    if (max_tiles > 64) max_tiles = 64;
+    if (max_tiles > idx->n_tiles) max_tiles = idx->n_tiles;
+    SR_TRY(idx->ws.ensure(q_batch, k, max_tiles * SP_TILE));
+
+    // query-block path: order every batch's queries, cut them into blocks of SPB_Q and plan the blocks, once per call
     bool use_blocks = idx->n_dense > 0;
     if (const char* e = sr_dev_getenv("SR_SPARSE_BLOCKS")) use_blocks = use_blocks && atoi(e) != 0;
     bool any_fallback = !use_blocks;
-    int64_t nnz_base = 0;
+    const int64_t n_batches = ceil_div64(nq, q_batch);
+    const int64_t blocks_per_batch = ceil_div64(q_batch, SPB_Q);
+    const int pad = (int)(blocks_per_batch * SPB_Q);
+    const int64_t n_blocks = n_batches * blocks_per_batch;
     if (use_blocks) {
         int64_t h[2];
         SR_CHECK_HIP(hipMemcpyAsync(h, d_q_indptr, 8, hipMemcpyDeviceToHost, s));
         SR_CHECK_HIP(hipMemcpyAsync(h + 1, d_q_indptr + nq, 8, hipMemcpyDeviceToHost, s));
         SR_CHECK_HIP(hipStreamSynchronize(s));
-        nnz_base = h[0];
         const int64_t nnz = h[1] - h[0];
         SR_REQUIRE(nnz >= 0, "sr_sparse_search: query indptr not monotone");
-        const int64_t n_blocks = ceil_div64(nq, SPB_Q);
-        if (nnz > idx->plan_cap || n_blocks > idx->plan_blocks_cap) {
-            void* old[] = {idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok};
+        if (nnz > idx->plan_cap || n_blocks > idx->plan_blocks_cap || nq > idx->plan_q_cap) {
+            void* old[] = {idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_off, idx->plan_perm, idx->q_done};
             for (void* p : old)
                 if (p) (void)hipFree(p);
             idx->plan_term = nullptr; idx->plan_w = nullptr; idx->plan_n = nullptr; idx->plan_ok = nullptr;
-            idx->plan_cap = idx->plan_blocks_cap = 0;
+            idx->plan_off = nullptr; idx->plan_perm = nullptr; idx->q_done = nullptr;
+            idx->plan_cap = idx->plan_blocks_cap = idx->plan_q_cap = 0;
             const int64_t cap = nnz > 0 ? nnz : 1;
             SR_CHECK_HIP(hipMalloc(&idx->plan_term, sizeof(int32_t) * (size_t)cap));
             SR_CHECK_HIP(hipMalloc(&idx->plan_w, sizeof(float) * SPB_Q * (size_t)cap));
             SR_CHECK_HIP(hipMalloc(&idx->plan_n, sizeof(int32_t) * (size_t)n_blocks));
             SR_CHECK_HIP(hipMalloc(&idx->plan_ok, (size_t)n_blocks));
+            SR_CHECK_HIP(hipMalloc(&idx->plan_off, sizeof(int64_t) * (size_t)n_blocks));
+            SR_CHECK_HIP(hipMalloc(&idx->plan_perm, sizeof(int32_t) * (size_t)n_blocks * SPB_Q));
+            SR_CHECK_HIP(hipMalloc(&idx->q_done, (size_t)nq));
             idx->plan_cap = cap;
             idx->plan_blocks_cap = n_blocks;
+            idx->plan_q_cap = nq;
         }
         if (!idx->plan_bad) SR_CHECK_HIP(hipMalloc(&idx->plan_bad, sizeof(int)));
         SR_CHECK_HIP(hipMemsetAsync(idx->plan_bad, 0, sizeof(int), s));
+        int do_sort = 1;
+        if (const char* e = sr_dev_getenv("SR_SPARSE_SORT")) do_sort = atoi(e);       // A/B switch: 0 = blocks of consecutive queries
+        hipLaunchKernelGGL(sparse_block_order_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, d_q_indptr, d_q_cols, nq, q_batch, pad,
+                           idx->n_terms, idx->indptr, idx->dense_slot, idx->n_tiles * (SP_TILE / SP_SUB), do_sort, idx->plan_perm,
+                           idx->plan_off, blocks_per_batch);
+        SR_CHECK_LAUNCH();
         hipLaunchKernelGGL(sparse_block_plan_kernel, dim3((unsigned)ceil_div64(n_blocks, 64)), dim3(64), 0, s, d_q_indptr, d_q_cols,
-                           d_q_vals, nq, idx->n_terms, idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->plan_bad);
+                           d_q_vals, nq, idx->n_terms, q_batch, pad, blocks_per_batch, n_blocks, idx->plan_perm, idx->plan_off,
+                           idx->plan_term, idx->plan_w, idx->plan_n, idx->plan_ok, idx->q_done, idx->plan_bad);
         SR_CHECK_LAUNCH();
         int h_bad = 0;
         SR_CHECK_HIP(hipMemcpyAsync(&h_bad, idx->plan_bad, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1041,16 +1165,6 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
         ++idx->n_block_calls;
         if (any_fallback) ++idx->n_fallback_calls;
     }
-
-    // query batches bound the candidate workspace: cap (slots per query) = docs per launch
-    int64_t q_batch_max = 1024;
-    if (const char* e = sr_dev_getenv("SR_SPARSE_QBATCH")) q_batch_max = atoll(e) >= 4 ? atoll(e) / 4 * 4 : 4;
-    const int64_t q_batch = nq < q_batch_max ? nq : q_batch_max;
-    int64_t max_tiles = idx->ws_limit / (8 * q_batch * SP_TILE);
-    if (max_tiles < 1) max_tiles = 1;
-    if (max_tiles > 64) max_tiles = 64;
-    if (max_tiles > idx->n_tiles) max_tiles = idx->n_tiles;
-    SR_TRY(idx->ws.ensure(q_batch, k, max_tiles * SP_TILE));
 
     for (int64_t qb = 0; qb < nq; qb += q_batch) {
         const int64_t nqb = (nq - qb) < q_batch ? (nq - qb) : q_batch;
@@ -1079,7 +1193,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             a.cand_cap = idx->ws.cand_cap;
             a.id_base = (uint32_t)id_base;
             a.id_stride = (uint32_t)id_stride;
-            a.blk_done = use_blocks ? idx->plan_ok : nullptr;
+            a.q_done = use_blocks ? idx->q_done : nullptr;
             idx->prof.begin(s);
             if (use_blocks) {
                 SparseBlockArgs b;
@@ -1091,8 +1205,9 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 b.plan_w = idx->plan_w;
                 b.plan_n = idx->plan_n;
                 b.plan_ok = idx->plan_ok;
-                b.nnz_base = nnz_base;
-                b.q_end = qb + nqb;
+                b.plan_off = idx->plan_off;
+                b.blk_q = idx->plan_perm + (qb / q_batch) * pad;
+                b.blk_base = (qb / q_batch) * blocks_per_batch;
                 b.diag = 0;
                 if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
                 b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));

@@ -183,3 +183,21 @@ def test_block_kernel_randomised(seed):
     assert np.array_equal(c.cpu().numpy(), es_c)
     assert np.array_equal(i.cpu().numpy(), es_i)
     assert np.array_equal(s.cpu().numpy(), es_s)
+
+
+def test_block_order_does_not_change_results(monkeypatch):
+    """The batch's queries are sorted (scatter work, dense-term set) before they are cut into blocks of 4; with the sort
+    switched off (blocks of consecutive queries) every query's ids and scores are the same bits."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(77)
+    V, N = 150, 26000
+    heavy = {int(t): float(rng.uniform(0.3, 1.0)) for t in rng.choice(V, size=9, replace=False)}
+    indptr, ids, vals = _index(rng, V, N, heavy, 5000, 400)
+    qi, qc, qv = _queries(rng, V, 1301, 20, always=tuple(heavy))            # two batches of queries, ragged last block
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    s1, i1, c1 = idx.search(qi, qc, qv, 50)
+    monkeypatch.setenv("SR_SPARSE_SORT", "0")
+    s0, i0, c0 = idx.search(qi, qc, qv, 50)
+    assert torch.equal(s1, s0) and torch.equal(i1, i0) and torch.equal(c1, c0)
+    es_i, es_s, es_c = O.sparse_retrieve_c(indptr, ids, vals, qi, qc, qv, 50, 0.0, N, q_threads=4)
+    assert np.array_equal(i1.cpu().numpy(), es_i) and np.array_equal(s1.cpu().numpy(), es_s) and np.array_equal(c1.cpu().numpy(), es_c)
