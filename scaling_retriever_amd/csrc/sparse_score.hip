@@ -307,6 +307,7 @@ struct SparseBlockArgs {
     const int32_t* blk_q;        // this batch's queries in block order (batch-local indices, -1 = none): block j holds blk_q[SPB_Q j ..]
     int64_t blk_base;            // global index of this batch's first block
     int n_sub;                   // sub-tiles of this launch
+    unsigned long long* stamps;  // dev switch SR_SPARSE_STAMPS: [7] sums of s_memrealtime ticks (10 ns) per phase over the sampled waves + [7] = waves
     int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): bit mask of skipped run kinds, 2 = dense, 4 = light scatter, 8 = big scatter
 };
 
@@ -316,8 +317,6 @@ struct SparseBlockArgs {
 __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_kernel(SparseBlockArgs b) {
 #pragma clang fp contract(off)
     extern __shared__ float sc[];              // [SPB_Q][SPB_TSTRIDE]: score slices + one dummy slot per lane
-    __shared__ int wave_tot[SPB_Q][SPB_THREADS / 64];
-    __shared__ int s_base[SPB_Q];
     __shared__ int desc_all[SPB_THREADS / 64][SPB_DESC];    // per wave: (term lane << 8 | group) of the scatter walk
     const SparseArgs& a = b.a;
     const int tid = threadIdx.x;
@@ -340,6 +339,17 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
         tq[qi] = qls[qi] >= 0 ? a.tau[qls[qi]] : 0.f;
     }
     if (!blk_ok) return;
+    // diagnostic: time per phase of every 256th workgroup's waves (0 fetch, 1 dense runs, 2 short runs, 3 longer runs, 4 filter, 5 all)
+    const bool st = b.stamps != nullptr && (blockIdx.x & 15) == 0 && (blockIdx.y & 15) == 0;
+    unsigned long long st_t[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = st ? __builtin_amdgcn_s_memrealtime() : 0, st_first = st_last;
+    auto stamp = [&](int kind) {
+        if (st) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            st_t[kind] += now - st_last;
+            st_last = now;
+        }
+    };
     float* const my_slice = sc + wave * SPB_TSTRIDE;           // scatter phase: wave q owns slice q
 
     // lane j: plan entry j of a batch of 64 (every wave holds the same entries); the next batch's entries - of this sub-tile
@@ -415,7 +425,10 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
         const uint64_t bmask = __ballot(slot < 0 && seg_n > SPB_LIGHT);                    // scatter runs walked in groups
         const uint64_t lmask = __ballot(slot < 0 && seg_n > 0 && seg_n <= SPB_LIGHT);      // one wave step per run
         uint64_t rem = dmask | bmask | lmask;
+        stamp(0);
+        int st_prev = -1;
         while (rem) {
+            if (st_prev >= 0) stamp(st_prev);
             const int j_first = __builtin_ctzll(rem);
             const bool dense_run = (dmask >> j_first) & 1;
             const bool light_run = (lmask >> j_first) & 1;
@@ -425,6 +438,7 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
             uint64_t run = same & rem & below;
             rem &= ~run;
             if (b.diag & (dense_run ? 2 : light_run ? 4 : 8)) continue;      // 2: dense, 4: light, 8: big runs skipped
+            st_prev = dense_run ? 1 : light_run ? 2 : 3;
             if (dense_run) {
                 if (!in_regs) { to_regs(); in_regs = true; }
                 auto dload = [&](int j, f32x4 (&v)[SPB_DV]) {
@@ -603,11 +617,17 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
                 }
             }
         }
+        if (st_prev >= 0) stamp(st_prev);
     }
     // ---- filter the 4 slices, from registers: score > threshold and score >= tau ---------------
     if (!in_regs) to_regs();
-    int cnt[SPB_Q];
-    int any = 0;
+    stamp(6);            // the barrier in front of the filter: waiting for the slowest wave's scatter walk
+    // Wave-level: every wave counts and places the survivors among ITS lanes' docs (the order inside a query's candidate list is
+    // free).  Per query one wave scan; the lanes 63 of the waves that keep something reserve their slots with one atomic each -
+    // all queries' atomics are in flight together - and nothing waits on a workgroup barrier or on another wave.  (Almost every
+    // (block, sub-tile) keeps a few docs per query for most of the scan: the workgroup-wide scan + serial atomics this replaces
+    // cost 6 of a workgroup's 30 us.)
+    int cnt[SPB_Q], incl[SPB_Q], base[SPB_Q];
 #pragma unroll
     for (int qi = 0; qi < SPB_Q; ++qi) {
         cnt[qi] = 0;
@@ -620,49 +640,42 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
                     cnt[qi] += (4 * SPB_THREADS * i + 4 * tid + e < n_here && sv > thr && sv >= tq[qi]) ? 1 : 0;
                 }
         }
-        any |= cnt[qi];
-    }
-    if (__syncthreads_or(any)) {            // most (block, sub-tile) pairs keep nothing once tau has tightened
-        int incl[SPB_Q];
-#pragma unroll
-        for (int qi = 0; qi < SPB_Q; ++qi) {
-            incl[qi] = cnt[qi];
+        incl[qi] = cnt[qi];
+        if (__ballot(cnt[qi] != 0)) {          // wave-uniform
             for (int off = 1; off < 64; off <<= 1) {
                 int o = __shfl_up(incl[qi], off);
                 if (lane >= off) incl[qi] += o;
             }
-            if (lane == 63) wave_tot[qi][wave] = incl[qi];
         }
-        __syncthreads();
-        if (tid < SPB_Q) {
-            int total = 0;
-            for (int w = 0; w < SPB_THREADS / 64; ++w) total += wave_tot[tid][w];
-            const int ql = b.blk_q[(int64_t)bx * SPB_Q + tid];
-            s_base[tid] = (total && ql >= 0) ? atomicAdd(&a.cand_count[ql], total) : 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int qi = 0; qi < SPB_Q; ++qi) {
-            if (qls[qi] < 0 || cnt[qi] == 0) continue;
-            int wbase = 0;
-            for (int w = 0; w < wave; ++w) wbase += wave_tot[qi][w];
-            int pos = s_base[qi] + wbase + incl[qi] - cnt[qi];
-            uint64_t* dst = a.cand_keys + (int64_t)qls[qi] * a.cand_cap;
-#pragma unroll
-            for (int i = 0; i < SPB_DV; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sv = acc[qi][i][e];
-                    const int d = 4 * SPB_THREADS * i + 4 * tid + e;
-                    if (d < n_here && sv > thr && sv >= tq[qi]) {
-                        if (pos < a.cand_cap) dst[pos] = sr_make_key(sv, a.id_base + (uint32_t)(doc0 + d) * a.id_stride);
-                        ++pos;
-                    }
-                }
-        }
+        base[qi] = 0;
+        if (lane == 63 && incl[qi] > 0) base[qi] = atomicAdd(&a.cand_count[qls[qi]], incl[qi]);
     }
+#pragma unroll
+    for (int qi = 0; qi < SPB_Q; ++qi) {
+        if (__ballot(cnt[qi] != 0) == 0) continue;          // wave-uniform: nothing of this query among this wave's docs
+        int pos = __builtin_amdgcn_readlane(base[qi], 63) + incl[qi] - cnt[qi];
+        if (cnt[qi] == 0) continue;
+        uint64_t* dst = a.cand_keys + (int64_t)qls[qi] * a.cand_cap;
+#pragma unroll
+        for (int i = 0; i < SPB_DV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sv = acc[qi][i][e];
+                const int d = 4 * SPB_THREADS * i + 4 * tid + e;
+                if (d < n_here && sv > thr && sv >= tq[qi]) {
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sv, a.id_base + (uint32_t)(doc0 + d) * a.id_stride);
+                    ++pos;
+                }
+            }
+    }
+    stamp(4);
     __syncthreads();       // the slices are re-used by the next sub-tile
   }
+    if (st && lane == 0) {
+        st_t[5] = __builtin_amdgcn_s_memrealtime() - st_first;
+        for (int i = 0; i < 7; ++i) atomicAdd(&b.stamps[i], st_t[i]);
+        atomicAdd(&b.stamps[7], 1ull);
+    }
 }
 
 // Order of a batch's queries before it is cut into blocks of SPB_Q.  Wave q of a workgroup walks query q's scatter terms
@@ -863,6 +876,7 @@ struct sr_sparse_index {
     int32_t* plan_n = nullptr;
     uint8_t* plan_ok = nullptr;
     int64_t* plan_off = nullptr;
+    unsigned long long* d_stamps = nullptr;   // dev switch SR_SPARSE_STAMPS
     int32_t* plan_perm = nullptr;     // every batch's queries in block order
     uint8_t* q_done = nullptr;
     int64_t plan_q_cap = 0;
@@ -1038,6 +1052,14 @@ extern "C" int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t
 
 extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     if (!idx) return SR_OK;
+    if (idx->d_stamps) {       // diagnostic: mean microseconds per phase of a sampled wave
+        unsigned long long h[8] = {0};
+        if (hipMemcpy(h, idx->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7])
+            fprintf(stderr, "[sparse stamps] waves %llu: fetch %.2f dense %.2f short %.2f long %.2f wait-for-slowest %.2f filter %.2f total %.2f us\n",
+                    h[7], h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[6] * 0.01 / h[7], h[4] * 0.01 / h[7],
+                    h[5] * 0.01 / h[7]);
+        (void)hipFree(idx->d_stamps);
+    }
     idx->ws.release();
     idx->order.release();
     sparse_free_device(idx);
@@ -1162,6 +1184,10 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                                              (int)(sizeof(float) * SPB_Q * SPB_TSTRIDE)));
             *slot = true;
         }
+        if (sr_dev_getenv("SR_SPARSE_STAMPS") && !idx->d_stamps) {
+            SR_CHECK_HIP(hipMalloc((void**)&idx->d_stamps, 8 * 8));
+            SR_CHECK_HIP(hipMemsetAsync(idx->d_stamps, 0, 8 * 8, s));
+        }
         ++idx->n_block_calls;
         if (any_fallback) ++idx->n_fallback_calls;
     }
@@ -1209,6 +1235,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 b.blk_q = idx->plan_perm + (qb / q_batch) * pad;
                 b.blk_base = (qb / q_batch) * blocks_per_batch;
                 b.diag = 0;
+                b.stamps = idx->d_stamps;
                 if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
                 b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));
                 const dim3 grid((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)ceil_div64(b.n_sub, SPB_SUBS));
