@@ -73,20 +73,21 @@ int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int
  *                       path), ~1.7x faster than fp32 MFMA; keeps three bf16 planes per segment.  */
 #define SR_PRECISION_BF16X6 2
 /*   SR_PRECISION_FP32_FILTERED  the SAME results as SR_PRECISION_FP32, bit for bit, several times faster for batches
- *                       > 64 queries: a bf16 score (one bf16 plane of the query x one plane of the document) picks
- *                       3k candidates per query, only those that can still reach the top-k are re-scored with the
- *                       exact fp32 fmaf chain, and a certificate (every outsider's exact score <= its bf16 score +
- *                       c|q|max|d| < the k-th exact score found) proves that the result is the exact top-k.  An
- *                       index whose score gaps are too tight for the one-product bound (c = 2^-8) is switched to
- *                       two query planes (c = 2^-9) for good; a batch that cannot be certified with those is redone
- *                       by the exact kernel.  Keeps one bf16 plane per segment (half the bytes of the fp32 rows);
- *                       without room for it the exact kernel is used.                                          */
+ *                       > 64 queries: one fp16 plane product (fp16 rounding of the query x fp16 rounding of the document,
+ *                       both scaled by powers of two) plus a per-pair error term e(q, j) built from the ACTUAL rounding
+ *                       residuals |d - d0|, |q - q0| (Cauchy-Schwarz) gives an upper bound U >= the exact fp32 score of
+ *                       every pair; the 3k documents with the largest U are the candidates, those that can still reach
+ *                       the top-k are re-scored with the exact fp32 fmaf chain, and the certificate U_3k < (k-th exact
+ *                       score found) proves that the result is the exact top-k.  A query without a certificate (more
+ *                       than 2k near-ties at the cut, a zero or non-finite query) is re-done by the exact kernel, that
+ *                       query alone.  Keeps one fp16 plane + 8 bytes per document (half the bytes of the fp32 rows);
+ *                       without room for it, or for data that is not finite, the exact kernel is used.            */
 #define SR_PRECISION_FP32_FILTERED 3
 int sr_dense_index_set_precision(sr_dense_index* idx, int mode);
-/* searches of more than 64 queries answered through the filter / redone by the exact kernel so far */
+/* searches of more than 64 queries answered by the filter alone / with some (or all) queries re-done by the exact kernel */
 int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback);
-/* plane products of the filter's approximate pass now (1 or 2) and how many times a failed certificate raised it */
-int sr_dense_index_filter_products(sr_dense_index* idx, int* products, int64_t* n_raised);
+/* the same per query: queries certified by the filter / re-done by the exact kernel so far */
+int sr_dense_index_filter_query_stats(sr_dense_index* idx, int64_t* n_certified, int64_t* n_redone);
 /* Workspace ceiling in bytes for candidate buffers (default 4 GiB). */
 int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes);
 int sr_dense_index_destroy(sr_dense_index* idx);

@@ -41,7 +41,7 @@ SIGNATURES = {
     "sr_dense_index_set_workspace_limit": (c_int, [c_void_p, c_int64]),
     "sr_dense_index_set_precision": (c_int, [c_void_p, c_int]),
     "sr_dense_index_filter_stats": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
-    "sr_dense_index_filter_products": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "sr_dense_index_filter_query_stats": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "sr_dense_index_destroy": (c_int, [c_void_p]),
     "sr_dense_index_profile": (c_int, [c_void_p, c_int]),
     "sr_dense_index_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double),

@@ -15,6 +15,18 @@ void sr_set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 
+int sr_cu_count() {
+    static int per_dev[SR_MAX_DEVICES] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SR_MAX_DEVICES) d = 0;
+    if (per_dev[d] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        per_dev[d] = n;
+    }
+    return per_dev[d];
+}
+
 extern "C" const char* sr_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sr_version(void) { return 1; }
 extern "C" int sr_max_topk(void) { return SR_MAX_TOPK; }

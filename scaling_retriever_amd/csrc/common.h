@@ -45,6 +45,8 @@ static inline const char* sr_dev_getenv(const char* name) {
     } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// compute units of the current device (256 on MI355X); api.hip
+int sr_cu_count();
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: a per-kernel flag array indexed by the CURRENT device, so a
 // process that drives several GPUs sets it on each (set twice by racing threads is harmless: same value).

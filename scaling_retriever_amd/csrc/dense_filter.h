@@ -3,30 +3,44 @@
 #include "common.h"
 
 #define SR_FILTER_MAX_SEGS 64
+#define SR_FILTER_MAX_SHIFT 40     // the power-of-two scales of segments and queries are 2^t with |t| <= 40
 struct FilterSegs {                 // where a global doc index lives: row = (gid - id_base) / id_stride of segment s
     const float* rows[SR_FILTER_MAX_SEGS];
+    const float* xy[SR_FILTER_MAX_SEGS];      // [n, 2] per-document error terms of the segment's fp16 plane (scaled domain)
+    float isd[SR_FILTER_MAX_SEGS];            // inverse of the segment's scale
     int64_t n[SR_FILTER_MAX_SEGS];
     uint32_t id_base[SR_FILTER_MAX_SEGS], id_stride[SR_FILTER_MAX_SEGS];
     int count;
 };
 
-// |S_a - S_x| <= sr_filter_c(H, products) * |q| * |d| for the filter's score S_a = q0 . d0 (products = 1) or
-// (q0 + q1) . d0 (products = 2) against the fp32 fmaf chain S_x
-double sr_filter_c(int H, int products);
-// *d_max2 = max(*d_max2, max over rows of |row|^2)   (non-negative floats order as their bit patterns)
-int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s);
-// qnorm[q] = |Q[q]|
-int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStream_t s);
-// Candidates = the kp best approximate scores per query, sorted descending (a_scores / a_ids [nq, kp], pads id < 0).
-// launch_filter_rescore: exact score of every candidate that can still be in the top-k (approximate score within 2E of
-// the k-th best approximate score, and - for the candidates beyond the k best - within E of the smallest exact score of
-// those k, xmin [nq] scratch; the others are provably out) = fp32 fmaf chain in the k order of dense_score_pipe_kernel, key =
-// (score desc, doc index asc) into cand_keys [nq, cand_cap]; flags[q] |= 2 if a candidate's two scores differ by more than
-// the bound.  launch_filter_certify (after the exact top-k x_scores [nq, k] is known): flags[q] |= 1 unless every document
-// outside the candidates is provably below the k-th exact score.  flags must be zeroed first; non-zero -> the caller falls
-// back to the exact kernel.
-int launch_filter_certify(const float* a_scores, const float* x_scores, const float* qnorm, const float* d_max2, int64_t nq, int k,
-                          int kp, double c, int* flags, hipStream_t s);
-int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
-                          const float* d_max2, int64_t nq, int k, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
-                          int64_t cand_cap, int* flags, unsigned int* xmin, hipStream_t s);
+// sigma(H): the share of |q||d| the two fp32 summations (the exact fmaf chain and the MFMA's accumulation of the plane
+// product) can differ by, with slack for the epilogue's own roundings
+double sr_filter_sigma(int H);
+// *d_absmax_bits = max(*d_absmax_bits, bits of max |x| over the rows); a NaN or an infinity shows up as bits >= 0x7f800000
+int launch_filter_absmax(const float* rows, int64_t n, int H, unsigned int* d_absmax_bits, hipStream_t s);
+// the power-of-two scale that puts absmax into [2^14, 2^15) (clamped to 2^+-SR_FILTER_MAX_SHIFT); false when absmax is not
+// finite or the clamp would let a scaled value overflow fp16
+bool sr_filter_scale_of(float absmax, float* scale, float* inv_scale);
+// fp16 plane of a segment: plane[r, i] = fp16(rows[r, i] * sd), and per document, in the scaled domain,
+//   xy[r] = ((|rows_r sd - plane_r| + sigma |rows_r sd|) * 1.001, |plane_r| * 1.001);  *d_bad |= 1 on any non-finite value
+int launch_filter_plane(const float* rows, int64_t n, int H, float sd, double sigma, unsigned short* plane, float* xy, int* d_bad,
+                        hipStream_t s);
+// fp16 plane of the queries, each scaled by its own power of two sq, and qa[q] = (A', B', sq, 1 / sq):
+//   A' = |q sq| * 1.001, B' = |q sq - plane_q| * 1.001; a query that cannot be filtered (non-finite, out of the scale range)
+//   gets A' = +inf and is re-done by the exact kernel
+int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* plane, float* qa, hipStream_t s);
+// Candidates = the kp best upper bounds U per query, sorted descending (u_scores / u_ids [nq, kp], pads id < 0).
+// launch_filter_rescore: exact score (fp32 fmaf chain in the k order of dense_score_pipe_kernel) of the first min(k, kp)
+// candidates, then of every later candidate whose upper bound reaches the smallest exact score among those (xmin [nq]
+// scratch) - the others are provably outside the top-k; key = (score desc, doc index asc) into cand_keys [nq, cand_cap];
+// flags[q] |= 2 if a candidate's exact score lies outside [U - 2 e, U] (the bound itself, checked on every re-scored pair).
+// launch_filter_certify (after the exact top-k x_scores [nq, k] is known): flags[q] |= 1 unless every document outside the
+// candidates is provably below the k-th exact score (U_kp < x_k), or there are no outsiders.  flags must be zeroed first;
+// a flagged query is re-done by the exact kernel.
+int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
+                          int64_t nq, int k, int kp, int H, uint64_t* cand_keys, int* cand_count, int64_t cand_cap, int* flags,
+                          unsigned int* xmin, hipStream_t s);
+int launch_filter_certify(const float* u_scores, const float* x_scores, const float* qa, int64_t nq, int k, int kp, int* flags,
+                          hipStream_t s);
+// rows of src [*, width] picked by idx [n] -> dst [n, width] (gather), or dst rows idx[i] <- src row i (scatter); 4-byte elements
+int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t width, void* dst, bool scatter, hipStream_t s);

@@ -1,106 +1,202 @@
-// Exact dense top-k at bf16 speed: a certified filter in front of an exact re-score (gfx950).
+// Exact dense top-k at fp16 MFMA speed: a certified filter in front of an exact re-score (gfx950).
 //
 // sr_dense_search must return what faiss.IndexFlatIP.search returns (scaling_retriever/indexer.py:210-214): the k largest
 // fp32 inner products.  dense_score_pipe_kernel computes every one of the nq x N products on the fp32 MFMA pipe (157 TF
-// peak).  The bf16 MFMA pipe is 16x faster, and the score S_a = (q0 + q1) . d0 - two bf16 planes of the query against ONE
-// bf16 plane of the document, 2 plane products (dense_split.hip) - differs from the fp32 chain S_x by a PROVABLY bounded
-// amount, so it can decide which few documents need the exact arithmetic at all:
+// peak).  The 16-bit MFMA pipe is 16x faster, and ONE plane product q0 . d0 - the fp16 rounding of the (power-of-two scaled)
+// query against the fp16 rounding of the (scaled) document - differs from the fp32 chain S_x by an amount that is bounded
+// PER PAIR by quantities known exactly at index / query time, so it can decide which few documents need exact arithmetic:
 //
-//   1. approximate pass: the kp = 3k best documents by S_a per query (dense_split_kernel + the fused top-k, unchanged);
-//   2. exact pass: S_x for those kp candidates only - the same fp32 fmaf chain, in the same k order, as
-//      dense_score_pipe_kernel (oracle: scoring.mfma_korder) - then the top-k by (S_x desc, doc index asc);
-//   3. certificate: with E = c |q| max|d| >= |S_a - S_x| for every document, a document that is NOT a candidate has
-//      S_x <= S_a + E <= a_kp + E (a_kp = the kp-th best S_a).  If a_kp + E is strictly below the k-th best exact score
-//      found among the candidates, no outsider can enter the top-k or tie with its last member: the result IS the exact
-//      top-k.
-// The result is bit-identical to the exact kernel's (tests/test_dense_filtered_gpu.py, and every bench.py run on the whole
-// problem).  A query whose certificate fails (more than kp - k documents inside the margin: near-duplicates, a zero query)
-// or for which any candidate's |S_a - S_x| exceeds E (the bound is checked on every pair that is re-scored) makes
-// sr_dense_search redo the batch with the exact kernel - correctness never rests on the filter.
+//   1. upper-bound pass (dense_split_kernel<true>): U(q, j) = q0 . d0 + e(q, j) >= S_x(q, j) for every pair; the kp = 3k
+//      documents with the largest U per query are the candidates (fused top-k, unchanged);
+//   2. exact pass: S_x for the first k candidates, then for every later candidate whose U reaches the smallest exact score
+//      found among those (a candidate with U below it cannot be in the top-k) - the same fp32 fmaf chain, in the same k
+//      order, as dense_score_pipe_kernel (oracle: scoring.mfma_korder) - then the top-k by (S_x desc, doc index asc);
+//   3. certificate: a document that is NOT a candidate has S_x <= U <= U_kp (the kp-th largest U).  If U_kp is strictly
+//      below the k-th best exact score found among the candidates, no outsider can enter the top-k or tie with its last
+//      member: the result IS the exact top-k.
+// A query whose certificate fails (more than kp - k documents inside the margin: near-duplicates, a zero query) or for which
+// any re-scored pair violates S_x in [U - 2e, U] (the bound, checked on every pair that is re-scored) is re-done by the exact
+// kernel - that query alone (sr_dense_search gathers the flagged queries into one small exact batch).  Correctness never
+// rests on the filter; tests/test_dense_filtered_gpu.py and every bench.py run compare with the exact kernel bit for bit.
 //
-// The bound.  B = sum |q_i||d_i| <= |q||d|;  u = 2^-24, gamma_n = n u / (1 - n u).
-//   fp32 chain of H fmaf:                          |S_x - q.d| <= gamma_H B
-//   planes: x0 = bf16(x): |x - x0| <= 2^-9 |x|;  x1 = bf16(x - x0): |x - x0 - x1| <= 2^-18 |x|
-//     q.d - (q0 + q1).d0 = q.(d - d0) + (q - q0 - q1).d0:      <= (2^-9 + 2^-18 (1 + 2^-9)) B
-//   2H bf16 products (exact in fp32) summed in fp32 by the MFMA, 32 per instruction, modelled as no better than a plain
-//     fp32 summation of 2H terms:                                <= gamma_2H * 1.004 B
-//   c(H) = 2^-9 * 1.004 + 1.25 * (3 H 2^-24) + 1e-5   (2.43e-3 at H = 2048, 2.89e-3 at 4096) covers the sum with room to
-//   spare; the measured maximum is ~1e-3 (the 2^-9 plane truncation dominates).
-//   One product, S_a = q0 . d0:   q.d - q0.d0 = q.(d - d0) + (q - q0).d0 <= (2^-9 + 2^-9 (1 + 2^-9)) B, H products summed:
-//   c1(H) = 2^-8 * 1.004 + the same summation terms (4.38e-3 at H = 2048).  Half the MFMA work of the two-product pass; it
-//   needs twice the gap between the k-th and the kp-th score, which sr_dense_search tries first (dense_score.hip).
+// The bound.  Primes = the scaled domain (q' = q sq, d' = d sd, sq / sd powers of two: exact).  q0 = fp16(q'), d0 = fp16(d').
+//   q'.d' - q0.d0 = q'.(d' - d0) + (q' - q0).d0, so by Cauchy-Schwarz   |q'.d' - q0.d0| <= |q'| |d' - d0| + |q' - q0| |d0|
+//   with the ACTUAL residual norms |d' - d0| (per document, stored at index time) and |q' - q0| (per query): no worst-case
+//   unit roundoff enters (round 2 used 2^-9 |x| per bf16 plane - but bf16 has 8 significand bits, its unit roundoff is 2^-8;
+//   that constant was wrong by 2x.  fp16 planes: 11 bits, typical residual 2.3e-4 |x|, and nothing is assumed about it).
+//   fp32 chain of H fmaf: |S_x - q.d| <= gamma_H |q||d|  (u = 2^-24, gamma_n = n u / (1 - n u));  the MFMA's fp32 summation
+//   of the H exact products (fp16 x fp16 is exact in fp32), modelled as no better than a plain fp32 sum with truncation:
+//   <= 2 H u |q0||d0|.   sigma(H) = 1.25 * 3 H 2^-24 + 1e-5 covers both and the epilogue's roundings.
+//   e'(q, j) = A'[q] X'[j] + B'[q] Y'[j],  A' = |q'| 1.001, B' = |q' - q0| 1.001,
+//              X' = (|d' - d0| + sigma |d'|) 1.001, Y' = |d0| 1.001          (1.001: the fp32 evaluation of the norms)
+//   U' = acc + e' (two fmas in the kernel epilogue), compared with tau sq sd; a survivor's key carries U = U' / (sq sd).
+//   At H = 2048 on unit-scale Gaussian data e ~ 8e-4 |q||d| (4.6e-4 of it sigma), against 4.4e-3 |q| max|d| in round 2.
 #include "dense_filter.h"
 #include <math.h>
 
-double sr_filter_c(int H, int products) {
-    return ldexp(1.0, products == 1 ? -8 : -9) * 1.004 + 1.25 * (3.0 * (double)H * ldexp(1.0, -24)) + 1.0e-5;
+double sr_filter_sigma(int H) { return 1.25 * (3.0 * (double)H * ldexp(1.0, -24)) + 1.0e-5; }
+
+__global__ __launch_bounds__(256) void filter_absmax_kernel(const float* __restrict__ rows, int64_t n4, unsigned int* __restrict__ out) {
+    unsigned int mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(rows)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int b = __float_as_uint(v[e]) & 0x7fffffffu;     // |x| as bits: ordered like the magnitudes, NaN on top
+            mx = b > mx ? b : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
 }
 
-__global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ rows, int64_t n, int H, float* __restrict__ d_max2) {
+int launch_filter_absmax(const float* rows, int64_t n, int H, unsigned int* d_absmax_bits, hipStream_t s) {
+    const int64_t n4 = n * (int64_t)H / 4;
+    if (n4 == 0) return SR_OK;
+    int64_t blocks = ceil_div64(n4, 256 * 8);
+    if (blocks > (1 << 16)) blocks = 1 << 16;
+    hipLaunchKernelGGL(filter_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows, n4, d_absmax_bits);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+bool sr_filter_scale_of(float absmax, float* scale, float* inv_scale) {
+    *scale = *inv_scale = 1.0f;
+    if (!(absmax < 3.0e38f)) return false;
+    if (!(absmax > 0.f)) return true;                       // all zeros: any scale
+    int e;
+    (void)frexpf(absmax, &e);                               // absmax = m 2^e, m in [0.5, 1)
+    int t = 15 - e;
+    if (t < -SR_FILTER_MAX_SHIFT) return false;             // values beyond 2^55: the clamped scale would overflow fp16
+    if (t > SR_FILTER_MAX_SHIFT) t = SR_FILTER_MAX_SHIFT;   // tiny values: less precise planes, honest residuals
+    *scale = ldexpf(1.0f, t);
+    *inv_scale = ldexpf(1.0f, -t);
+    return true;
+}
+
+// one wave per row; a row of H <= 8192 floats passes through registers once
+template <bool QUERY>
+__global__ __launch_bounds__(256) void filter_plane_kernel(const float* __restrict__ rows, int64_t n, int H, float sd, float sigma,
+                                                           unsigned short* __restrict__ plane, float* __restrict__ out, int* __restrict__ d_bad) {
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
-    float mx = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {   // grid-stride (< 2^32 threads)
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
         const float* p = rows + r * H;
-        float ss = 0.f;
+        float scale = sd, inv = 1.f;
+        bool ok = true;
+        if (QUERY) {                          // its own power-of-two scale
+            unsigned int mx = 0;
+            for (int i = lane * 4; i < H; i += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const unsigned int b = __float_as_uint(v[e]) & 0x7fffffffu; mx = b > mx ? b : mx; }
+            }
+            for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+            const float am = __uint_as_float(mx);
+            scale = 1.f;
+            if (!(am < 3.0e38f)) ok = false;
+            else if (am > 0.f) {
+                int e;
+                (void)frexpf(am, &e);
+                int t = 15 - e;
+                if (t < -SR_FILTER_MAX_SHIFT) ok = false;
+                t = t > SR_FILTER_MAX_SHIFT ? SR_FILTER_MAX_SHIFT : (t < -SR_FILTER_MAX_SHIFT ? -SR_FILTER_MAX_SHIFT : t);
+                scale = ldexpf(1.0f, t);
+                inv = ldexpf(1.0f, -t);
+            }
+        }
+        float s_n = 0.f, s_0 = 0.f, s_r = 0.f;
         for (int i = lane * 4; i < H; i += 256) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float vs = v[e] * scale;                 // exact (power of two), |vs| < 2^15 unless the clamp is active
+                const _Float16 h = (_Float16)vs;               // round to nearest even
+                const float hf = (float)h;
+                const float res = vs - hf;                     // exact in fp32
+                s_n += vs * vs;
+                s_0 += hf * hf;
+                s_r += res * res;
+                o[e] = (short)__builtin_bit_cast(unsigned short, h);
+            }
+            *reinterpret_cast<bf16x4*>(plane + r * H + i) = o;
         }
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-        // NaN / inf rows make every bound meaningless: record +inf so that nothing is ever certified
-        if (!(ss < INFINITY)) ss = INFINITY;
-        mx = fmaxf(mx, ss);
+        for (int off = 32; off > 0; off >>= 1) {
+            s_n += __shfl_xor(s_n, off);
+            s_0 += __shfl_xor(s_0, off);
+            s_r += __shfl_xor(s_r, off);
+        }
+        if (lane == 0) {
+            const float nn = sqrtf(s_n), n0 = sqrtf(s_0), nr = sqrtf(s_r);
+            if (QUERY) {
+                float A = nn * 1.001f, B = nr * 1.001f;
+                if (!ok || !(A < INFINITY) || !(B < INFINITY) || !(n0 < INFINITY)) A = INFINITY;     // not filterable: exact kernel
+                reinterpret_cast<f32x4*>(out)[r] = f32x4{A, B, scale, inv};
+            } else {
+                const float X = (nr + sigma * nn) * 1.001f, Y = n0 * 1.001f;
+                out[r * 2] = X;
+                out[r * 2 + 1] = Y;
+                if (!(X < INFINITY) || !(Y < INFINITY)) atomicOr(d_bad, 1);
+            }
+        }
     }
-    if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(d_max2), __float_as_uint(mx * 1.0001f));   // summation slack
 }
 
-int launch_row_norm2_max(const float* rows, int64_t n, int H, float* d_max2, hipStream_t s) {
+int launch_filter_plane(const float* rows, int64_t n, int H, float sd, double sigma, unsigned short* plane, float* xy, int* d_bad,
+                        hipStream_t s) {
     if (n == 0) return SR_OK;
     int64_t blocks = ceil_div64(n, 4);
     if (blocks > (1 << 20)) blocks = 1 << 20;
-    hipLaunchKernelGGL(row_norm2_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows, n, H, d_max2);
+    hipLaunchKernelGGL(filter_plane_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, rows, n, H, sd, (float)sigma, plane, xy, d_bad);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
 
-__global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict__ Q, int64_t nq, int H, float* __restrict__ qnorm) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    float ss = 0.f;
-    for (int i = lane * 4; i < H; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Q + q * H + i);
-        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) qnorm[q] = (ss < INFINITY) ? sqrtf(ss * 1.0001f) : INFINITY;
-}
-
-int launch_query_norms(const float* Q, int64_t nq, int H, float* qnorm, hipStream_t s) {
-    hipLaunchKernelGGL(query_norm_kernel, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, s, Q, nq, H, qnorm);
+int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* plane, float* qa, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    hipLaunchKernelGGL(filter_plane_kernel<true>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, s, Q, nq, H, 1.0f, 0.0f, plane, qa,
+                       (int*)nullptr);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
 
-__global__ void filter_certify_kernel(const float* __restrict__ a_scores, const float* __restrict__ x_scores,
-                                      const float* __restrict__ qnorm, const float* __restrict__ d_max2, int64_t nq, int k, int kp,
-                                      double c, int* __restrict__ flags) {
+__global__ void filter_certify_kernel(const float* __restrict__ u_scores, const float* __restrict__ x_scores,
+                                      const float* __restrict__ qa, int64_t nq, int k, int kp, int* __restrict__ flags) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
-    const double akp = (double)a_scores[q * kp + (kp - 1)];   // kp-th best approximate score; -FLT_MAX pad when fewer documents exist
-    const double xk = (double)x_scores[q * k + (k - 1)];      // k-th best EXACT score among the candidates (pad when fewer than k)
-    // fewer than kp documents: every document was re-scored.  Otherwise every outsider's exact score is <= akp + E, which
-    // must stay strictly below the k-th exact score.  NaN / inf anywhere -> not certified.
-    const bool all_docs = akp <= -3.0e38;
-    const bool ok = all_docs || (E < INFINITY && xk > -3.0e38 && akp + E < xk);
+    const float A = qa[q * 4], B = qa[q * 4 + 1];
+    const float ukp = u_scores[q * kp + (kp - 1)];   // kp-th largest upper bound; -FLT_MAX pad when fewer documents exist
+    const float xk = x_scores[q * k + (k - 1)];      // k-th best EXACT score among the candidates (pad when fewer than k)
+    // fewer than kp documents: every document was re-scored.  Otherwise every outsider's exact score is <= ukp, which must
+    // stay strictly below the k-th exact score.  NaN / inf anywhere -> not certified.
+    const bool finite = A < INFINITY && B < INFINITY;
+    const bool all_docs = ukp <= -3.0e38f;
+    const bool ok = finite && (all_docs || (xk > -3.0e38f && ukp < xk));
     if (!ok) atomicOr(&flags[q], 1);
 }
 
-int launch_filter_certify(const float* a_scores, const float* x_scores, const float* qnorm, const float* d_max2, int64_t nq, int k,
-                          int kp, double c, int* flags, hipStream_t s) {
-    hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, a_scores, x_scores, qnorm, d_max2,
-                       nq, k, kp, c, flags);
+int launch_filter_certify(const float* u_scores, const float* x_scores, const float* qa, int64_t nq, int k, int kp, int* flags,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, u_scores, x_scores, qa, nq, k, kp,
+                       flags);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+__global__ __launch_bounds__(256) void filter_gather_rows_kernel(const uint32_t* __restrict__ src, const int64_t* __restrict__ idx, int64_t width,
+                                                                 uint32_t* __restrict__ dst, int scatter) {
+    const int64_t i = blockIdx.x;
+    const int64_t r = idx[i];
+    const uint32_t* sp = src + (scatter ? i : r) * width;
+    uint32_t* dp = dst + (scatter ? r : i) * width;
+    for (int64_t c = threadIdx.x; c < width; c += blockDim.x) dp[c] = sp[c];
+}
+
+int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t width, void* dst, bool scatter, hipStream_t s) {
+    if (n == 0 || width == 0) return SR_OK;
+    hipLaunchKernelGGL(filter_gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, (const uint32_t*)src, idx, width, (uint32_t*)dst,
+                       scatter ? 1 : 0);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -110,12 +206,11 @@ int launch_filter_certify(const float* a_scores, const float* x_scores, const fl
 // broadcast read, and every lane runs the fp32 fmaf chain of ITS candidate in dense_score_pipe_kernel's k order: per
 // group of 8 columns, k = 8s + j then 8s + 4 + j for j = 0..3.
 #define RS_KC 64
-__global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, const float* __restrict__ Q, const float* __restrict__ a_scores,
-                                                            const int64_t* __restrict__ a_ids, const float* __restrict__ qnorm,
-                                                            const float* __restrict__ d_max2, int k, int kp, int H, double c,
-                                                            uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
-                                                            int64_t cand_cap, int* __restrict__ flags, int j_begin,
-                                                            unsigned int* __restrict__ xmin) {
+__global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, const float* __restrict__ Q, const float* __restrict__ u_scores,
+                                                            const int64_t* __restrict__ u_ids, const float* __restrict__ qa,
+                                                            int k, int kp, int H, uint64_t* __restrict__ cand_keys,
+                                                            int* __restrict__ cand_count, int64_t cand_cap, int* __restrict__ flags,
+                                                            int j_begin, unsigned int* __restrict__ xmin) {
 #pragma clang fp contract(off)
     __shared__ float tile[64][RS_KC + 1];
     __shared__ float qs[RS_KC];
@@ -124,28 +219,26 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     const int64_t q = blockIdx.x;
     const int j0 = j_begin + blockIdx.y * 64;
     const int j = j0 + lane;
-    const int j_end = j_begin == 0 ? (k < kp ? k : kp) : kp;        // stage 1: the k best approximate scores; stage 2: the rest
+    const int j_end = j_begin == 0 ? (k < kp ? k : kp) : kp;        // stage 1: the k largest upper bounds; stage 2: the rest
     if (j0 >= j_end) return;
-    // A candidate whose approximate score lies more than 2E below the k-th best approximate score cannot be in the exact
-    // top-k: its exact score is < a_k - E, and the k candidates with approximate scores >= a_k all have exact scores >= a_k - E.
-    // The approximate list is sorted, so what has to be re-scored is a prefix of it.
-    const double E = c * (double)qnorm[q] * sqrt((double)*d_max2);
-    double need = (double)a_scores[q * kp + (k < kp ? k : kp) - 1] - 2.0 * E;
-    // stage 2 knows better: the smallest EXACT score among the k candidates of stage 1 is a lower bound of the exact k-th
-    // score, and a candidate with S_a + E strictly below it cannot reach the top-k
-    if (j_begin > 0) {
-        const double lo = (double)sr_ord2f(xmin[q]) - E;
-        need = lo > need ? lo : need;
-    }
-    if ((double)a_scores[q * kp + j0] < need) return;           // the whole wave
-    int64_t gid = j < j_end ? a_ids[q * kp + j] : -1;
-    if (gid >= 0 && (double)a_scores[q * kp + j] < need) gid = -1;
+    // stage 2: the smallest EXACT score among the k candidates of stage 1 is a lower bound of the exact k-th score; a
+    // candidate whose upper bound lies strictly below it cannot reach the top-k, nor tie with its last member.  The list is
+    // sorted by U, so what has to be re-scored is a prefix of it.
+    float need = -INFINITY;
+    if (j_begin > 0) need = sr_ord2f(xmin[q]);
+    if (u_scores[q * kp + j0] < need) return;           // the whole wave
+    int64_t gid = j < j_end ? u_ids[q * kp + j] : -1;
+    if (gid >= 0 && u_scores[q * kp + j] < need) gid = -1;
     const float* row = nullptr;
+    double e2 = 0.0;                                     // 2 e(q, j) in the true domain
     if (gid >= 0) {
         for (int sgi = 0; sgi < segs.count; ++sgi) {
             const int64_t off = gid - (int64_t)segs.id_base[sgi];
             if (off >= 0 && off % segs.id_stride[sgi] == 0 && off / segs.id_stride[sgi] < segs.n[sgi]) {
-                row = segs.rows[sgi] + (off / segs.id_stride[sgi]) * (int64_t)H;
+                const int64_t r = off / segs.id_stride[sgi];
+                row = segs.rows[sgi] + r * (int64_t)H;
+                e2 = 2.0 * ((double)qa[q * 4] * (double)segs.xy[sgi][r * 2] + (double)qa[q * 4 + 1] * (double)segs.xy[sgi][r * 2 + 1]) *
+                     (double)qa[q * 4 + 3] * (double)segs.isd[sgi];
                 break;
             }
         }
@@ -185,40 +278,41 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
             }
     };
     f32x4 va[16], vb[16];
-    float qa, qb;
-    fetch(0, va, qa);
+    float qva, qvb;
+    fetch(0, va, qva);
     for (int k0 = 0; k0 < H; k0 += 2 * RS_KC) {       // H is a multiple of RS_KC; an odd chunk count ends in the first half
         const bool has_b = k0 + RS_KC < H;
-        if (has_b) fetch(k0 + RS_KC, vb, qb);
-        chunk(va, qa);
+        if (has_b) fetch(k0 + RS_KC, vb, qvb);
+        chunk(va, qva);
         if (!has_b) break;
-        if (k0 + 2 * RS_KC < H) fetch(k0 + 2 * RS_KC, va, qa);
-        chunk(vb, qb);
+        if (k0 + 2 * RS_KC < H) fetch(k0 + 2 * RS_KC, va, qva);
+        chunk(vb, qvb);
     }
     if (row) {
-        // the bound, checked on every pair that is re-scored
-        if (!(fabs((double)acc - (double)a_scores[q * kp + j]) <= E)) atomicOr(&flags[q], 2);
+        // the bound, checked on every pair that is re-scored: S_x in [U - 2e, U]
+        const double U = (double)u_scores[q * kp + j];
+        if (!((double)acc <= U && (double)acc >= U - e2 * 1.001)) atomicOr(&flags[q], 2);
         const int pos = atomicAdd(&cand_count[q], 1);
         if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
         if (j_begin == 0) atomicMin(&xmin[q], sr_f2ord(acc));
     }
 }
 
-int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* a_scores, const int64_t* a_ids, const float* qnorm,
-                          const float* d_max2, int64_t nq, int k, int kp, int H, double c, uint64_t* cand_keys, int* cand_count,
-                          int64_t cand_cap, int* flags, unsigned int* xmin, hipStream_t s) {
+int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
+                          int64_t nq, int k, int kp, int H, uint64_t* cand_keys, int* cand_count, int64_t cand_cap, int* flags,
+                          unsigned int* xmin, hipStream_t s) {
     SR_REQUIRE(H % RS_KC == 0, "filter(rescore): dim %d must be a multiple of %d", H, RS_KC);
     SR_REQUIRE(nq <= 0x7fffffff && ceil_div64(kp, 64) <= 65535, "filter(rescore): grid too large");
-    // stage 1: the k best candidates by approximate score (and the smallest exact score among them, xmin); stage 2: the rest,
-    // pruned against xmin.  When stage 1 saw fewer than k documents there is nothing left for stage 2.
+    // stage 1: the k candidates with the largest upper bounds (and the smallest exact score among them, xmin); stage 2: the
+    // rest, pruned against xmin.  When stage 1 saw fewer than k documents there is nothing left for stage 2.
     SR_CHECK_HIP(hipMemsetAsync(xmin, 0xff, (size_t)nq * 4, s));
     const int k1 = k < kp ? k : kp;
-    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(k1, 64)), dim3(64), 0, s, segs, Q, a_scores, a_ids,
-                       qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags, 0, xmin);
+    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(k1, 64)), dim3(64), 0, s, segs, Q, u_scores, u_ids,
+                       qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, 0, xmin);
     SR_CHECK_LAUNCH();
     if (kp > k1) {
-        hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp - k1, 64)), dim3(64), 0, s, segs, Q, a_scores,
-                           a_ids, qnorm, d_max2, k, kp, H, c, cand_keys, cand_count, cand_cap, flags, k1, xmin);
+        hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp - k1, 64)), dim3(64), 0, s, segs, Q, u_scores,
+                           u_ids, qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, k1, xmin);
         SR_CHECK_LAUNCH();
     }
     return SR_OK;

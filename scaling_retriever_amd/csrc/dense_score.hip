@@ -375,9 +375,15 @@ struct DenseSegment {
     const float* rows;
     int64_t n;
     int64_t id_base, id_stride;
-    unsigned short* pl[3] = {nullptr, nullptr, nullptr};   // library-owned bf16 planes (split precisions only)
+    unsigned short* pl[3] = {nullptr, nullptr, nullptr};   // library-owned bf16 planes (bf16x3 / bf16x6 score modes only)
     int n_planes = 0;
-    bool in_dmax = false;      // its rows are folded into sr_dense_index::d_max2 (filtered mode)
+    // certified filter (SR_PRECISION_FP32_FILTERED, dense_filter.hip): fp16 plane of the rows scaled by fsd (a power of two)
+    // and the per-document error terms (x, y); f_state: 0 = not built, 1 = ready, -1 = cannot be filtered (non-finite or
+    // out-of-range values, no memory)
+    unsigned short* fpl = nullptr;
+    float* fxy = nullptr;
+    float fsd = 1.f, fisd = 1.f;
+    int f_state = 0;
 };
 
 struct sr_dense_index {
@@ -394,24 +400,56 @@ struct sr_dense_index {
     std::mutex mu;
     // SR_PRECISION_FP32_FILTERED (dense_filter.hip)
     TopkWS ws2;                       // exact top-k over the re-scored candidates
-    float* d_max2 = nullptr;          // max |row|^2 over all segments
-    float* qnorm = nullptr;           // [fq_cap]
-    float* a_scores = nullptr;        // [fq_cap, fkp] approximate top-kp, sorted
+    TopkWS ws3;                       // exact re-do of the queries without a certificate
+    float* qa = nullptr;              // [fq_cap, 4] per query (A', B', sq, 1 / sq)
+    float* a_scores = nullptr;        // [fq_cap, fkp] the kp largest upper bounds U, sorted
     int64_t* a_ids = nullptr;
-    int* flags = nullptr;             // [fq_cap + 1]: per query, + the OR of all of them
+    int* flags = nullptr;             // [2 fq_cap + 2]: per-query flags, then the xmin scratch of the re-score
     int64_t fq_cap = 0;
     int fkp = 0;
-    int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter / redone by the exact kernel
-    int filter_products = 1;                  // plane products of the filter's approximate pass (1, or 2 after a failed certificate)
-    int64_t n_downgrade = 0;
+    unsigned int* f_scratch = nullptr;    // [2]: absmax bits, bad flag (segment preparation)
+    // queries the certificate could not be given for are re-done by the exact kernel, those alone
+    float* redo_q = nullptr; int64_t* redo_idx = nullptr; float* redo_scores = nullptr; int64_t* redo_ids = nullptr;
+    int64_t redo_cap = 0; int redo_k = 0;
+    int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter alone / with queries (or all) redone by the exact kernel
+    int64_t nq_certified = 0, nq_redone = 0;  // queries answered by the filter / re-done by the exact kernel
 };
 
-// bf16 planes of every segment a precision needs (the certified filter scores against plane 0 only)
+// bf16 planes of every segment a score mode needs (the certified filter keeps its own fp16 plane, filter_prepare_segment)
 static int planes_of(int precision) {
-    return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : (precision == SR_PRECISION_FP32_FILTERED ? 1 : 0));
+    return precision == SR_PRECISION_BF16X6 ? 3 : (precision == SR_PRECISION_BF16X3 ? 2 : 0);
 }
-#define SR_PASS_FILTER 100   // dense_search_pass: the filter's 2-product pass, (q0 + q1) . d0
-#define SR_PASS_FILTER1 101  // the filter's 1-product pass, q0 . d0
+#define SR_PASS_FILTER 101   // dense_search_pass: the filter's upper-bound pass (one fp16 plane product + the per-pair error term)
+
+// fp16 plane + per-document error terms of one segment.  Never fails the caller: a segment that cannot be filtered (values
+// that are not finite or beyond 2^55, no device memory for the plane) is marked, and the index then answers with the exact
+// kernel - the filter is an accelerator of the exact search, not a precondition.
+static int filter_prepare_segment(sr_dense_index* idx, DenseSegment& seg) {
+    if (seg.f_state != 0) return SR_OK;
+    seg.f_state = -1;
+    if (idx->dim % 64 != 0) return SR_OK;
+    if (!idx->f_scratch && hipMalloc((void**)&idx->f_scratch, 8) != hipSuccess) { (void)hipGetLastError(); idx->f_scratch = nullptr; return SR_OK; }
+    unsigned int h[2] = {0, 0};
+    SR_CHECK_HIP(hipMemsetAsync(idx->f_scratch, 0, 8, nullptr));
+    SR_TRY(launch_filter_absmax(seg.rows, seg.n, idx->dim, idx->f_scratch, nullptr));
+    SR_CHECK_HIP(hipMemcpy(h, idx->f_scratch, 8, hipMemcpyDeviceToHost));
+    float absmax;
+    memcpy(&absmax, &h[0], 4);
+    if (h[0] >= 0x7f800000u || !sr_filter_scale_of(absmax, &seg.fsd, &seg.fisd)) return SR_OK;
+    const size_t bytes = (size_t)seg.n * (size_t)idx->dim * 2;
+    if (hipMalloc((void**)&seg.fpl, bytes) != hipSuccess || hipMalloc((void**)&seg.fxy, (size_t)seg.n * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (seg.fpl) (void)hipFree(seg.fpl);
+        seg.fpl = nullptr; seg.fxy = nullptr;
+        return SR_OK;
+    }
+    SR_TRY(launch_filter_plane(seg.rows, seg.n, idx->dim, seg.fsd, sr_filter_sigma(idx->dim), seg.fpl, seg.fxy,
+                               reinterpret_cast<int*>(idx->f_scratch) + 1, nullptr));
+    SR_CHECK_HIP(hipMemcpy(h, idx->f_scratch, 8, hipMemcpyDeviceToHost));
+    if (h[1] != 0) return SR_OK;
+    seg.f_state = 1;
+    return SR_OK;
+}
 
 static int split_segment(sr_dense_index* idx, DenseSegment& seg, int want) {
     if (seg.n_planes >= want) return SR_OK;
@@ -468,11 +506,8 @@ extern "C" int sr_dense_index_add(sr_dense_index* idx, const float* d_rows, int6
     std::lock_guard<std::mutex> lock(idx->mu);
     DenseSegment seg;
     seg.rows = d_rows; seg.n = n_rows; seg.id_base = id_base; seg.id_stride = id_stride;
-    if (planes_of(idx->precision)) {
-        const int rc = split_segment(idx, seg, planes_of(idx->precision));
-        // the filtered mode is an accelerator of the exact search: without room for the planes it simply is not used
-        if (rc != SR_OK && !(rc == SR_ERR_NOMEM && idx->precision == SR_PRECISION_FP32_FILTERED)) return rc;
-    }
+    if (planes_of(idx->precision)) SR_TRY(split_segment(idx, seg, planes_of(idx->precision)));
+    if (idx->precision == SR_PRECISION_FP32_FILTERED) SR_TRY(filter_prepare_segment(idx, seg));
     idx->segs.push_back(seg);
     idx->ntotal += n_rows;
     return SR_OK;
@@ -490,14 +525,22 @@ extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
     idx->order.release();
-    for (DenseSegment& seg : idx->segs)
+    for (DenseSegment& seg : idx->segs) {
         for (int p = 0; p < 3; ++p)
             if (seg.pl[p]) (void)hipFree(seg.pl[p]);
+        if (seg.fpl) (void)hipFree(seg.fpl);
+        if (seg.fxy) (void)hipFree(seg.fxy);
+    }
     for (int p = 0; p < 3; ++p)
         if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
     idx->ws2.release();
-    if (idx->d_max2) (void)hipFree(idx->d_max2);
-    if (idx->qnorm) (void)hipFree(idx->qnorm);
+    idx->ws3.release();
+    if (idx->qa) (void)hipFree(idx->qa);
+    if (idx->f_scratch) (void)hipFree(idx->f_scratch);
+    if (idx->redo_q) (void)hipFree(idx->redo_q);
+    if (idx->redo_idx) (void)hipFree(idx->redo_idx);
+    if (idx->redo_scores) (void)hipFree(idx->redo_scores);
+    if (idx->redo_ids) (void)hipFree(idx->redo_ids);
     if (idx->a_scores) (void)hipFree(idx->a_scores);
     if (idx->a_ids) (void)hipFree(idx->a_ids);
     if (idx->flags) (void)hipFree(idx->flags);
@@ -513,18 +556,18 @@ extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
     std::lock_guard<std::mutex> lock(idx->mu);
     if (planes_of(mode)) {
         SR_REQUIRE(idx->dim % 64 == 0, "split precisions need dim %% 64 == 0 (dim = %d)", idx->dim);
-        for (DenseSegment& seg : idx->segs) {
-            const int rc = split_segment(idx, seg, planes_of(mode));
-            if (rc != SR_OK && !(rc == SR_ERR_NOMEM && mode == SR_PRECISION_FP32_FILTERED)) return rc;
-        }
+        for (DenseSegment& seg : idx->segs) SR_TRY(split_segment(idx, seg, planes_of(mode)));
     }
+    if (mode == SR_PRECISION_FP32_FILTERED)
+        for (DenseSegment& seg : idx->segs) SR_TRY(filter_prepare_segment(idx, seg));
     idx->precision = mode;
     return SR_OK;
 }
 
 // one pass in the given arithmetic (SR_PRECISION_FP32 | _BF16X3 | _BF16X6); caller holds idx->mu
 static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
-                             int64_t* d_out_ids, int precision, hipStream_t s) {
+                             int64_t* d_out_ids, int precision, hipStream_t s, bool force_tiled = false) {
+    TopkWS& ws = force_tiled ? idx->ws3 : idx->ws;      // the re-do of a few queries keeps its own (differently shaped) workspace
 
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
@@ -549,9 +592,9 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if ((planes_of(precision) || precision == SR_PASS_FILTER || precision == SR_PASS_FILTER1) && nq > 64) {
-        // scores on the bf16 MFMA pipe (dense_split.hip); same chunking and top-k machinery
-        const int np = precision == SR_PASS_FILTER ? 1 : precision == SR_PASS_FILTER1 ? 0 : planes_of(precision);
+    if ((planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64) {
+        // scores on the 16-bit MFMA pipe (dense_split.hip); same chunking and top-k machinery
+        const int np = precision == SR_PASS_FILTER ? 0 : planes_of(precision);
         if (idx->q_cap < nq) {
             for (int p = 0; p < 3; ++p) {
                 if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
@@ -561,9 +604,10 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
             for (int p = 0; p < 3; ++p) SR_CHECK_HIP(hipMalloc((void**)&idx->qpl[p], (size_t)nq * idx->dim * 2));
             idx->q_cap = nq;
         }
-        SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
-        SR_TRY(idx->ws.ensure(nq, k, chunk));
-        SR_TRY(topk_reset(idx->ws, nq, s));
+        if (np == 0) SR_TRY(launch_filter_queries(d_queries, nq, idx->dim, idx->qpl[0], idx->qa, s));     // idx->qa: dense_search_filtered
+        else SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
+        SR_TRY(ws.ensure(nq, k, chunk));
+        SR_TRY(topk_reset(ws, nq, s));
         int64_t step = ceil_div64((int64_t)k + 1024, TM) * TM;   // short first launches, see below
         if (step < TM * ceil_div64(256, qtiles)) step = TM * ceil_div64(256, qtiles);
         if (step > chunk) step = chunk;
@@ -572,15 +616,14 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                 const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
                 const int64_t r0_next = r1;
                 step = step * 2 < chunk ? step * 2 : chunk;
-                DenseSplitArgs a;
+                DenseSplitArgs a{};
                 for (int p = 0; p < 3; ++p) { a.D[p] = seg.pl[p]; a.Q[p] = idx->qpl[p]; }
-                if (np == 0) {            // the certified filter, cheapest form: one doc plane against one query plane
+                if (np == 0) {            // the certified filter: one fp16 plane product + the per-pair error term
                     a.n_pairs = 1;
                     a.pair_d[0] = 0; a.pair_q[0] = 0;
-                } else if (np == 1) {     // the certified filter: one doc plane against two query planes
-                    a.n_pairs = 2;
-                    a.pair_d[0] = 0; a.pair_q[0] = 1;
-                    a.pair_d[1] = 0; a.pair_q[1] = 0;
+                    a.D[0] = seg.fpl;
+                    a.upper_bound = 1;
+                    a.dxy = seg.fxy; a.qa = idx->qa; a.sd = seg.fsd; a.isd = seg.fisd;
                 } else if (np == 2) {     // (d plane, q plane), smallest products first
                     a.n_pairs = 3;
                     const int pd[3] = {1, 0, 0}, pq[3] = {0, 1, 0};
@@ -591,48 +634,48 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                     for (int i = 0; i < 6; ++i) { a.pair_d[i] = pd[i]; a.pair_q[i] = pq[i]; }
                 }
                 a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
-                a.tau = idx->ws.tau; a.cand_keys = idx->ws.cand_keys; a.cand_count = idx->ws.cand_count;
-                a.cand_cap = idx->ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
+                a.tau = ws.tau; a.cand_keys = ws.cand_keys; a.cand_count = ws.cand_count;
+                a.cand_cap = ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
                 idx->prof.begin(s);
                 SR_TRY(launch_dense_split(a, s));
                 idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
-                SR_TRY(topk_compact(idx->ws, nq, k, s));
+                SR_TRY(topk_compact(ws, nq, k, s));
                 r0 = r0_next;
             }
         }
-        SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+        SR_TRY(topk_finalize(ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
         return SR_OK;
     }
-    const bool use_stream = variant != 9 && dense_stream_supports((int)nq, idx->dim);
+    const bool use_stream = variant != 9 && !force_tiled && dense_stream_supports((int)nq, idx->dim);
     if (use_stream) {
         // HBM-bound regime: D straight to registers, chunks grow geometrically (64 Ki docs, x2 per launch)
         int64_t cap = idx->ws_limit / (8 * nq);
         if (cap > (1ll << 22)) cap = 1ll << 22;
         cap = (cap / 128) * 128;
         if (cap < 128) cap = 128;
-        SR_TRY(idx->ws.ensure(nq, k, cap));
-        SR_TRY(topk_reset(idx->ws, nq, s));
+        SR_TRY(ws.ensure(nq, k, cap));
+        SR_TRY(topk_reset(ws, nq, s));
         int64_t step = 65536 < cap ? 65536 : cap;
         for (const DenseSegment& seg : idx->segs) {
             for (int64_t r0 = 0; r0 < seg.n;) {
                 const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
                 DenseStreamArgs a;
                 a.D = seg.rows; a.Q = d_queries; a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
-                a.tau = idx->ws.tau; a.cand_keys = idx->ws.cand_keys; a.cand_count = idx->ws.cand_count;
-                a.cand_cap = idx->ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
+                a.tau = ws.tau; a.cand_keys = ws.cand_keys; a.cand_count = ws.cand_count;
+                a.cand_cap = ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
                 idx->prof.begin(s);
                 SR_TRY(launch_dense_stream(a, s));
                 idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
-                SR_TRY(topk_compact(idx->ws, nq, k, s));
+                SR_TRY(topk_compact(ws, nq, k, s));
                 r0 = r1;
                 step = step * 2 < cap ? step * 2 : cap;
             }
         }
-        SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+        SR_TRY(topk_finalize(ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
         return SR_OK;
     }
-    SR_TRY(idx->ws.ensure(nq, k, chunk));
-    SR_TRY(topk_reset(idx->ws, nq, s));
+    SR_TRY(ws.ensure(nq, k, chunk));
+    SR_TRY(topk_reset(ws, nq, s));
 
     // The first launches see no threshold yet (every doc is a candidate until k have been seen), so they are kept short
     // and doubled - 2048, 4096, ... docs - until the regular chunk: each then appends about k survivors per query
@@ -653,10 +696,10 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
             a.row_end = r1;
             a.H = idx->dim;
             a.nq = (int)nq;
-            a.tau = idx->ws.tau;
-            a.cand_keys = idx->ws.cand_keys;
-            a.cand_count = idx->ws.cand_count;
-            a.cand_cap = idx->ws.cand_cap;
+            a.tau = ws.tau;
+            a.cand_keys = ws.cand_keys;
+            a.cand_count = ws.cand_count;
+            a.cand_cap = ws.cand_cap;
             a.id_base = (uint32_t)seg.id_base;
             a.id_stride = (uint32_t)seg.id_stride;
             idx->prof.begin(s);
@@ -677,39 +720,33 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                 default: SR_TRY((launch_dense<4, 1, 2, 1>(a, r1 - r0, s))); break;
             }
             idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
-            SR_TRY(topk_compact(idx->ws, nq, k, s));
+            SR_TRY(topk_compact(ws, nq, k, s));
             r0 = r0_next;
         }
     }
-    SR_TRY(topk_finalize(idx->ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    SR_TRY(topk_finalize(ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
     return SR_OK;
 }
 
-// SR_PRECISION_FP32_FILTERED: exact results at split-bf16 speed (dense_filter.hip).  Returns SR_OK with *done = false when the
-// batch has to go through the exact kernel instead (not applicable, or not certified).
+// SR_PRECISION_FP32_FILTERED: exact results at 16-bit MFMA speed (dense_filter.hip).  Returns SR_OK with *done = false when
+// the batch has to go through the exact kernel as a whole (filter not applicable to this index / batch).
 static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
                                  int64_t* d_out_ids, hipStream_t s, bool* done) {
     *done = false;
     int kp = 3 * k > k + 2048 ? 3 * k : k + 2048;            // candidates per query: k = 1000 -> 3072
+    if (const char* e = sr_dev_getenv("SR_FILTER_KP")) kp = atoi(e);
     if (kp > SR_MAX_TOPK) kp = SR_MAX_TOPK;
-    if (nq <= 64 || kp < k + 64 || idx->dim % 64 != 0 || (int)idx->segs.size() > SR_FILTER_MAX_SEGS) return SR_OK;
-    for (const DenseSegment& seg : idx->segs)
-        if (seg.n_planes < 1) return SR_OK;                   // the plane could not be allocated: exact kernel
-    if (!idx->d_max2) {
-        SR_CHECK_HIP(hipMalloc((void**)&idx->d_max2, 4));
-        SR_CHECK_HIP(hipMemsetAsync(idx->d_max2, 0, 4, s));
+    if (nq <= 64 || kp < k + 64 || idx->dim % 64 != 0 || idx->dim < 128 || (int)idx->segs.size() > SR_FILTER_MAX_SEGS) return SR_OK;
+    for (DenseSegment& seg : idx->segs) {
+        if (seg.f_state == 0) SR_TRY(filter_prepare_segment(idx, seg));
+        if (seg.f_state != 1) return SR_OK;                   // not filterable / no room for the plane: exact kernel
     }
-    for (DenseSegment& seg : idx->segs)
-        if (!seg.in_dmax) {
-            SR_TRY(launch_row_norm2_max(seg.rows, seg.n, idx->dim, idx->d_max2, s));
-            seg.in_dmax = true;
-        }
     if (idx->fq_cap < nq || idx->fkp != kp) {
         auto F = [](void* p) { if (p) (void)hipFree(p); };
-        F(idx->qnorm); F(idx->a_scores); F(idx->a_ids); F(idx->flags);
-        idx->qnorm = nullptr; idx->a_scores = nullptr; idx->a_ids = nullptr; idx->flags = nullptr;
+        F(idx->qa); F(idx->a_scores); F(idx->a_ids); F(idx->flags);
+        idx->qa = nullptr; idx->a_scores = nullptr; idx->a_ids = nullptr; idx->flags = nullptr;
         idx->fq_cap = 0;
-        if (hipMalloc((void**)&idx->qnorm, (size_t)nq * 4) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
+        if (hipMalloc((void**)&idx->qa, (size_t)nq * 16) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
             hipMalloc((void**)&idx->a_ids, (size_t)nq * kp * 8) != hipSuccess || hipMalloc((void**)&idx->flags, (size_t)(2 * nq + 2) * 4) != hipSuccess) {
             (void)hipGetLastError();
             return SR_OK;                                     // no room for the candidate lists: exact kernel
@@ -717,45 +754,61 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         idx->fq_cap = nq;
         idx->fkp = kp;
     }
-    SR_TRY(launch_query_norms(d_queries, nq, idx->dim, idx->qnorm, s));
     FilterSegs fs;
     fs.count = (int)idx->segs.size();
     for (int i = 0; i < fs.count; ++i) {
         fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
+        fs.xy[i] = idx->segs[i].fxy; fs.isd[i] = idx->segs[i].fisd;
         fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
     }
-    // The approximate pass starts with ONE plane product, q0 . d0 (error bound 2^-8 |q| |d|); an index whose score gaps are
-    // too tight for that bound is switched - for good - to two products, (q0 + q1) . d0 (2^-9), and a batch that cannot be
-    // certified with those goes through the exact kernel.
-    if (const char* e = sr_dev_getenv("SR_FILTER_PRODUCTS")) idx->filter_products = atoi(e) >= 2 ? 2 : 1;
+    SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
+    // 1. the kp documents with the largest upper bounds U (the query planes and constants are made by the pass)
+    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s));
+    // 2. exact scores of the candidates that can still be in the top-k -> exact top-k
+    SR_TRY(idx->ws2.ensure(nq, k, kp));
+    SR_TRY(topk_reset(idx->ws2, nq, s));
+    SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qa, nq, k, kp, idx->dim, idx->ws2.cand_keys,
+                                 idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, s));
+    SR_TRY(topk_compact(idx->ws2, nq, k, s));
+    SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
+    // 3. certificate against the k-th exact score
+    SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qa, nq, k, kp, idx->flags, s));
+    // the queries that were not certified are re-done by the exact kernel - those alone (one small D2H per search)
     std::vector<int> h((size_t)nq);
-    for (;;) {
-        // (the split kernel's pipelined k loop needs two 64-wide k-tiles: a 64-dim index starts with two products)
-        const int products = idx->dim < 128 ? 2 : idx->filter_products;
-        const double c = sr_filter_c(idx->dim, products);
-        SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
-        // 1. the kp best documents by the approximate score
-        SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, products == 1 ? SR_PASS_FILTER1 : SR_PASS_FILTER, s));
-        // 2. exact scores of the candidates -> exact top-k
-        SR_TRY(idx->ws2.ensure(nq, k, kp));
-        SR_TRY(topk_reset(idx->ws2, nq, s));
-        SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qnorm, idx->d_max2, nq, k, kp, idx->dim, c,
-                                     idx->ws2.cand_keys, idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags,
-                                     reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, s));
-        SR_TRY(topk_compact(idx->ws2, nq, k, s));
-        SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
-        // 3. certificate against the k-th exact score
-        SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qnorm, idx->d_max2, nq, k, kp, c, idx->flags, s));
-        // any query not certified -> the whole batch is redone (one small D2H per search)
-        SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        SR_CHECK_HIP(hipStreamSynchronize(s));
-        bool ok = true;
-        for (int64_t q = 0; q < nq && ok; ++q) ok = h[(size_t)q] == 0;
-        if (ok) break;
-        if (products == 1) { idx->filter_products = 2; ++idx->n_downgrade; continue; }      // never taken at dim < 128
-        return SR_OK;
-    }
+    SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<int64_t> redo;
+    for (int64_t q = 0; q < nq; ++q)
+        if (h[(size_t)q] != 0) redo.push_back(q);
+    const int64_t nf = (int64_t)redo.size();
+    idx->nq_certified += nq - nf;
+    idx->nq_redone += nf;
     *done = true;
+    if (nf == 0) { ++idx->n_filtered; return SR_OK; }
+    ++idx->n_fallback;
+    if (nf * 2 > nq) {                                         // most of the batch: redo all of it in place
+        return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, SR_PRECISION_FP32, s);
+    }
+    if (idx->redo_cap < nf || idx->redo_k != k) {
+        auto F = [](void* p) { if (p) (void)hipFree(p); };
+        F(idx->redo_q); F(idx->redo_idx); F(idx->redo_scores); F(idx->redo_ids);
+        idx->redo_q = nullptr; idx->redo_idx = nullptr; idx->redo_scores = nullptr; idx->redo_ids = nullptr;
+        idx->redo_cap = 0;
+        const int64_t cap = nf < 64 ? 64 : nf;
+        SR_CHECK_HIP(hipMalloc((void**)&idx->redo_q, (size_t)cap * idx->dim * 4));
+        SR_CHECK_HIP(hipMalloc((void**)&idx->redo_idx, (size_t)cap * 8));
+        SR_CHECK_HIP(hipMalloc((void**)&idx->redo_scores, (size_t)cap * k * 4));
+        SR_CHECK_HIP(hipMalloc((void**)&idx->redo_ids, (size_t)cap * k * 8));
+        idx->redo_cap = cap;
+        idx->redo_k = k;
+    }
+    SR_CHECK_HIP(hipMemcpyAsync(idx->redo_idx, redo.data(), (size_t)nf * 8, hipMemcpyHostToDevice, s));
+    SR_TRY(launch_filter_gather_rows(d_queries, idx->redo_idx, nf, idx->dim, idx->redo_q, false, s));
+    // the tiled kernels whatever the count: one k order for the whole batch (the streaming kernel accumulates in another)
+    SR_TRY(dense_search_pass(idx, idx->redo_q, nf, k, idx->redo_scores, idx->redo_ids, SR_PRECISION_FP32, s, true));
+    SR_TRY(launch_filter_gather_rows(idx->redo_scores, idx->redo_idx, nf, k, d_out_scores, true, s));
+    SR_TRY(launch_filter_gather_rows(idx->redo_ids, idx->redo_idx, nf, 2 * (int64_t)k, d_out_ids, true, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));                    // `redo` (pageable host memory) is the source of an async copy
     return SR_OK;
 }
 
@@ -773,19 +826,11 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
     if (idx->precision == SR_PRECISION_FP32_FILTERED) {
         bool done = false;
         SR_TRY(dense_search_filtered(idx, d_queries, nq, k, d_out_scores, d_out_ids, s, &done));
-        if (done) { ++idx->n_filtered; return SR_OK; }
-        if (nq > 64) ++idx->n_fallback;
+        if (done) return SR_OK;
+        if (nq > 64) { ++idx->n_fallback; idx->nq_redone += nq; }
         return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, SR_PRECISION_FP32, s);
     }
     return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, idx->precision, s);
-}
-
-extern "C" int sr_dense_index_filter_products(sr_dense_index* idx, int* products, int64_t* n_raised) {
-    SR_REQUIRE(idx && products && n_raised, "sr_dense_index_filter_products: null argument");
-    std::lock_guard<std::mutex> lock(idx->mu);
-    *products = idx->filter_products;
-    *n_raised = idx->n_downgrade;
-    return SR_OK;
 }
 
 extern "C" int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback) {
@@ -793,6 +838,14 @@ extern "C" int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filte
     std::lock_guard<std::mutex> lock(idx->mu);
     *n_filtered = idx->n_filtered;
     *n_fallback = idx->n_fallback;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_index_filter_query_stats(sr_dense_index* idx, int64_t* n_certified, int64_t* n_redone) {
+    SR_REQUIRE(idx && n_certified && n_redone, "sr_dense_index_filter_query_stats: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *n_certified = idx->nq_certified;
+    *n_redone = idx->nq_redone;
     return SR_OK;
 }
 

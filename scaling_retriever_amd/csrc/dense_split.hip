@@ -54,18 +54,55 @@ int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, 
 
 #define SP_BN 256   // docs per workgroup
 #define SP_BM 256   // queries per workgroup
+typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 split_mma(const mfma_bf16x8& w, const mfma_bf16x8& a, const f32x4& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, w), __builtin_bit_cast(mfma_f16x8, a), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+}
+
 // ---- epilogue: lane = query (frow + 16 j), registers = docs (16 i + 4 fg + r): tau filter, survivors as 64-bit keys ----
-template <int NB, int MB>
-__device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, const f32x4 (&acc)[NB][MB], int64_t row0, int q0, int wn, int wm,
-                                               int frow, int fg) {
+// UB (the certified filter's pass): the accumulators are turned into upper bounds of the exact score first, in the scaled
+// domain, U' = acc + A'[q] x[j] + B'[q] y[j] ((x, y) of the tile's 256 documents staged in LDS by the tile prologue), and
+// compared with tau[q] * sq * sd (a power of two: exact); a survivor's key carries U = U' / (sq sd).
+template <bool UB, int NB, int MB>
+__device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&acc)[NB][MB], int64_t row0, int q0, int wn, int wm,
+                                               int frow, int fg, const float* xy_s, const float* qa_s) {
+#pragma clang fp contract(off)
+    // the workgroup is persistent: without this hipcc hoists the 32 per-register row indices, id offsets and slots of this
+    // epilogue out of the tile loop and carries (spills) them through the k-loop
+    asm volatile("" : "+v"(fg), "+v"(frow));
     const int64_t left = a.row_end - row0;
     const int rows_valid = left < SP_BN ? (int)left : SP_BN;
     const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+    f32x4 qa[MB];
+    if constexpr (UB) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) qa[j] = *reinterpret_cast<const f32x4*>(qa_s + (wm * MB * 16 + j * 16 + frow) * 4);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float* p = xy_s + 2 * (wn * NB * 16 + i * 16 + fg * 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+            const float x[4] = {v0[0], v0[2], v1[0], v1[2]}, y[4] = {v0[1], v0[3], v1[1], v1[3]};
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = __builtin_fmaf(qa[j][0], x[r], __builtin_fmaf(qa[j][1], y[r], acc[i][j][r]));
+        }
+    }
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int q = q0 + wm * MB * 16 + j * 16 + frow;
         if (q >= a.nq) continue;
-        const float tq = a.tau[q];
+        float tq = a.tau[q];
+        float out_scale = 1.f;
+        if constexpr (UB) {
+            tq = tq * (qa[j][2] * a.sd);           // scaled-domain threshold (-inf stays -inf)
+            out_scale = qa[j][3] * a.isd;
+        }
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -84,18 +121,19 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, const f3
                 const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
                 const float sc = acc[i][j][r];
                 if (lr < rows_valid && sc >= tq) {
-                    if (pos < a.cand_cap) dst[pos] = sr_make_key(sc, gid0 + (uint32_t)lr * a.id_stride);
+                    if (pos < a.cand_cap) dst[pos] = sr_make_key(UB ? sc * out_scale : sc, gid0 + (uint32_t)lr * a.id_stride);
                     ++pos;
                 }
             }
     }
 }
 
-// Workgroup -> (doc tile, query tile).  1-D grid; workgroups are dealt to the 8 XCDs round-robin by their linear id, every XCD
-// has its own 4 MB L2, and 256 workgroups are resident at a time (one per CU), 32 per XCD.  xcd_order: the 32 workgroups an XCD
-// runs together form a block of 8 doc tiles x 4 query tiles (12 operand tiles behind 32 output tiles - in query-tile-fastest
+// Tile slot -> (doc tile, query tile).  Workgroups are dealt to the 8 XCDs round-robin by their linear id, every XCD has its
+// own 4 MB L2, and 256 workgroups are resident at a time (one per CU), 32 per XCD.  xcd_order: the 32 tiles an XCD works on
+// together form a block of 8 doc tiles x 4 query tiles (12 operand tiles behind 32 output tiles - in query-tile-fastest
 // linear order they touch ~9 doc tiles and most of the query tiles), blocks walked query-block fastest so that a doc tile is
-// fetched from HBM once and the query planes stay in the Infinity Cache.  Without it: query tile fastest.
+// fetched from HBM once and the query planes stay in the Infinity Cache.  Without it: query tile fastest.  Workgroups are
+// persistent: workgroup b takes slots b, b + G, b + 2G, ... (G a multiple of 8, so all its slots belong to its XCD).
 struct SplitGrid { int qt, dt, bq, bd, nbq, total; };
 static inline SplitGrid split_grid(int64_t rows, int nq, int xcd_order) {
     SplitGrid g;
@@ -107,8 +145,7 @@ static inline SplitGrid split_grid(int64_t rows, int nq, int xcd_order) {
     g.total = !xcd_order ? g.qt * g.dt : (int)(ceil_div64((int64_t)g.nbq * ceil_div64(g.dt, g.bd) * 32, 256) * 256);
     return g;
 }
-__device__ __forceinline__ bool split_tile_of(const DenseSplitArgs& a, int& d_tile, int& q_tile) {
-    const int lin = (int)blockIdx.x;
+__device__ __forceinline__ bool split_tile_of(const DenseSplitArgs& a, int lin, int& d_tile, int& q_tile) {
     if (!a.xcd_order) {
         q_tile = lin % a.grid_qt;
         d_tile = lin / a.grid_qt;
@@ -124,46 +161,66 @@ __device__ __forceinline__ bool split_tile_of(const DenseSplitArgs& a, int& d_ti
 }
 
 // ---- scoring kernel ----------------------------------------------------------------------------------
+// Persistent workgroups: the LDS-DMA of the NEXT tile's first two k-steps is issued during the last two k-steps of the
+// current one (the stages they free), so a tile's prologue latency and most of its epilogue hide behind the neighbour
+// tile's transfers; at K = 2048 a tile lives only 32 k-steps, and an exposed prologue + epilogue per tile was ~10 % of it.
+template <bool UB>
 __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     constexpr int NB = 8, MB = 4, WAVES_M = 4, HB = NB / 2;   // wave tile: 128 docs x 64 queries
     constexpr int W_BYTES = SP_BN * 128, STAGE_BYTES = (SP_BN + SP_BM) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xy_s = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);       // UB: (x, y) of the tile's 256 documents
+    float* qa_s = xy_s + 2 * SP_BN;                                        // UB: (A', B', sq, 1 / sq) of the tile's 256 queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-    int d_tile, q_tile;
-    if (!split_tile_of(a, d_tile, q_tile)) return;
-    const int64_t row0 = a.row_begin + (int64_t)d_tile * SP_BN;
-    const int q0 = q_tile * SP_BM;
+    const int G = (int)gridDim.x;
     const int H = a.H;
 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ (srow & 7);
-    int64_t doff[4], qoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t rn = row0 + (wave * 4 + i) * 8 + srow;
-        rn = rn < a.row_end ? rn : a.row_end - 1;
-        doff[i] = rn * H + schunk * 8;
-        int rq = q0 + (wave * 4 + i) * 8 + srow;
-        rq = rq < a.nq ? rq : a.nq - 1;
-        qoff[i] = (int64_t)rq * H + schunk * 8;
-    }
-    const int nk = H / 64;
+    int doff[4], qoff[4];          // element offsets inside the tile's row block (the block's base is wave-uniform)
+    int64_t st_dbase = 0, st_qbase = 0;
     // k-tiles are staged strictly in order (0, 1, 2, ...), so the plane pair of the NEXT tile is tracked incrementally:
     // the plane pointers change once per H / 64 tiles.  (Looking them up per tile - a division, then two dependent
     // scalar loads from the kernel arguments - sat right behind the k-step barrier, in front of the LDS-DMA issue.)
     int st_pair = 0, st_k0 = 0;
     const unsigned short* st_d = a.D[a.pair_d[0]];
     const unsigned short* st_q = a.Q[a.pair_q[0]];
-    auto stage = [&](int st, int /*kt: the next tile in order*/) {
+    int64_t st_row0 = 0;          // the tile `stage` is streaming
+    int st_q0 = 0;
+    auto next_slot = [&](int t) {
+        int d_t, q_t;
+        while (t < a.grid_total && !split_tile_of(a, t, d_t, q_t)) t += G;
+        return t;
+    };
+    auto set_tile = [&](int lin) {
+        int d_tile, q_tile;
+        (void)split_tile_of(a, lin, d_tile, q_tile);
+        st_row0 = a.row_begin + (int64_t)d_tile * SP_BN;
+        st_q0 = q_tile * SP_BM;
+        st_dbase = st_row0 * H;
+        st_qbase = (int64_t)st_q0 * H;
+        const int64_t dleft = a.row_end - 1 - st_row0;
+        const int dmax = dleft < SP_BN - 1 ? (int)dleft : SP_BN - 1, qmax = a.nq - 1 - st_q0 < SP_BM - 1 ? a.nq - 1 - st_q0 : SP_BM - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + srow;
+            doff[i] = (r < dmax ? r : dmax) * H + schunk * 8;
+            qoff[i] = (r < qmax ? r : qmax) * H + schunk * 8;
+        }
+        st_pair = 0; st_k0 = 0;
+        st_d = a.D[a.pair_d[0]];
+        st_q = a.Q[a.pair_q[0]];
+    };
+    auto stage = [&](int st) {          // the next k-tile in order
         unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 4) * 1024;
         unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 4) * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + doff[i] + st_k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + (st_dbase + st_k0) + doff[i]), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + qoff[i] + st_k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + (st_qbase + st_k0) + qoff[i]), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
         st_k0 += 64;
         if (st_k0 == H) {
             st_k0 = 0;
@@ -175,14 +232,9 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         }
     };
 
-    f32x4 acc[NB][MB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int frow = lane & 15, fg = lane >> 4;
-    const int nkt = a.n_pairs * nk;      // >= 2 (checked at launch)
+    const int nkt = a.n_pairs * (H / 64);      // >= 2 (checked at launch)
+    f32x4 acc[NB][MB];
     mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
     auto load_w = [&](int st, int kk, int h, mfma_bf16x8 (&wf)[HB]) {
         const unsigned char* wt = smem + st * STAGE_BYTES;
@@ -201,192 +253,109 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
 #define SR_MFMA_HALF(HH, WF, AF)                                                                              \
     _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                            \
         _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                        \
-            acc[(HH) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(HH) * HB + i][j], 0, 0, 0);
+            acc[(HH) * HB + i][j] = split_mma<UB>(WF[i], AF[j], acc[(HH) * HB + i][j]);
 
-    stage(0, 0);
-    stage(1, 1);
-    __syncthreads();
-    int buf = 0;
-    load_w(buf, 0, 0, wx);
-    load_a(buf, 0, a0);
-    int kt = 0;
-    // steady state with the issue order pinned (see gemm_bf16.hip): reads and LDS-DMA pieces dealt out one per MFMA
-#define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
-    for (; kt + 2 < nkt; ++kt) {
-        load_w(buf, 0, 1, wy);
-        load_a(buf, 1, a1);
-        SR_MFMA_HALF(0, wx, a0)
-#pragma unroll
-        for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 0); SR_SGB(0x100, 1, 0); }
-        SR_SGB(0x008, HB * MB - HB - MB, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(buf, 1, 0, wx);
-        SR_MFMA_HALF(1, wy, a0)
-#pragma unroll
-        for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 1); SR_SGB(0x100, 1, 1); }
-        SR_SGB(0x008, HB * MB - HB, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(buf, 1, 1, wy);
-        SR_MFMA_HALF(0, wx, a1)
-#pragma unroll
-        for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 2); SR_SGB(0x100, 1, 2); }
-        SR_SGB(0x008, HB * MB - HB, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        load_w(buf ^ 1, 0, 0, wx);
-        load_a(buf ^ 1, 0, a0);
-        stage(buf, kt + 2);
-        SR_MFMA_HALF(1, wy, a1)
-#pragma unroll
-        for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x100, 1, 3); }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x010, 1, 3); }
-        __builtin_amdgcn_sched_barrier(0);
-        buf ^= 1;
-    }
-#undef SR_SGB
-    for (; kt < nkt; ++kt) {     // last two k-steps: 4 phases per k-step, see gemm_bf16.hip
-        load_w(buf, 0, 1, wy);
-        SR_MFMA_HALF(0, wx, a0)
-        load_w(buf, 1, 0, wx);
-        load_a(buf, 1, a1);
-        SR_MFMA_HALF(1, wy, a0)
-        load_w(buf, 1, 1, wy);
-        SR_MFMA_HALF(0, wx, a1)
-        // The LDS-DMA of k-step kt + 1 was issued in the PREVIOUS iteration: hipcc does not see it as pending here and
-        // emits no vmcnt wait for this barrier, so drain it by hand (every wave its own pieces, then the barrier).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 2 < nkt) stage(buf, kt + 2);
-        if (kt + 1 < nkt) {
-            load_w(buf ^ 1, 0, 0, wx);
-            load_a(buf ^ 1, 0, a0);
-        }
-        SR_MFMA_HALF(1, wy, a1)
-        buf ^= 1;
-    }
-#undef SR_MFMA_HALF
-
-    split_epilogue<NB, MB>(a, acc, row0, q0, wn, wm, frow, fg);
-}
-
-// ---- the same kernel with BK = 32 and FOUR LDS stages ----------------------------------------------------------------
-// 2 x 64 KB stages leave the LDS-DMA of k-step kt + 2 one k-step (~2 000 MFMA cycles) to land; here a stage is 32 KB, the DMA
-// of k-step kt + 3 is issued three (half-length) steps ahead, and the wait before the barrier is a counted vmcnt(4): only
-// the stage that is needed next has to be complete.  Tile rows are 64 B (32 bf16) with the 16-byte chunks XOR-swizzled by
-// (row >> 1) & 3 on the source side of the DMA, which makes the ds_read_b128 fragment reads conflict-free per 8 lanes.
-// Twice the barriers per K.  Dev switch SR_SPLIT_K32 (A/B against dense_split_kernel; same products in the same order,
-// bit-identical scores).
-__global__ __launch_bounds__(512, 2) void dense_split_kernel_k32(DenseSplitArgs a) {
-    constexpr int NB = 8, MB = 4, WAVES_M = 4, HB = NB / 2;   // wave tile: 128 docs x 64 queries
-    constexpr int ROWB = 64;
-    constexpr int W_BYTES = SP_BN * ROWB, STAGE_BYTES = (SP_BN + SP_BM) * ROWB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-    int d_tile, q_tile;
-    if (!split_tile_of(a, d_tile, q_tile)) return;
-    const int64_t row0 = a.row_begin + (int64_t)d_tile * SP_BN;
-    const int q0 = q_tile * SP_BM;
-    const int H = a.H;
-    // one LDS-DMA instruction = 64 lanes x 16 B = 16 rows of 64 B; wave w stages rows [32 w, 32 w + 32) of both tiles
-    const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((srow >> 1) & 3);
-    int64_t doff[2], qoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int64_t rn = row0 + wave * 32 + i * 16 + srow;
-        rn = rn < a.row_end ? rn : a.row_end - 1;
-        doff[i] = rn * H + schunk * 8;
-        int rq = q0 + wave * 32 + i * 16 + srow;
-        rq = rq < a.nq ? rq : a.nq - 1;
-        qoff[i] = (int64_t)rq * H + schunk * 8;
-    }
-    int st_pair = 0, st_k0 = 0;
-    const unsigned short* st_d = a.D[a.pair_d[0]];
-    const unsigned short* st_q = a.Q[a.pair_q[0]];
-    auto stage = [&](int st) {     // the next k-step in order
-        unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 2) * 1024;
-        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 2) * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + doff[i] + st_k0), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + qoff[i] + st_k0), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
-        st_k0 += 32;
-        if (st_k0 == H) {
-            st_k0 = 0;
-            ++st_pair;
-            if (st_pair < a.n_pairs) {
-                st_d = a.D[a.pair_d[st_pair]];
-                st_q = a.Q[a.pair_q[st_pair]];
-            }
-        }
-    };
-    f32x4 acc[NB][MB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fg = lane >> 4;
-    const int pos = (fg ^ ((frow >> 1) & 3)) * 16;
-    const int nkt = a.n_pairs * (H / 32);     // even, >= 2
-    mfma_bf16x8 wx[HB], wy[HB], a0[MB], a1[MB];
-    auto load_w = [&](int st, int h, mfma_bf16x8 (&wf)[HB]) {
-        const unsigned char* wt = smem + st * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < HB; ++i)
-            wf[i] = *reinterpret_cast<const mfma_bf16x8*>(wt + (wn * NB * 16 + (h * HB + i) * 16 + frow) * ROWB + pos);
-    };
-    auto load_a = [&](int st, mfma_bf16x8 (&af)[MB]) {
-        const unsigned char* at = smem + st * STAGE_BYTES + W_BYTES;
-#pragma unroll
-        for (int j = 0; j < MB; ++j)
-            af[j] = *reinterpret_cast<const mfma_bf16x8*>(at + (wm * MB * 16 + j * 16 + frow) * ROWB + pos);
-    };
-#define SR_MFMA_HALF(HH, WF, AF)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < HB; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                        \
-            acc[(HH) * HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], AF[j], acc[(HH) * HB + i][j], 0, 0, 0);
-    // k-step kt: AC holds its query fragments, AN receives those of kt + 1.  WAIT: vmcnt count that leaves only younger
-    // stages outstanding.
-#define SR_K32_STEP(KT, AC, AN, WAIT)                                                                         \
-    {                                                                                                         \
-        const int kt_ = (KT);                                                                                 \
-        const int buf = kt_ & 3;                                                                              \
-        load_w(buf, 1, wy);                                                                                   \
-        SR_MFMA_HALF(0, wx, AC)                                                                               \
-        asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                              \
-        __syncthreads();                                                                                      \
-        if (kt_ + 1 < nkt) {                                                                                  \
-            load_w((kt_ + 1) & 3, 0, wx);                                                                     \
-            load_a((kt_ + 1) & 3, AN);                                                                        \
-        }                                                                                                     \
-        if (kt_ + 3 < nkt) stage((kt_ + 3) & 3);                                                              \
-        SR_MFMA_HALF(1, wy, AC)                                                                               \
-    }
+    int tile = next_slot((int)blockIdx.x);
+    if (tile >= a.grid_total) return;
+    set_tile(tile);
     stage(0);
     stage(1);
-    if (nkt > 2) stage(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    load_w(0, 0, wx);
-    load_a(0, a0);
-    int kt = 0;
-    // steady state: at the wait, stages kt + 1 and kt + 2 are outstanding (4 DMA instructions per wave each)
-    for (; kt + 4 < nkt; kt += 2) {
-        SR_K32_STEP(kt, a0, a1, 4)
-        SR_K32_STEP(kt + 1, a1, a0, 4)
+    int buf = 0;
+    for (;;) {
+        const int64_t row0 = st_row0;           // this tile (set_tile moves st_* on to the next one inside the k-loop)
+        const int q0 = st_q0;
+        const int tile_next = next_slot(tile + G);
+        const bool has_next = tile_next < a.grid_total;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k-steps 0 and 1 of this tile are on their way (issued above, or under the previous tile's last two k-steps);
+        // the barrier also ends the previous tile's epilogue reads of xy_s
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (UB) {
+            // the tile's per-document (x, y): 512 floats, 64 per wave, one 4-byte LDS-DMA piece per lane, and its per-query
+            // constants: 256 x 16 bytes, one 16-byte piece per lane of waves 0-3; they land under the k-loop (every k-step
+            // drains vmcnt before its barrier) and cost no register there
+            int64_t r = row0 + wave * 32 + (lane >> 1);
+            r = r < a.row_end ? r : a.row_end - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.dxy + r * 2 + (lane & 1)), (lds_void_ptr)(xy_s + wave * 64), 4, 0, 0);
+            if (wave < 4) {
+                int q = q0 + wave * 64 + lane;
+                q = q < a.nq ? q : a.nq - 1;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.qa + (int64_t)q * 4), (lds_void_ptr)(qa_s + wave * 256), 16, 0, 0);
+            }
+        }
+        load_w(buf, 0, 0, wx);
+        load_a(buf, 0, a0);
+        int kt = 0;
+        // steady state with the issue order pinned (see gemm_bf16.hip): reads and LDS-DMA pieces dealt out one per MFMA
+#define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
+        for (; kt + 2 < nkt; ++kt) {
+            load_w(buf, 0, 1, wy);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(0, wx, a0)
+#pragma unroll
+            for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 0); SR_SGB(0x100, 1, 0); }
+            SR_SGB(0x008, HB * MB - HB - MB, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 0, wx);
+            SR_MFMA_HALF(1, wy, a0)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 1); SR_SGB(0x100, 1, 1); }
+            SR_SGB(0x008, HB * MB - HB, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) { SR_SGB(0x008, 1, 2); SR_SGB(0x100, 1, 2); }
+            SR_SGB(0x008, HB * MB - HB, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            load_w(buf ^ 1, 0, 0, wx);
+            load_a(buf ^ 1, 0, a0);
+            stage(buf);
+            SR_MFMA_HALF(1, wy, a1)
+#pragma unroll
+            for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x100, 1, 3); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x010, 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+#undef SR_SGB
+        for (; kt < nkt; ++kt) {     // last two k-steps: 4 phases per k-step, see gemm_bf16.hip
+            load_w(buf, 0, 1, wy);
+            SR_MFMA_HALF(0, wx, a0)
+            load_w(buf, 1, 0, wx);
+            load_a(buf, 1, a1);
+            SR_MFMA_HALF(1, wy, a0)
+            load_w(buf, 1, 1, wy);
+            SR_MFMA_HALF(0, wx, a1)
+            // The LDS-DMA of k-step kt + 1 was issued in the PREVIOUS iteration: hipcc does not see it as pending here and
+            // emits no vmcnt wait for this barrier, so drain it by hand (every wave its own pieces, then the barrier).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < nkt) {
+                stage(buf);
+            } else if (has_next) {          // the freed stage takes the next tile's k-step kt + 2 - nkt
+                if (kt + 2 == nkt) set_tile(tile_next);
+                stage(buf);
+            }
+            if (kt + 1 < nkt) {
+                load_w(buf ^ 1, 0, 0, wx);
+                load_a(buf ^ 1, 0, a0);
+            }
+            SR_MFMA_HALF(1, wy, a1)
+            buf ^= 1;
+        }
+        split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s);
+        if (!has_next) break;
+        tile = tile_next;
     }
-    for (; kt < nkt; kt += 2) {           // nkt is even (H is a multiple of 64): the last 2 or 4 k-steps drain everything
-        SR_K32_STEP(kt, a0, a1, 0)
-        SR_K32_STEP(kt + 1, a1, a0, 0)
-    }
-#undef SR_K32_STEP
 #undef SR_MFMA_HALF
-    split_epilogue<NB, MB>(a, acc, row0, q0, wn, wm, frow, fg);
 }
 
 int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
@@ -394,11 +363,14 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     if (rows <= 0) return SR_OK;
     SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
     SR_REQUIRE(a.n_pairs >= 1 && a.n_pairs <= 6 && a.n_pairs * (a.H / 64) >= 2, "dense_split: bad plane-pair count %d", a.n_pairs);
-    constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128;
+    SR_REQUIRE(!a.upper_bound || (a.n_pairs == 1 && a.dxy && a.qa), "dense_split: the upper-bound pass is one plane product");
+    constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128 + SP_BN * 2 * sizeof(float) + SP_BM * 4 * sizeof(float);
     static DeviceOnce attr_once;
     bool* attr_slot = attr_once.pending();
     if (attr_slot) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         *attr_slot = true;
     }
@@ -406,20 +378,15 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     b.xcd_order = 1;
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
     const SplitGrid sg = split_grid(rows, a.nq, b.xcd_order);
-    b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq;
-    const dim3 grid((unsigned)sg.total);
-    static const bool k32 = [] { const char* e = sr_dev_getenv("SR_SPLIT_K32"); return e && atoi(e) != 0; }();
-    if (k32) {
-        static DeviceOnce attr32;
-        if (bool* slot = attr32.pending()) {
-            SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_split_kernel_k32),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            *slot = true;
-        }
-        hipLaunchKernelGGL(dense_split_kernel_k32, grid, dim3(512), lds, s, b);
-    } else {
-        hipLaunchKernelGGL(dense_split_kernel, grid, dim3(512), lds, s, b);
-    }
+    b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq; b.grid_total = sg.total;
+    // one persistent workgroup per CU (130 KB of LDS each); SR_SPLIT_PERSIST=0: one workgroup per tile slot (A/B)
+    int wgs = sr_cu_count();
+    wgs -= wgs % 8;
+    if (wgs < 8) wgs = 8;
+    if (const char* e = sr_dev_getenv("SR_SPLIT_PERSIST")) if (atoi(e) == 0) wgs = sg.total;
+    const dim3 grid((unsigned)(sg.total < wgs ? sg.total : wgs));
+    if (a.upper_bound) hipLaunchKernelGGL(dense_split_kernel<true>, grid, dim3(512), lds, s, b);
+    else hipLaunchKernelGGL(dense_split_kernel<false>, grid, dim3(512), lds, s, b);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

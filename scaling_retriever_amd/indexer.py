@@ -299,12 +299,14 @@ class SparseIndexer:
             indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=counts.device), torch.cumsum(counts, 0)])
             rows_t, vals_t = rows_t[order].contiguous(), vals_t[order].contiguous()
             n_docs = (count - 1) * self.world_size + self.local_rank + 1 if self.world_size > 1 else count   # nb_docs() = max g_row + 1
-            if self.index_dir is not None:       # the host copy is only needed to write the files
+            if self.index_dir is not None:       # the host copy is needed to write the files; the 12 B per posting in HBM are released
                 self.sparse_index.set_csr(indptr.cpu().numpy(), rows_t.cpu().numpy(), vals_t.cpu().numpy(), n_docs)
+                self.device_csr = None
             else:
-                self.sparse_index.n = int(n_docs)
-            # an immediately following SparseRetrieval(index_d=...) scores from these device arrays: no 13 GB round trip
-            self.device_csr = (indptr, rows_t, vals_t, int(n_docs))
+                # the container carries the postings like the reference's in-memory index_d (host copy made on first use);
+                # an immediately following SparseRetrieval(index_d=...) scores from the device arrays: no 13 GB round trip
+                self.sparse_index.set_device_csr(indptr, rows_t, vals_t, n_docs)
+                self.device_csr = (indptr, rows_t, vals_t, int(n_docs))
 
         if self.compute_stats:
             stats = {key: value / max(1, n_batches) for key, value in stats.items()}     # mean over batches, as the reference

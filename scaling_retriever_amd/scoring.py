@@ -70,6 +70,8 @@ class DenseIndexHIP:
         n_buffers = max(1, min(n_buffers, len(pieces)))
         with torch.cuda.device(self.device):
             side = torch.cuda.Stream()
+            # `dev` came from the caching allocator on the current stream: a recycled block may still have kernels queued there
+            side.wait_stream(torch.cuda.current_stream(self.device))
             bufs = [torch.empty((piece_rows, self.dim), dtype=torch.float32, pin_memory=True) for _ in range(n_buffers)]
             free = [torch.cuda.Event() for _ in range(n_buffers)]
             locks = [threading.Lock() for _ in range(n_buffers)]
@@ -112,6 +114,7 @@ class DenseIndexHIP:
         try:
             with torch.cuda.device(self.device):
                 side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream(self.device))      # see add_host_rows
                 bufs = [torch.empty((piece_rows, self.dim), dtype=torch.float32, pin_memory=True) for _ in range(n_buffers)]
                 free = [torch.cuda.Event() for _ in range(n_buffers)]
                 locks = [threading.Lock() for _ in range(n_buffers)]
@@ -146,23 +149,23 @@ class DenseIndexHIP:
         _lib.check(self.lib.sr_dense_index_set_workspace_limit(self._h, int(nbytes)))
 
     def set_precision(self, mode):
-        """"fp32" (default: the exact kernel), "fp32_filtered" (the same results bit for bit through a certified bf16 filter +
-        exact re-score, ~7x faster for batches > 64 queries, one bf16 plane of the corpus in HBM), "bf16x3" / "bf16x6"
+        """"fp32" (default: the exact kernel), "fp32_filtered" (the same results bit for bit through a certified fp16 filter +
+        exact re-score, ~7x faster for batches > 64 queries, one fp16 plane of the corpus in HBM), "bf16x3" / "bf16x6"
         (split-bf16 scores, not bit-identical)."""
         code = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp32_filtered": 3}[mode]
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sr_dense_index_set_precision(self._h, code), "sr_dense_index_set_precision")
 
     def filter_stats(self):
-        """(searches answered through the certified filter, searches redone by the exact kernel)."""
+        """(searches answered by the certified filter alone, searches where some or all queries were re-done by the exact kernel)."""
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(self.lib.sr_dense_index_filter_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
-    def filter_products(self):
-        """(plane products of the filter's approximate pass now: 1 or 2, times a failed certificate raised it)."""
-        a, b = ctypes.c_int(0), ctypes.c_int64(0)
-        _lib.check(self.lib.sr_dense_index_filter_products(self._h, ctypes.byref(a), ctypes.byref(b)))
+    def filter_query_stats(self):
+        """(queries certified by the filter, queries re-done by the exact kernel) so far."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.sr_dense_index_filter_query_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def search(self, queries, k):

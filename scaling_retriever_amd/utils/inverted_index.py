@@ -96,7 +96,21 @@ class IndexDictOfArray:
         if len(row):
             self._pending.append((row, col, data))
 
+    def set_device_csr(self, indptr, doc_ids, vals, n_docs):
+        """Adopt a CSR that still lives on the device (torch tensors; SparseIndexer.index without an index_dir): the host copy is
+        made by the first access that needs one (csr(), a per-term view, save(), merge) - an immediately following
+        SparseRetrieval scores from the device arrays and never triggers it."""
+        self._pending = []
+        self._device_csr = (indptr, doc_ids, vals)
+        self.n = int(n_docs)
+
     def _finalize(self):
+        dev = getattr(self, "_device_csr", None)
+        if dev is not None:
+            self._device_csr = None
+            self.indptr = np.ascontiguousarray(dev[0].cpu().numpy(), dtype=np.int64)
+            self.doc_ids = np.ascontiguousarray(dev[1].cpu().numpy(), dtype=np.int32)
+            self.vals = np.ascontiguousarray(dev[2].cpu().numpy(), dtype=np.float32)
         if not self._pending:
             return
         rows = np.concatenate([p[0] for p in self._pending])
@@ -118,6 +132,7 @@ class IndexDictOfArray:
     def set_csr(self, indptr, doc_ids, vals, n_docs):
         """Adopt a finished CSR (built on the device by SparseIndexer): postings inside a term in insertion order."""
         self._pending = []
+        self._device_csr = None
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int32)
         self.vals = np.ascontiguousarray(vals, dtype=np.float32)

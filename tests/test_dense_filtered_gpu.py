@@ -1,4 +1,4 @@
-"""SR_PRECISION_FP32_FILTERED: sr_dense_search through the certified bf16 filter + exact re-score must return EXACTLY what
+"""SR_PRECISION_FP32_FILTERED: sr_dense_search through the certified fp16 filter + exact re-score must return EXACTLY what
 the exact fp32 kernel returns - ids and fp32 scores, bit for bit (= the oracle's k-ordered fmaf chain, i.e. what
 faiss.IndexFlatIP.search is restated as, /root/reference/scaling_retriever/indexer.py:210-214) - on benign and on
 adversarial data, and must fall back to the exact kernel when the certificate cannot be given.  Also pins the error bound
@@ -82,64 +82,62 @@ def test_filtered_adversarial_data_still_exact():
     assert np.array_equal(fi[:16].cpu().numpy(), oi) and np.array_equal(fs[:16].cpu().numpy(), os_)
 
 
-def test_filtered_falls_back_when_it_cannot_certify():
+def test_filtered_redoes_what_it_cannot_certify():
     """More than kp - k documents tie with the k-th one (exact duplicates): no certificate -> the exact kernel answers, the
-    result is still the exact kernel's (ties by ascending doc index)."""
+    result is still the exact kernel's (ties by ascending doc index).  A query without a certificate is re-done ALONE."""
     rng = np.random.default_rng(3)
     H, k = 128, 50
     base = rng.standard_normal((8, H), dtype=np.float32)
-    D = np.repeat(base, 1500, axis=0)[rng.permutation(12000)]                      # 1 499 exact twins each: more than kp - k
+    D = np.repeat(base, 3000, axis=0)[rng.permutation(24000)]                      # 2 999 exact twins each: more than kp - k
     Q = rng.standard_normal((100, H), dtype=np.float32)
     (es, ei), (fs, fi), filt = _both([D], Q, k)
     assert torch.equal(fi, ei) and torch.equal(fs, es)
-    assert filt.filter_stats() == (0, 1)
-    # a zero query: every score is 0, nothing can be separated
+    assert filt.filter_stats() == (0, 1) and filt.filter_query_stats() == (0, 100)
+    # 1 499 twins each fit inside the candidates: the ties at the cut are all re-scored, the certificate holds
+    D2 = np.repeat(base, 1500, axis=0)[rng.permutation(12000)]
+    (es, ei), (fs, fi), filt = _both([D2], Q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_stats() == (1, 0)
+    # a zero query: every score is 0, nothing can be separated - that query alone goes to the exact kernel
     Q[5] = 0
     (es, ei), (fs, fi), filt = _both([rng.standard_normal((5000, H), dtype=np.float32)], Q, k)
-    assert torch.equal(fi, ei) and torch.equal(fs, es) and filt.filter_stats() == (0, 1)
-    # non-finite data: never certified
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    assert filt.filter_stats() == (0, 1) and filt.filter_query_stats() == (99, 1)
+    # a non-finite query: the same
+    Q[5] = rng.standard_normal(H)
+    Q[7, 3] = np.inf
+    Dg = rng.standard_normal((5000, H), dtype=np.float32)
+    (es, ei), (fs, fi), filt = _both([Dg], Q, k)
+    ok = np.ones(100, bool)
+    ok[7] = False                                      # (inf and NaN scores: the two kernels agree on ids only where scores order)
+    assert torch.equal(fi[ok], ei[ok]) and torch.equal(fs[ok], es[ok])
+    assert filt.filter_query_stats() == (99, 1)
+    # non-finite data: the index is never filtered
     Dn = rng.standard_normal((5000, H), dtype=np.float32)
     Dn[17, 3] = np.inf
     _, (fs, fi), filt = _both([Dn], rng.standard_normal((100, H), dtype=np.float32), k)
     assert filt.filter_stats() == (0, 1)
 
 
-def test_filter_raises_its_plane_products_when_one_is_not_enough():
-    """Score gaps between rank k and rank kp that the one-product bound (2^-8 |q||d|) cannot separate but the two-product
-    bound (2^-9) can: the first search fails its certificate once, switches the index to two products for good, and is
-    answered by the filter - identical to the exact kernel - without the exact kernel running."""
-    from scaling_retriever_amd.scoring import DenseIndexHIP
-    rng = np.random.default_rng(21)
-    H, N, nq, k = 256, 30000, 100, 100                       # kp = k + 2048
-    c = 2.0 ** -9 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
-    c1 = c + 2.0 ** -9 * 1.004
-    # every document = s_i * u + small noise, queries = u: scores = s_i |u|^2 (+ noise), descending in i with a relative step
-    # chosen so that the gap between rank k and rank kp is 1.5 c |q|: above E = c |q| (two products certify), below
-    # E1 = c1 |q| ~ 2 c |q| (one product does not)
-    u = rng.standard_normal(H).astype(np.float32)
-    u /= np.linalg.norm(u)
-    kp = k + 2048
-    assert c < 1.5 * c < c1
-    step = 1.5 * c / (kp - k)
-    s = (1.0 - step * np.arange(N)).astype(np.float32)
-    s[s < 0.2] = 0.2
-    D = (s[:, None] * u[None, :]).astype(np.float32)
-    Q = np.repeat(u[None, :], nq, axis=0).astype(np.float32) * rng.uniform(0.5, 2.0, size=(nq, 1)).astype(np.float32)
-    exact = DenseIndexHIP(H)
-    exact.add_host_rows(D)
-    filt = DenseIndexHIP(H)
-    filt.set_precision("fp32_filtered")
-    filt.add_host_rows(D)
-    q = torch.from_numpy(Q).cuda()
-    es, ei = exact.search(q, k)
-    assert filt.filter_products() == (1, 0)
-    fs, fi = filt.search(q, k)
+def test_filter_redoes_a_few_queries_in_the_tiled_k_order():
+    """A handful of uncertifiable queries (each aimed at a block of 3 000 exact twins) inside a batch of 300: they are re-done
+    by the exact kernel in a batch of their own - far fewer than 64 queries, where sr_dense_search would pick the streaming
+    kernel and ITS accumulation order - and must still match the exact kernel run on the whole batch bit for bit."""
+    rng = np.random.default_rng(17)
+    H, k, nq = 256, 100, 300
+    D = rng.standard_normal((40000, H), dtype=np.float32)
+    twins = rng.standard_normal((3, H), dtype=np.float32)
+    for t in range(3):
+        D[5000 + 3000 * t:8000 + 3000 * t] = twins[t]
+    Q = rng.standard_normal((nq, H), dtype=np.float32)
+    for t, q in enumerate((4, 150, 299)):
+        Q[q] = twins[t] * 3.0
+    (es, ei), (fs, fi), filt = _both([D[:20000], D[20000:]], Q, k)
     assert torch.equal(fi, ei) and torch.equal(fs, es)
-    assert filt.filter_products() == (2, 1), filt.filter_products()
-    assert filt.filter_stats() == (1, 0)
-    fs, fi = filt.search(q, k)                                # stays on two products
-    assert torch.equal(fi, ei) and torch.equal(fs, es)
-    assert filt.filter_products() == (2, 1) and filt.filter_stats() == (2, 0)
+    cert, redone = filt.filter_query_stats()          # the 3 aimed queries + the few random ones whose rank-k cut falls into a twin block
+    assert filt.filter_stats() == (0, 1) and cert + redone == nq and 3 <= redone <= 15, (cert, redone)
+    os_, oi = O.topk_rows(O.dense_scores_fma(Q[[4, 150, 299]], D, O.mfma_korder(H)), k)
+    assert np.array_equal(fi[[4, 150, 299]].cpu().numpy(), oi) and np.array_equal(fs[[4, 150, 299]].cpu().numpy(), os_)
 
 
 def test_filtered_small_index_and_small_batches():
@@ -160,34 +158,58 @@ def test_filtered_small_index_and_small_batches():
     assert torch.equal(fi, ei) and torch.equal(fs, es) and filt.filter_stats() == (0, 0)
 
 
-def test_filter_error_bound_dominates_the_filter_score():
-    """The certificate's E = c(H) |q| |d| must dominate |S_a - S_x| for S_a = (q0 + q1) . d0 (two bf16 planes of the query, one
-    of the document) and, with c1(H), for S_a = q0 . d0 (the one-product pass tried first).  S_a is restated in float64 from the planes (the MFMA's fp32 accumulation adds at most what the bound
-    reserves for it and is checked on the device for every re-scored pair), S_x comes from the exact kernel; Gaussian,
-    same-sign and adversarially aligned data (every rounding error pushed the same way)."""
+def _restated_upper_bound(Q, D):
+    """The filter's U(q, j) restated in float64 from its definition (csrc/dense_filter.hip): power-of-two scales, fp16 planes,
+    actual residual norms.  Returns (U, e), both [nq, N], in the true domain."""
+    H = Q.shape[1]
+    sigma = 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
+    d = torch.from_numpy(D).cuda()
+    q = torch.from_numpy(Q).cuda()
+    sd = 2.0 ** (15 - int(np.frexp(float(np.abs(D).max()))[1]))
+    sq = torch.exp2(15 - torch.frexp(q.abs().amax(dim=1)).exponent.double())[:, None]
+    dp, qp = d.double() * sd, q.double() * sq
+    d0, q0 = (d * sd).half().double(), (q * sq.float()).half().double()
+    X = ((dp - d0).norm(dim=1) + sigma * dp.norm(dim=1)) * 1.001
+    Y = d0.norm(dim=1) * 1.001
+    A = qp.norm(dim=1) * 1.001
+    B = (qp - q0).norm(dim=1) * 1.001
+    e = (A[:, None] * X[None, :] + B[:, None] * Y[None, :]) / (sq * sd)
+    return (q0 @ d0.T) / (sq * sd) + e, e
+
+
+def test_filter_upper_bound_dominates_the_exact_score():
+    """The certificate rests on U(q, j) >= S_x(q, j) >= U - 2 e for EVERY pair.  U is restated in float64 from the definition
+    (the MFMA's fp32 accumulation adds at most what sigma reserves for it and is checked on the device for every re-scored
+    pair: a violation re-does the query, which filter_query_stats would show), S_x comes from the exact kernel.  Gaussian,
+    same-sign, adversarially aligned data (every fp16 rounding error at its maximum, all pushed the same way) and rows whose
+    values span 1e6."""
     from scaling_retriever_amd.scoring import DenseIndexHIP
     rng = np.random.default_rng(11)
     for H in (256, 2048):
-        c = 2.0 ** -9 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
-        c1 = 2.0 ** -8 * 1.004 + 1.25 * (3.0 * H * 2.0 ** -24) + 1.0e-5
-        for kind in ("gauss", "same_sign", "aligned"):
+        for kind in ("gauss", "same_sign", "aligned", "wide"):
             D = rng.standard_normal((2000, H), dtype=np.float32)
             Q = rng.standard_normal((128, H), dtype=np.float32)
-            if kind != "gauss":
+            if kind in ("same_sign", "aligned"):
                 D, Q = np.abs(D), np.abs(Q)
-            if kind == "aligned":            # values just below a bf16 rounding boundary: d - d0 is -2^-9 |d| for every element
-                D = (np.float32(1.0) + np.float32(2.0 ** -8) * np.float32(0.499)) * np.exp2(rng.integers(-3, 3, size=D.shape)).astype(np.float32)
+            if kind == "aligned":            # values just below an fp16 rounding boundary: d - d0 = -2^-11 |d| for every element
+                D = (np.float32(1.0) + np.float32(2.0 ** -10) * np.float32(0.499)) * np.exp2(rng.integers(-3, 3, size=D.shape)).astype(np.float32)
+            if kind == "wide":
+                D *= np.exp(rng.uniform(-7, 7, size=(1, H))).astype(np.float32)
             a = DenseIndexHIP(H)
             a.add_host_rows(D)
             q = torch.from_numpy(Q).cuda()
             es, ei = a.search(q, 2000)
             ex = torch.zeros((128, 2000), device="cuda").scatter_(1, ei, es).double()
-            d0 = torch.from_numpy(D).cuda().bfloat16().double()
-            q0 = q.bfloat16()
-            q1 = (q - q0.float()).bfloat16()
-            sa = (q0.double() + q1.double()) @ d0.T
+            U, e = _restated_upper_bound(Q, D)
             bound = torch.from_numpy(np.linalg.norm(Q, axis=1)[:, None] * np.linalg.norm(D, axis=1)[None, :]).cuda()
-            worst = float(((ex - sa).abs() / bound).max())
-            worst1 = float(((ex - q0.double() @ d0.T).abs() / bound).max())
-            print(f"H {H} {kind}: max |S_a - S_x| / (|q||d|) = {worst:.2e} (bound c = {c:.2e}); one product {worst1:.2e} (c1 = {c1:.2e})")
-            assert worst < c and worst1 < c1
+            slack_hi = float(((U - ex) / bound).min())
+            slack_lo = float(((ex - (U - 2 * e)) / bound).min())
+            print(f"H {H} {kind}: e / (|q||d|) = {float((e / bound).mean()):.2e}; min (U - S_x) / |q||d| = {slack_hi:.2e}, "
+                  f"min (S_x - U + 2e) / |q||d| = {slack_lo:.2e}")
+            assert slack_hi >= 0 and slack_lo >= 0
+            f = DenseIndexHIP(H)
+            f.set_precision("fp32_filtered")
+            f.add_host_rows(D)
+            fs, fi = f.search(q, 50)
+            assert torch.equal(fs, es[:, :50]) and torch.equal(fi, ei[:, :50])
+            assert f.filter_query_stats() == (128, 0), (H, kind, f.filter_query_stats())      # no pair violated the bound on the device

@@ -188,3 +188,20 @@ def test_gather_topk_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "MERGE_OK" in out.stdout and "SPARSE_MERGE_OK" in out.stdout
+
+
+def test_in_memory_index_carries_its_postings():
+    """SparseIndexer.index(index_dir=None) hands the device CSR to the container; every consumer of
+    index_d["index"] (csr(), per-term views, save, the world_size > 1 retrieval path) must see the postings, as with the
+    reference's in-memory index_d (indexer.py:239-308)."""
+    import torch
+    from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+    idx = IndexDictOfArray(dim_voc=6)
+    indptr = torch.tensor([0, 2, 2, 5, 5, 5, 6])
+    ids = torch.tensor([0, 3, 1, 2, 3, 0], dtype=torch.int32)
+    vals = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    idx.set_device_csr(indptr, ids, vals, 4)
+    assert idx.nb_docs() == 4
+    assert len(idx) == 3 and idx.index_doc_id[2].tolist() == [1, 2, 3] and idx.index_doc_value[5].tolist() == [6.0]
+    ip, di, va = idx.csr(8)
+    assert ip.tolist() == [0, 2, 2, 5, 5, 5, 6, 6, 6] and di.tolist() == ids.tolist() and va.tolist() == vals.tolist()
