@@ -156,3 +156,37 @@ void oracle_topk_rows(const float* S, int64_t Nq, int64_t N, int k, float* out_s
         free(h);
     }
 }
+
+
+/* ---- dense: faiss IndexFlatIP.search restated as the library runs it (faiss-cpu 1.8.0, IndexFlat.cpp ->
+ * knn_inner_product -> exhaustive_inner_product_blas): sgemm over (query block, database block) pairs, then one heap per
+ * query fed from the block's score rows (HeapBlockResultHandler: a score enters when it beats the heap's worst).  The sgemm
+ * is the host BLAS (called from oracle/scoring.py); this is the heap side, one OpenMP thread per query row.
+ * heaps: [Nq, k] cand_t min-heaps on (score, then higher doc index = worse), heap_n: [Nq] fill counts. */
+void oracle_heap_block(const float* S, int64_t Nq, int64_t nb, int64_t ld, int64_t base, int k, void* heaps, int32_t* heap_n) {
+    cand_t* H = (cand_t*)heaps;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < Nq; ++q) {
+        cand_t* h = H + q * (int64_t)k;
+        int n = heap_n[q];
+        const float* row = S + q * ld;
+        for (int64_t j = 0; j < nb; ++j) {
+            if (n == k && !(row[j] > h[0].s || (row[j] == h[0].s && base + j < h[0].i))) continue;
+            cand_t c = { row[j], base + j };
+            n = topk_push(h, n, k, c);
+        }
+        heap_n[q] = n;
+    }
+}
+
+void oracle_heap_finish(void* heaps, const int32_t* heap_n, int64_t Nq, int k, float* out_score, int64_t* out_idx) {
+    cand_t* H = (cand_t*)heaps;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < Nq; ++q) {
+        cand_t* h = H + q * (int64_t)k;
+        const int n = heap_n[q];
+        qsort(h, (size_t)n, sizeof(cand_t), cand_cmp_desc);
+        for (int j = 0; j < n; ++j) { out_score[q * k + j] = h[j].s; out_idx[q * k + j] = h[j].i; }
+        for (int j = n; j < k; ++j) { out_score[q * k + j] = -3.402823466e38f; out_idx[q * k + j] = -1; }
+    }
+}

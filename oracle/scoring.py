@@ -50,6 +50,11 @@ def clib():
         L.oracle_dense_scores_fma.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, i32p, f32p]
         L.oracle_topk_rows.restype = None
         L.oracle_topk_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, f32p, i64p]
+        L.oracle_heap_block.restype = None
+        L.oracle_heap_block.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_void_p, i32p]
+        L.oracle_heap_finish.restype = None
+        L.oracle_heap_finish.argtypes = [ctypes.c_void_p, i32p, ctypes.c_int64, ctypes.c_int, f32p, i64p]
     return _LIB
 
 
@@ -133,6 +138,45 @@ def flat_ip_search(Q, D, k, block=65536):
         o = np.lexsort((best_i[r], -best_s[r].astype(np.float64)))[:k]
         out_s[r, :len(o)] = best_s[r, o]
         out_i[r, :len(o)] = best_i[r, o]
+    return out_s, out_i
+
+
+def flat_ip_search_blas_heap(Q, D, k, d_block=16384, q_block=4096, stats=None):
+    """IndexFlatIP.search the way faiss-cpu runs it (knn_inner_product -> exhaustive_inner_product_blas; the reference calls
+    it at /root/reference/scaling_retriever/indexer.py:210-214): sgemm over (query block, database block) pairs - the host
+    BLAS through torch.mm, all cores - and one heap per query fed from the block's scores (oracle/score_cpu.c, OpenMP over
+    queries).  faiss's own blocks are 4096 queries x 1024 vectors; 16 384 vectors per block here keep the threaded sgemm
+    efficient on a many-core host (to the baseline's advantage).  The cpu_baseline of bench.py.  stats (dict): receives the
+    seconds spent in sgemm and in the heaps."""
+    import time
+    import torch
+    L = clib()
+    Qt = torch.from_numpy(np.ascontiguousarray(Q, np.float32))
+    Dt = torch.from_numpy(np.ascontiguousarray(D, np.float32)) if isinstance(D, np.ndarray) else D
+    Nq, N = Qt.shape[0], Dt.shape[0]
+    out_s = np.empty((Nq, k), np.float32)
+    out_i = np.empty((Nq, k), np.int64)
+    t_mm = t_heap = 0.0
+    for q0 in range(0, Nq, q_block):
+        Qb = Qt[q0:q0 + q_block]
+        nqb = Qb.shape[0]
+        heaps = np.zeros((nqb, k, 2), np.int64)          # cand_t = {float, int64}: 16 bytes
+        heap_n = np.zeros(nqb, np.int32)
+        S = torch.empty((nqb, d_block), dtype=torch.float32)
+        for b in range(0, N, d_block):
+            nb = min(d_block, N - b)
+            t0 = time.perf_counter()
+            torch.mm(Qb, Dt[b:b + nb].T, out=S[:, :nb])
+            t1 = time.perf_counter()
+            L.oracle_heap_block(ctypes.cast(S.data_ptr(), ctypes.POINTER(ctypes.c_float)), nqb, nb, d_block, b, k,
+                                ctypes.c_void_p(heaps.ctypes.data), _p(heap_n, ctypes.c_int32))
+            t2 = time.perf_counter()
+            t_mm += t1 - t0
+            t_heap += t2 - t1
+        L.oracle_heap_finish(ctypes.c_void_p(heaps.ctypes.data), _p(heap_n, ctypes.c_int32), nqb, k,
+                             _p(out_s[q0:q0 + nqb], ctypes.c_float), _p(out_i[q0:q0 + nqb], ctypes.c_int64))
+    if stats is not None:
+        stats.update({"sgemm_s": t_mm, "heap_s": t_heap, "sgemm_gflops": 2.0 * Nq * N * Qt.shape[1] / max(t_mm, 1e-9) / 1e9})
     return out_s, out_i
 
 

@@ -23,6 +23,7 @@ struct DenseSplitArgs {
     float sd, isd;               // the segment's power-of-two scale and its inverse
     // filled by launch_dense_split: workgroup -> tile mapping (dense_split.hip split_tile_of)
     int xcd_order, grid_qt, grid_dt, grid_bq, grid_bd, grid_nbq, grid_total;
+    int diag;                    // dev switch SR_SPLIT_DIAG (timing only)
 };
 // p1 and p2 may be null (fewer planes)
 int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, unsigned short* p2, int64_t n_elems, hipStream_t s);

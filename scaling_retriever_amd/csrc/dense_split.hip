@@ -77,10 +77,12 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
     const int64_t left = a.row_end - row0;
     const int rows_valid = left < SP_BN ? (int)left : SP_BN;
     const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
+    if (a.diag & 2) return;                   // timing only (SR_SPLIT_DIAG): no epilogue at all
     f32x4 qa[MB];
     if constexpr (UB) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) qa[j] = *reinterpret_cast<const f32x4*>(qa_s + (wm * MB * 16 + j * 16 + frow) * 4);
+        if (!(a.diag & 1))                     // timing only (SR_SPLIT_DIAG): plane product without the error term
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const float* p = xy_s + 2 * (wn * NB * 16 + i * 16 + fg * 4);
@@ -377,6 +379,8 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     DenseSplitArgs b = a;
     b.xcd_order = 1;
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
+    b.diag = 0;
+    if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only: wrong results
     const SplitGrid sg = split_grid(rows, a.nq, b.xcd_order);
     b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq; b.grid_total = sg.total;
     // one persistent workgroup per CU (130 KB of LDS each); SR_SPLIT_PERSIST=0: one workgroup per tile slot (A/B)

@@ -13,6 +13,14 @@ result equals the single-GPU result bit for bit (same keys, same tie rule).
 import torch
 import torch.distributed as dist
 
+# The collectives below are no-ops on a group of one rank.  Tests set this to run them through torch.distributed anyway (a
+# 1-rank "nccl" group on one MI355X is the only way RCCL executes on a one-GPU box: tests/test_rccl_one_rank_gpu.py).
+FORCE_COLLECTIVES = False
+
+
+def _single(group):
+    return not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES)
+
 
 def shard_rows(n_total, rank, world_size):
     """Dataset rows of this rank: rank, rank + W, ... (no wrap-around padding)."""
@@ -42,7 +50,7 @@ def unpack_topk(packed):
 def gather_topk(scores, ids, dst=0, group=None):
     """The single collective of doc-sharded retrieval.  Every rank passes its local (scores, global ids)
     [nq, k]; rank `dst` gets (scores [W,nq,k], ids [W,nq,k]), the others (None, None)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group):
         return scores.unsqueeze(0), ids.unsqueeze(0)
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     packed = pack_topk(scores, ids)
@@ -67,7 +75,7 @@ def all_gather_query_reps(local_reps, n_queries, group=None):
     """Second (small) collective of the sharded path: every rank encodes only ITS block of queries
     (query_slice) and the fp32 embeddings are all-gathered (6980 x 2048 x 4 B = 57 MB in total), instead of every
     rank re-encoding all queries.  local_reps: [hi - lo, H]; returns [n_queries, H] on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group):
         return local_reps
     W = dist.get_world_size(group)
     per = (n_queries + W - 1) // W
@@ -89,7 +97,7 @@ def all_gather_query_csr(row_ptr, cols, vals, n_queries, group=None):
     (row_ptr int64 [n_local + 1], cols int32, vals fp32; 6980 x 32 x 8 B = 1.8 MB in total at MS MARCO Dev) are
     all-gathered in ONE collective: a rank's piece travels as one int64 buffer [per + cap] - per row counts, then
     (col << 32 | value bits) entries - padded to the largest piece.  Returns the CSR of ALL queries on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group):
         return row_ptr, cols, vals
     W = dist.get_world_size(group)
     per = (n_queries + W - 1) // W

@@ -167,6 +167,12 @@ def test_eval_dense_and_sparse_drivers_end_to_end(golden_dir, tmp_path):
 
     tok = AutoTokenizer.from_pretrained(lora)
     d_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, docs, 16)
+    # both loaders' artefacts against the oracle directly (llm_encoder.py:424-443 restated): the token-budget pipeline is held
+    # to the reference, not only to this repo's sequential path
+    for name_, got_ in (("sequential", seq), ("token budget", bud)):
+        for i in range(len(docs)):
+            err = np.linalg.norm(got_[f"d{i}"] - d_ref[i]) / np.linalg.norm(d_ref[i])
+            assert err < 1.5e-2, (name_, i, err)
     q_ref = _encode_oracle(LB.dense_encode, merged, cfg, tok, queries, 8)
     ref_scores = q_ref @ d_ref.T
     for qi in range(len(queries)):

@@ -37,6 +37,14 @@ def test_both_heads_from_one_pass_equal_the_single_head_encoders(golden_dir, nam
         ref_s = sparse.encode(input_ids=ids, attention_mask=mask)
         # right padding: the dense span also computes the trailing pad rows (masked keys, skipped by the max) - same values
         assert torch.equal(s, ref_s) if side == "left" else bool((s - ref_s).abs().max() <= 1e-6 * ref_s.abs().max()), side
+        # ... and BOTH heads of the one-pass encoder against the reference's own head classes (tests/golden/enc_*.npz: fp32
+        # outputs of LlamaBiDense / LlamaBiSparse .encode, /root/reference/scaling_retriever/modeling/llm_encoder.py:186-196,424-443,
+        # the heads HybridIndexer / HybridRetriever call, indexer.py:764,939): 2e-5 in the fp32 regime, the bf16-autocast band otherwise
+        tol = 2e-5 if prec == "fp32" else 1.5e-2
+        for got, key in ((d, "dense"), (s, "sparse")):
+            ref = z[f"{side}:{key}"]
+            err = float(np.linalg.norm(got.cpu().numpy() - ref) / np.linalg.norm(ref))
+            assert err < tol, (name, prec, side, key, err)
 
 
 def test_hybrid_indexer_and_retriever_end_to_end(golden_dir, tmp_path):

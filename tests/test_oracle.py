@@ -111,3 +111,19 @@ def test_plan_file_order(golden_dir):
     z = np.load(os.path.join(golden_dir, "plan_files.npz"))
     exp_v = [f"embs_{i}_{j}.npy" for i in range(int(z["nranks"])) for j in range(int(z["num_chunks"]))]
     assert list(z["vec"]) == exp_v
+
+
+def test_blas_heap_flat_ip_equals_the_brute_force_restatement():
+    """The cpu_baseline's faiss-style search (host BLAS sgemm blocks + one heap per query in C) returns what the numpy
+    restatement of IndexFlatIP.search returns (/root/reference/scaling_retriever/indexer.py:210-214): exact inner products,
+    descending, ties by ascending index, (-FLT_MAX, -1) pads when k > N."""
+    rng = np.random.default_rng(4)
+    Q = rng.standard_normal((37, 64), dtype=np.float32)
+    D = rng.standard_normal((3000, 64), dtype=np.float32)
+    D[100:130] = D[7]
+    for k, db, qb in ((10, 512, 16), (200, 4096, 64)):
+        s, i = SC.flat_ip_search_blas_heap(Q, D, k, d_block=db, q_block=qb)
+        es, ei = SC.flat_ip_search(Q, D, k)
+        assert np.array_equal(i, ei) and np.allclose(s, es, rtol=1e-6, atol=1e-6)
+    s, i = SC.flat_ip_search_blas_heap(Q[:3], D[:5], 8)
+    assert (i[:, 5:] == -1).all() and (s[:, 5:] < -3e38).all()
