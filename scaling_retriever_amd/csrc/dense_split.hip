@@ -95,36 +95,67 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
                     acc[i][j][r] = __builtin_fmaf(qa[j][0], x[r], __builtin_fmaf(qa[j][1], y[r], acc[i][j][r]));
         }
     }
+    // Survivors: the four queries of a lane are counted first and their four slot reservations (one atomic each) are issued
+    // together - one memory round trip per tile instead of four in a row (the epilogue was 10 % of the pass, most of it
+    // waiting for those) - then the keys are stored.
+    float tq[MB], out_scale[MB];
+    int cnt[MB], pos[MB];
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int q = q0 + wm * MB * 16 + j * 16 + frow;
-        if (q >= a.nq) continue;
-        float tq = a.tau[q];
-        float out_scale = 1.f;
+        tq[j] = q < a.nq ? a.tau[q] : INFINITY;          // a query beyond the batch keeps nothing
+        out_scale[j] = 1.f;
         if constexpr (UB) {
-            tq = tq * (qa[j][2] * a.sd);           // scaled-domain threshold (-inf stays -inf)
-            out_scale = qa[j][3] * a.isd;
+            tq[j] = tq[j] * (qa[j][2] * a.sd);           // scaled-domain threshold (-inf stays -inf)
+            out_scale[j] = qa[j][3] * a.isd;
         }
-        int cnt = 0;
+    }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+    for (int j = 0; j < MB; ++j) {
+        // the largest of the lane's 32 values first: most (lane, query) pairs keep nothing once tau has risen
+        float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
-                cnt += (lr < rows_valid && acc[i][j][r] >= tq) ? 1 : 0;
+        for (int i = 0; i < NB; ++i) {
+            const int lr0 = wn * NB * 16 + i * 16 + fg * 4;
+            if (lr0 + 3 < rows_valid) {
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (lr0 + r < rows_valid) mx = fmaxf(mx, acc[i][j][r]);
             }
-        if (cnt == 0) continue;
-        int pos = atomicAdd(&a.cand_count[q], cnt);
+        }
+        cnt[j] = 0;
+        if (mx >= tq[j]) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
+                    cnt[j] += (lr < rows_valid && acc[i][j][r] >= tq[j]) ? 1 : 0;
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int q = q0 + wm * MB * 16 + j * 16 + frow;
+        pos[j] = cnt[j] ? atomicAdd(&a.cand_count[q], cnt[j]) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        if (cnt[j] == 0) continue;
+        const int q = q0 + wm * MB * 16 + j * 16 + frow;
         uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
+        int p = pos[j];
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
                 const float sc = acc[i][j][r];
-                if (lr < rows_valid && sc >= tq) {
-                    if (pos < a.cand_cap) dst[pos] = sr_make_key(UB ? sc * out_scale : sc, gid0 + (uint32_t)lr * a.id_stride);
-                    ++pos;
+                if (lr < rows_valid && sc >= tq[j]) {
+                    if (p < a.cand_cap) dst[p] = sr_make_key(UB ? sc * out_scale[j] : sc, gid0 + (uint32_t)lr * a.id_stride);
+                    ++p;
                 }
             }
     }
