@@ -52,6 +52,8 @@ LION_1B = dict(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector peak
 PEAK_BF16_MFMA_TF = 2500.0   # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0       # HBM3E spec peak (about 6300 GB/s is what a streaming copy reaches)
+PEAK_L2_GBPS = 17800.0       # MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 16.8-18.8 TB/s chip-wide out of the XCDs' L2
+PEAK_VALU_F32_OPS = 256 * 4 * 16 * 2 * 2.4e9     # packed fp32 lane-operations per second (a multiply or an add each): 78.6e12
 FLOP_PER_TOKEN_1B = 1.946e9  # 2 x linear params of the 1B body
 
 
@@ -232,8 +234,14 @@ def sparse_leg(args, device):
     _lib.check(lib.sr_sparse_index_profile_read(idx._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by)))
     _lib.check(lib.sr_sparse_index_profile(idx._h, 0))
     kernel_s = ms.value * 1e-3 / steps
-    rmw = by.value / 8.0 / steps                                    # one LDS read-modify-write per touched posting
-    rmw_rate = rmw / kernel_s
+    # what the query-block kernel really loads and applies in one pass (device counters, one extra untimed pass)
+    idx.work_counters(True)
+    idx.search(q_indptr, q_cols, q_vals, k)
+    wc = idx.work_counters(False)
+    TILE = 4096
+    valu_ops = 2.0 * wc["dense_column_applications"] * TILE          # unfused multiply + add per (column, query, doc)
+    rmw = float(wc["light_postings"] + wc["grouped_postings"])        # one LDS read-modify-write per posting of a scatter run
+    bytes_loaded = 4.0 * TILE * wc["dense_columns_loaded"] + 8.0 * rmw + 40.0 * wc["plan_entries"]
     lds_peak, lds_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "r02_lds_rmw.json")) as f:
@@ -243,6 +251,22 @@ def sparse_leg(args, device):
     except Exception:
         pass
     hbm_gbps = unique_bytes / kernel_s / 1e9
+    valu_rate = valu_ops / kernel_s
+    l2_rate = bytes_loaded / kernel_s
+    bounds = {
+        "valu_dense_columns": {"bound": "valu", "achieved": round(valu_rate / 1e12, 2), "peak": round(PEAK_VALU_F32_OPS / 1e12, 1),
+                               "unit": "T unfused fp32 lane-operations/s (v_pk_mul_f32 + v_pk_add_f32; 256 CUs x 4 SIMDs x 16 lanes x 2 packed x 2.4 GHz)",
+                               "frac": round(valu_rate / PEAK_VALU_F32_OPS, 4), "ops_per_pass": valu_ops,
+                               "floor_ms_per_pass": round(valu_ops / PEAK_VALU_F32_OPS * 1e3, 1)},
+        "l2_bytes_loaded": {"bound": "l2", "achieved": round(l2_rate / 1e9, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s out of L2 (MI355X_MICROARCH.md, "
+                            "rows gathered from the XCD's L2: 16.8-18.8 TB/s chip-wide)", "frac": round(l2_rate / 1e9 / PEAK_L2_GBPS, 4),
+                            "bytes_per_pass": bytes_loaded, "floor_ms_per_pass": round(bytes_loaded / (PEAK_L2_GBPS * 1e9) * 1e3, 1),
+                            "of_which_dense_columns": 4.0 * TILE * wc["dense_columns_loaded"], "of_which_postings": 8.0 * rmw},
+        "lds_scatter": {"bound": "lds", "achieved": rmw / kernel_s, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",
+                        "frac": round(rmw / kernel_s / lds_peak, 4) if lds_peak else None, "rmw_per_pass": rmw, "peak_source": lds_src,
+                        "floor_ms_per_pass": round(rmw / lds_peak * 1e3, 1) if lds_peak else None},
+        "work_counters_per_pass": wc,
+    }
     out = {"metric": "sparse inverted-index queries/s (index resident in HBM, top-%d)" % k, "value": round(nq / dt, 1), "unit": "queries/s",
            "ms_per_pass": round(dt * 1e3, 1), "dtype": "f32", "data": "synthetic",
            "config": {"workload": "Lion-SP-1B sparse scoring (BASELINE.json configs[2]), synthetic Zipf(1.0) index", "V": V, "N": N, "L0_d": L0_d,
@@ -254,12 +278,15 @@ def sparse_leg(args, device):
                         "kernel_ms_per_pass": round(kernel_s * 1e3, 1), "unique_index_bytes_per_pass": unique_bytes,
                         "hbm_floor_ms_per_pass": round(unique_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3, 2),
                         "note": "achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per posting) / "
-                                "kernel time: the HBM floor is a small fraction of the kernel time, i.e. this kernel is NOT HBM-bound - the posting "
-                                "lists and the dense columns of the heavy terms are re-read per (4 queries, 4096-doc tile) from L2 / Infinity "
-                                "Cache; `lds_rmw` prices every touched posting as one LDS read-modify-write (the per-query kernel's model; the "
-                                "query-block kernel applies the dense-column terms - most of the touched postings - in registers instead)"},
-           "lds_rmw": {"bound": "lds", "achieved": rmw_rate, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",
-                       "frac": round(rmw_rate / lds_peak, 4) if lds_peak else None, "rmw_per_pass": rmw, "peak_source": lds_src}}
+                                "kernel time: the HBM floor is a small fraction of the kernel time, i.e. this kernel is NOT HBM-bound.  `bounds` prices "
+                                "the work the kernel really does, counted on the device in an extra pass: the unfused multiply-adds of the "
+                                "dense-column terms against the fp32 VALU rate, the bytes it loads (columns + postings + plan) against the L2 rate, "
+                                "the postings it scatters against the LDS read-modify-write rate of tools/micro/lds_rmw.hip - the three run one "
+                                "after another inside a workgroup, so their floors ADD (sum_of_floors_ms)"},
+           "bounds": bounds}
+    fl_ = [bounds[b_]["floor_ms_per_pass"] for b_ in ("valu_dense_columns", "l2_bytes_loaded", "lds_scatter") if bounds[b_]["floor_ms_per_pass"]]
+    out["bounds"]["sum_of_floors_ms"] = round(sum(fl_), 1)
+    out["bounds"]["kernel_over_sum_of_floors"] = round(kernel_s * 1e3 / max(sum(fl_), 1e-9), 2)
     from oracle import scoring as SC
     h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
     nqc = max(args.sparse_cpu_queries, 4)

@@ -128,6 +128,12 @@ int sr_sparse_index_set_workspace_limit(sr_sparse_index* idx, int64_t bytes);
 int sr_sparse_index_destroy(sr_sparse_index* idx);
 /* Measurement hook as for the dense index; algorithmic bytes = 8 B per posting of the
  * query terms that falls in the launched doc tiles (computed on the device).       */
+/* Work counters of the query-block kernel (measurement hook): while enabled, every workgroup adds what it loads and applies
+ * to six device counters; each call returns them (out6 may be null) and resets them.  out6[0] dense columns loaded (one =
+ * 4096 floats), [1] (column, query) applications (one = 4096 unfused multiply-adds), [2] / [3] postings loaded by the one-step /
+ * grouped scatter runs (8 bytes and one LDS read-modify-write each), [4] plan entries fetched, [5] (query block, doc tile)
+ * workgroups.  bench.py prices the kernel's VALU and L2 bounds from these.                                                  */
+int sr_sparse_index_work_counters(sr_sparse_index* idx, int enable, uint64_t* out6);
 int sr_sparse_index_profile(sr_sparse_index* idx, int enable);
 int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_launches, double* total_ms,
                                  double* total_posting_bytes);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sr_dense_index_profile": (c_int, [c_void_p, c_int]),
     "sr_dense_index_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "sr_sparse_index_work_counters": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "sr_sparse_index_profile": (c_int, [c_void_p, c_int]),
     "sr_sparse_index_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]),

@@ -373,7 +373,9 @@ __global__ __launch_bounds__(256) void convert_rows_split_h_kernel(const void* _
 // first (x = embed[tok] if embed; y = (x * rsqrt(mean(x^2) + eps)) * w), i.e. rmsnorm_split_kernel on fp16 planes
 __global__ __launch_bounds__(256) void rows_split_h_kernel(float* __restrict__ x, const float* __restrict__ embed,
                                                            const int* __restrict__ tok_id, const float* __restrict__ w,
-                                                           bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, int K, float eps) {
+                                                           bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, int K, float eps,
+                                                           const float* __restrict__ gu_cmax, float* __restrict__ act_sc,
+                                                           float* __restrict__ act_inv) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= T) return;
@@ -390,17 +392,26 @@ __global__ __launch_bounds__(256) void rows_split_h_kernel(float* __restrict__ x
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
         rs = 1.0f / sqrtf(ss / (float)K + eps);
     }
-    float mx = 0.f;
+    float mx = 0.f, s2 = 0.f;
     for (int i = lane * 4; i < K; i += 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
         f32x4 g = {1.f, 1.f, 1.f, 1.f};
         if (w) g = *reinterpret_cast<const f32x4*>(w + i);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(w ? (v[c] * rs) * g[c] : v[c]));
+        for (int c = 0; c < 4; ++c) {
+            const float y = w ? (v[c] * rs) * g[c] : v[c];
+            mx = fmaxf(mx, fabsf(y));
+            s2 += y * y;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float sc = row_scale_pow2(mx);
     if (lane == 0) a_inv[t] = 1.0f / sc;
+    if (gu_cmax) {                              // see rows_split_h_reg_kernel
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+        const float osc = row_scale_pow2(s2 * *gu_cmax * 1.02f);
+        if (lane == 0) { act_sc[t] = osc; act_inv[t] = 1.0f / osc; }
+    }
     bf16_t* orow = xs + (int64_t)t * K * 3;
     for (int i = lane * 4; i < K; i += 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
@@ -424,7 +435,9 @@ __global__ __launch_bounds__(256) void rows_split_h_kernel(float* __restrict__ x
 template <int NV>
 __global__ __launch_bounds__(256) void rows_split_h_reg_kernel(float* __restrict__ x, const float* __restrict__ embed,
                                                                const int* __restrict__ tok_id, const float* __restrict__ w,
-                                                               bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, float eps) {
+                                                               bf16_t* __restrict__ xs, float* __restrict__ a_inv, int T, float eps,
+                                                               const float* __restrict__ gu_cmax, float* __restrict__ act_sc,
+                                                               float* __restrict__ act_inv) {
     constexpr int K = 256 * NV;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -458,6 +471,16 @@ __global__ __launch_bounds__(256) void rows_split_h_reg_kernel(float* __restrict
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float sc = row_scale_pow2(mx);
     if (lane == 0) a_inv[t] = 1.0f / sc;
+    if (gu_cmax) {
+        // scale of this row's SwiGLU output, known before the gate-up GEMM runs: |silu(g_j) u_j| <= |g_j||u_j| <=
+        // |xn|^2 |wg_j||wu_j| <= |xn|^2 cmax (Cauchy-Schwarz; 1.02: the fp32 evaluation of the norms) - EPI_SWIGLU_SPLIT_H
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s2 += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+        const float osc = row_scale_pow2(s2 * *gu_cmax * 1.02f);
+        if (lane == 0) { act_sc[t] = osc; act_inv[t] = 1.0f / osc; }
+    }
     bf16_t* orow = xs + (int64_t)t * K * 3;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -475,15 +498,41 @@ __global__ __launch_bounds__(256) void rows_split_h_reg_kernel(float* __restrict
     }
 }
 
+// gu_cmax (device float) / act_sc / act_inv: the row scales of the SwiGLU output this row will produce
 static void launch_rows_split_h(float* x, const float* embed, const int* tok, const float* w, bf16_t* xs, float* inv, int T, int K,
-                                float eps, hipStream_t s) {
+                                float eps, hipStream_t s, const float* gu_cmax = nullptr, float* act_sc = nullptr,
+                                float* act_inv = nullptr) {
     const dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
     switch (K) {
-        case 2048: hipLaunchKernelGGL(rows_split_h_reg_kernel<8>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
-        case 4096: hipLaunchKernelGGL(rows_split_h_reg_kernel<16>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
-        case 8192: hipLaunchKernelGGL(rows_split_h_reg_kernel<32>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps); break;
-        default: hipLaunchKernelGGL(rows_split_h_kernel, grid, block, 0, s, x, embed, tok, w, xs, inv, T, K, eps);
+        case 2048: hipLaunchKernelGGL(rows_split_h_reg_kernel<8>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps, gu_cmax, act_sc, act_inv); break;
+        case 4096: hipLaunchKernelGGL(rows_split_h_reg_kernel<16>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps, gu_cmax, act_sc, act_inv); break;
+        case 8192: hipLaunchKernelGGL(rows_split_h_reg_kernel<32>, grid, block, 0, s, x, embed, tok, w, xs, inv, T, eps, gu_cmax, act_sc, act_inv); break;
+        default: hipLaunchKernelGGL(rows_split_h_kernel, grid, block, 0, s, x, embed, tok, w, xs, inv, T, K, eps, gu_cmax, act_sc, act_inv);
     }
+}
+
+// max over the MLP's feature pairs j of |w_gate_j| |w_up_j|, from the fp16 plane segments [w0 | w1 | w0] of the interleaved
+// gate/up matrix (gate rows and up rows alternate in 16-row blocks) and the rows' inverse scales: one wave per pair
+__global__ __launch_bounds__(256) void gu_cmax_kernel(const bf16_t* __restrict__ wgu_s, const float* __restrict__ wgu_i, int I, int K,
+                                                      float* __restrict__ cmax) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= I) return;
+    const int64_t rg = (int64_t)(j / 16) * 32 + (j % 16), ru = rg + 16;
+    float n2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bf16_t* row = wgu_s + (h ? ru : rg) * 3 * (int64_t)K;
+        float ss = 0.f;
+        for (int i = lane; i < K; i += 64) {
+            const float v = (float)__builtin_bit_cast(_Float16, row[i]) + (float)__builtin_bit_cast(_Float16, row[K + i]);
+            ss += v * v;
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float inv = wgu_i[h ? ru : rg];
+        n2[h] = ss * inv * inv;
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(cmax), __float_as_uint(sqrtf(n2[0]) * sqrtf(n2[1]) * 1.001f));
 }
 
 // ---- LoRA merge: W += scale * B @ A -----------------------------------------------------
@@ -554,6 +603,7 @@ struct LayerW {
     bf16_t *wqkv_s = nullptr, *wo_s = nullptr, *wgu_s = nullptr, *wdown_s = nullptr;
     // fp16-plane regime: inverse power-of-two scale of every weight row
     float *wqkv_i = nullptr, *wo_i = nullptr, *wgu_i = nullptr, *wdown_i = nullptr;
+    float* gu_cmax = nullptr;   // fp16-plane regime: max_j |w_gate_j||w_up_j| (device float), see gu_cmax_kernel
 };
 
 struct sr_model {
@@ -566,6 +616,7 @@ struct sr_model {
     float* lm_head_i = nullptr;    // fp16-plane regime: [V] inverse row scales
     float *attn_f = nullptr, *act_f = nullptr;                  // fp16-plane regime: fp32 attention / SwiGLU outputs before the row split
     float *xs_i = nullptr, *attn_i = nullptr, *act_i = nullptr; // ... and the inverse row scales of xs / attn_s / act_s
+    float* act_sc = nullptr;                                     // forward row scales of the fused SwiGLU split
     // fp32-regime workspace, allocated by the first fp32 encode call
     bf16_t* xs = nullptr;      // [Tm, n_seg * H]    normed hidden state, plane segments
     float* qkv_f = nullptr;    // [Tm, (nh + 2 nkv) hd] rotated q/k/v, fp32
@@ -596,10 +647,10 @@ static void model_free(sr_model* m) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(m->embed); F(m->lm_head); F(m->norm_w); F(m->rope_cos); F(m->rope_sin);
     F(m->lm_head_s); F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s);
-    F(m->lm_head_i); F(m->attn_f); F(m->act_f); F(m->xs_i); F(m->attn_i); F(m->act_i);
+    F(m->lm_head_i); F(m->attn_f); F(m->act_f); F(m->xs_i); F(m->attn_i); F(m->act_i); F(m->act_sc);
     for (auto& l : m->layers) {
         F(l.wqkv); F(l.wo); F(l.wgu); F(l.wdown); F(l.ln1); F(l.ln2); F(l.wqkv_s); F(l.wo_s); F(l.wgu_s); F(l.wdown_s);
-        F(l.wqkv_i); F(l.wo_i); F(l.wgu_i); F(l.wdown_i);
+        F(l.wqkv_i); F(l.wo_i); F(l.wgu_i); F(l.wdown_i); F(l.gu_cmax);
     }
     F(m->x); F(m->xn); F(m->qkv); F(m->attn); F(m->act); F(m->delta);
     F(m->span_start); F(m->span_len); F(m->pool_start); F(m->row_len); F(m->cu);
@@ -819,6 +870,16 @@ extern "C" int sr_model_finalize(sr_model* m) {
     SR_REQUIRE(!m->cfg.has_lm_head || m->have_lm_head, "sr_model_finalize: lm_head.weight missing");
     for (int i = 0; i < m->cfg.num_layers; ++i)
         SR_REQUIRE(m->layers[i].have == 511, "sr_model_finalize: layer %d is missing tensors (mask 0x%x)", i, m->layers[i].have);
+    if (m->cfg.fp32_planes == SR_FP32_PLANES_F16) {      // row bound of every layer's SwiGLU output (EPI_SWIGLU_SPLIT_H)
+        for (int i = 0; i < m->cfg.num_layers; ++i) {
+            LayerW& l = m->layers[i];
+            if (!l.gu_cmax) SR_CHECK_HIP(hipMalloc((void**)&l.gu_cmax, 4));
+            SR_CHECK_HIP(hipMemsetAsync(l.gu_cmax, 0, 4, nullptr));
+            hipLaunchKernelGGL(gu_cmax_kernel, dim3((unsigned)ceil_div64(m->cfg.intermediate_size, 4)), dim3(256), 0, nullptr, l.wgu_s, l.wgu_i,
+                               m->cfg.intermediate_size, m->cfg.hidden_size, l.gu_cmax);
+        }
+        SR_CHECK_LAUNCH();
+    }
     SR_CHECK_HIP(hipDeviceSynchronize());
     m->finalized = true;
     return SR_OK;
@@ -850,7 +911,7 @@ static int ensure_fp32_workspace(sr_model* m) {
               A((void**)&m->attn_s, Tm * nq * 2 * nsg) && A((void**)&m->act_s, Tm * I * 2 * nsg);
     if (ok && f16p)
         ok = A((void**)&m->attn_f, Tm * nq * 4) && A((void**)&m->act_f, Tm * I * 4) && A((void**)&m->xs_i, Tm * 4) &&
-             A((void**)&m->attn_i, Tm * 4) && A((void**)&m->act_i, Tm * 4);
+             A((void**)&m->attn_i, Tm * 4) && A((void**)&m->act_i, Tm * 4) && A((void**)&m->act_sc, Tm * 4);
     if (!ok) {
         auto F = [](void* p) { if (p) (void)hipFree(p); };
         F(m->xs); F(m->qkv_f); F(m->attn_s); F(m->act_s); F(m->attn_f); F(m->act_f); F(m->xs_i); F(m->attn_i); F(m->act_i);
@@ -908,6 +969,9 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
         auto split_rows = [&](float* src, const float* embed, const int* tok, const float* w, bf16_t* dst, float* inv, int K) {
             launch_rows_split_h(src, embed, tok, w, dst, inv, T, K, c.rms_norm_eps, s);
         };
+        // dev switch SR_FP32_FUSED_ACT=0: SwiGLU output as fp32 + a separate row-split pass (A/B, and the reference of the test)
+        const char* env_fa = sr_dev_getenv("SR_FP32_FUSED_ACT");
+        const bool fused_act = m->layers[0].gu_cmax && !(env_fa && *env_fa == '0');
         for (int li = 0; li < c.num_layers; ++li) {
             LayerW& l = m->layers[li];
             split_rows(m->x, li == 0 ? m->embed : (const float*)nullptr, li == 0 ? m->tok_id : (const int*)nullptr, l.ln1, m->xs, m->xs_i, H);
@@ -924,11 +988,21 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
             g = GemmArgs{};
             g.A = m->attn_s; g.W = l.wo_s; g.M = T; g.N = H; g.K = 3 * nq; g.C = m->x; g.a_scale = m->attn_i; g.w_scale = l.wo_i;
             SR_TRY(launch_gemm_bf16(EPI_RESID_F32_H, g, s));
-            split_rows(m->x, nullptr, nullptr, l.ln2, m->xs, m->xs_i, H);
-            g = GemmArgs{};
-            g.A = m->xs; g.W = l.wgu_s; g.M = T; g.N = 2 * I; g.K = 3 * H; g.C = m->act_f; g.a_scale = m->xs_i; g.w_scale = l.wgu_i;
-            SR_TRY(launch_gemm_bf16(EPI_SWIGLU_F32_H, g, s));
-            split_rows(m->act_f, nullptr, nullptr, nullptr, m->act_s, m->act_i, I);
+            if (fused_act) {
+                // the norm kernel also fixes the scale of the row's SwiGLU output (a rigorous bound, no overflow), so the
+                // gate-up GEMM writes the down_proj's fp16 plane segments itself: no fp32 intermediate, no split pass
+                launch_rows_split_h(m->x, nullptr, nullptr, l.ln2, m->xs, m->xs_i, T, H, c.rms_norm_eps, s, l.gu_cmax, m->act_sc, m->act_i);
+                g = GemmArgs{};
+                g.A = m->xs; g.W = l.wgu_s; g.M = T; g.N = 2 * I; g.K = 3 * H; g.C = m->act_s; g.a_scale = m->xs_i; g.w_scale = l.wgu_i;
+                g.out_scale = m->act_sc;
+                SR_TRY(launch_gemm_bf16(EPI_SWIGLU_SPLIT_H, g, s));
+            } else {
+                split_rows(m->x, nullptr, nullptr, l.ln2, m->xs, m->xs_i, H);
+                g = GemmArgs{};
+                g.A = m->xs; g.W = l.wgu_s; g.M = T; g.N = 2 * I; g.K = 3 * H; g.C = m->act_f; g.a_scale = m->xs_i; g.w_scale = l.wgu_i;
+                SR_TRY(launch_gemm_bf16(EPI_SWIGLU_F32_H, g, s));
+                split_rows(m->act_f, nullptr, nullptr, nullptr, m->act_s, m->act_i, I);
+            }
             g = GemmArgs{};
             g.A = m->act_s; g.W = l.wdown_s; g.M = T; g.N = H; g.K = 3 * I; g.C = m->x; g.a_scale = m->act_i; g.w_scale = l.wdown_i;
             SR_TRY(launch_gemm_bf16(EPI_RESID_F32_H, g, s));

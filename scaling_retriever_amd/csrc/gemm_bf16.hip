@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (
 void gemm_bf16_kernel(GemmArgs g) {
     constexpr bool F16 = EPI >= EPI_H_FIRST;          // fp16 plane operands + row scales (fp32 regime), see kernels.h
     constexpr int BEPI = !F16 ? EPI : (EPI == EPI_QKV_ROPE_F32_H ? EPI_QKV_ROPE_F32 : (EPI == EPI_RESID_F32_H ? EPI_RESID_F32
-                                      : (EPI == EPI_SWIGLU_F32_H ? EPI_SWIGLU_F32 : EPI_SEGMAX)));
+                                      : (EPI == EPI_SWIGLU_F32_H ? EPI_SWIGLU_F32 : (EPI == EPI_SWIGLU_SPLIT_H ? EPI_SWIGLU_SPLITH_BASE : EPI_SEGMAX))));
     constexpr int NW = WAVES_N * WAVES_M;
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE_BYTES = W_BYTES + A_BYTES;
@@ -514,6 +514,36 @@ void gemm_bf16_kernel(GemmArgs g) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * half_n + n) = y;
             }
         }
+    } else if constexpr (BEPI == EPI_SWIGLU_SPLITH_BASE) {
+        // fp32 regime on fp16 planes: silu(gate) * up (accurate exp, true division), scaled by the row's power of two and
+        // stored as [f1 | f0 | f0]: the fp32 intermediate and its row-split pass (112 -> 48 bytes of traffic per token and
+        // feature) are gone.  out_scale[m] comes from the bound |silu(g) u| <= |xn|^2 max_j |wg_j||wu_j|: no overflow.
+        const int half_n = g.N >> 1;
+        const int64_t ldc = 3 * (int64_t)half_n;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + wm * MB * 16 + j * 16 + frow;
+            if (m >= g.M) continue;
+            const float osc = g.out_scale[m];
+#pragma unroll
+            for (int i = 0; i < NB; i += 2) {
+                const int n = (n0 >> 1) + wn * NB * 8 + (i >> 1) * 16 + fg * 4;
+                if (n >= half_n) continue;
+                const f32x4 gt = acc[i][j], up = acc[i + 1][j];
+                bf16x4 p0, p1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = (gt[r] / (1.f + expf(-gt[r]))) * up[r];
+                    unsigned short f0, f1;
+                    split_f16x2(y * osc, f0, f1);
+                    p0[r] = (short)f0; p1[r] = (short)f1;
+                }
+                bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n;
+                *reinterpret_cast<bf16x4*>(crow) = p1;
+                *reinterpret_cast<bf16x4*>(crow + half_n) = p0;
+                *reinterpret_cast<bf16x4*>(crow + 2 * half_n) = p0;
+            }
+        }
     } else if constexpr (BEPI == EPI_SWIGLU_SPLIT) {
         // fp32 regime: silu(gate) * up with an accurate exp and a true division, then stored as the split-bf16 plane
         // segments the down_proj GEMM consumes: C [M, n_seg * N/2], segment sg holds plane out_map.plane[sg]
@@ -741,10 +771,12 @@ static GemmArgs rows_from(const GemmArgs& g, int row0) {
     t.A = g.A + (int64_t)row0 * g.K;
     t.M = g.M - row0;
     const int64_t ldc = (EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_F32 || EPI == EPI_SWIGLU_F32_H)
-                            ? g.N / 2 : (EPI == EPI_SWIGLU_SPLIT ? (int64_t)g.out_map.n_seg * (g.N / 2) : g.N);
-    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_SWIGLU_F32 || EPI >= EPI_H_FIRST) ? 4 : 2;
+                            ? g.N / 2 : (EPI == EPI_SWIGLU_SPLIT ? (int64_t)g.out_map.n_seg * (g.N / 2) : (EPI == EPI_SWIGLU_SPLIT_H ? 3 * (int64_t)(g.N / 2) : g.N));
+    const int64_t esz = (EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE_F32 || EPI == EPI_SWIGLU_F32 ||
+                         (EPI >= EPI_H_FIRST && EPI != EPI_SWIGLU_SPLIT_H)) ? 4 : 2;
     if constexpr (EPI != EPI_SEGMAX && EPI != EPI_SEGMAX_H) t.C = reinterpret_cast<unsigned char*>(g.C) + (int64_t)row0 * ldc * esz;
     if (g.a_scale) t.a_scale = g.a_scale + row0;
+    if (g.out_scale) t.out_scale = g.out_scale + row0;
     if (g.seq_of) t.seq_of = g.seq_of + row0;
     if (g.pos) t.pos = g.pos + row0;
     t.stamps = nullptr;
@@ -801,7 +833,8 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
     SR_REQUIRE(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0) return SR_OK;
     SR_REQUIRE(g.K % G_BK == 0, "gemm: K=%d must be a multiple of %d", g.K, G_BK);
-    const bool swiglu = epi == EPI_SWIGLU || epi == EPI_SWIGLU_SPLIT || epi == EPI_SWIGLU_F32 || epi == EPI_SWIGLU_F32_H;
+    const bool swiglu = epi == EPI_SWIGLU || epi == EPI_SWIGLU_SPLIT || epi == EPI_SWIGLU_F32 || epi == EPI_SWIGLU_F32_H || epi == EPI_SWIGLU_SPLIT_H;
+    SR_REQUIRE(epi != EPI_SWIGLU_SPLIT_H || g.out_scale, "gemm(swiglu split, fp16 planes): missing output row scales");
     SR_REQUIRE(g.N % 16 == 0 && (!swiglu || g.N % 32 == 0), "gemm: N=%d must be a multiple of 16 (32 for SwiGLU)", g.N);
     SR_REQUIRE(epi < EPI_H_FIRST || (g.a_scale && g.w_scale), "gemm(fp16 planes): missing row scales");
     SR_REQUIRE(epi != EPI_SWIGLU_SPLIT || (g.out_map.n_seg >= 1 && g.out_map.n_seg <= SR_MAX_SEG), "gemm(swiglu split): bad segment map");
@@ -819,6 +852,8 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
         case EPI_RESID_F32_H: return launch_one<EPI_RESID_F32_H>(g, s);
         case EPI_SWIGLU_F32_H: return launch_one<EPI_SWIGLU_F32_H>(g, s);
         case EPI_SEGMAX_H: return launch_one<EPI_SEGMAX_H>(g, s);
+        case EPI_SWIGLU_SPLIT_H: return launch_one<EPI_SWIGLU_SPLIT_H>(g, s);
+        default: break;
     }
     sr_set_error("gemm: unknown epilogue %d", (int)epi);
     return SR_ERR_INVALID;

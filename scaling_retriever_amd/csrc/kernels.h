@@ -19,6 +19,10 @@ enum GemmEpilogue {
     // epilogue of the base behaviour runs
     EPI_H_FIRST = 9,
     EPI_QKV_ROPE_F32_H = 9, EPI_RESID_F32_H = 10, EPI_SWIGLU_F32_H = 11, EPI_SEGMAX_H = 12,
+    // silu(gate) * up in fp32, multiplied by out_scale[m] (a power of two from a rigorous row bound, so that no value can
+    // overflow fp16) and stored directly as the [f1 | f0 | f0] fp16 plane segments the down_proj GEMM consumes: C [M, 3 N/2]
+    EPI_SWIGLU_SPLIT_H = 13,
+    EPI_SWIGLU_SPLITH_BASE = 14,    // internal: the base behaviour of EPI_SWIGLU_SPLIT_H
 };
 
 // ---- fp32 regime: fp32 operands as sums of bf16 planes ---------------------------------------------------
@@ -61,6 +65,7 @@ struct GemmArgs {
     unsigned long long* stamps;  // diagnostics only (tools/micro): 4 s_memrealtime stamps (100 MHz) per workgroup-tile, else null
     const float* a_scale;   // _H epilogues: [M] inverse scale of each activation row (a power of two)
     const float* w_scale;   // _H epilogues: [N] inverse scale of each weight row
+    const float* out_scale; // EPI_SWIGLU_SPLIT_H: [M] forward scale of each output row
     SplitMap out_map;  // EPI_SWIGLU_SPLIT: plane of each output segment; C is [M, n_seg * N/2] bf16
     int m_fastest;     // tile order, chosen by launch_gemm_bf16: 1 = token tiles fastest (W far larger than the caches)
     int xcd_order;     // 1: the workgroups of one XCD (blockIdx % 8) work on a compact block of tiles, so that its L2 serves

@@ -309,6 +309,10 @@ struct SparseBlockArgs {
     int n_sub;                   // sub-tiles of this launch
     unsigned long long* stamps;  // dev switch SR_SPARSE_STAMPS: [7] sums of s_memrealtime ticks (10 ns) per phase over the sampled waves + [7] = waves
     int diag;                    // dev switch SR_SPARSE_DIAG (timing only, wrong results): bit mask of skipped run kinds, 2 = dense, 4 = light scatter, 8 = big scatter
+    // work counters (sr_sparse_index_work_counters; off unless enabled): [0] dense columns loaded (one = SPB_TILE floats),
+    // [1] (dense column, query) applications (one = SPB_TILE unfused multiply-adds), [2] postings loaded by the one-step runs,
+    // [3] postings loaded by the grouped runs, [4] plan entries fetched, [5] (block, sub-tile) workgroups
+    unsigned long long* counters;
 };
 
 #ifndef SPB_WAVES_PER_SIMD
@@ -425,6 +429,24 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
         const uint64_t bmask = __ballot(slot < 0 && seg_n > SPB_LIGHT);                    // scatter runs walked in groups
         const uint64_t lmask = __ballot(slot < 0 && seg_n > 0 && seg_n <= SPB_LIGHT);      // one wave step per run
         uint64_t rem = dmask | bmask | lmask;
+        if (b.counters && wave == 0) {
+            int nqw = 0;
+#pragma unroll
+            for (int q = 0; q < SPB_Q; ++q) nqw += seg_w[q] != 0.f ? 1 : 0;
+            const bool is_d = slot >= 0 && seg_n > 0, is_l = slot < 0 && seg_n > 0 && seg_n <= SPB_LIGHT, is_b = slot < 0 && seg_n > SPB_LIGHT;
+            unsigned long long c1 = is_d ? nqw : 0, c2 = is_l ? (unsigned long long)seg_n * nqw : 0, c3 = is_b ? (unsigned long long)seg_n * nqw : 0;
+            for (int off = 32; off > 0; off >>= 1) {
+                c1 += __shfl_xor(c1, off); c2 += __shfl_xor(c2, off); c3 += __shfl_xor(c3, off);
+            }
+            if (lane == 0) {
+                atomicAdd(&b.counters[0], (unsigned long long)__builtin_popcountll(dmask));
+                atomicAdd(&b.counters[1], c1);
+                atomicAdd(&b.counters[2], c2);
+                atomicAdd(&b.counters[3], c3);
+                atomicAdd(&b.counters[4], (unsigned long long)((ne - e0) < 64 ? (ne - e0) : 64));
+                if (e0 == 0) atomicAdd(&b.counters[5], 1ull);
+            }
+        }
         stamp(0);
         int st_prev = -1;
         while (rem) {
@@ -877,6 +899,8 @@ struct sr_sparse_index {
     uint8_t* plan_ok = nullptr;
     int64_t* plan_off = nullptr;
     unsigned long long* d_stamps = nullptr;   // dev switch SR_SPARSE_STAMPS
+    unsigned long long* d_counters = nullptr; // sr_sparse_index_work_counters
+    bool count_work = false;
     int32_t* plan_perm = nullptr;     // every batch's queries in block order
     uint8_t* q_done = nullptr;
     int64_t plan_q_cap = 0;
@@ -1064,6 +1088,7 @@ extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     idx->order.release();
     sparse_free_device(idx);
     if (idx->d_postings) (void)hipFree(idx->d_postings);
+    if (idx->d_counters) (void)hipFree(idx->d_counters);
     delete idx;
     return SR_OK;
 }
@@ -1075,6 +1100,24 @@ extern "C" int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dens
     *n_dense_terms = idx->n_dense;
     *n_block_calls = idx->n_block_calls;
     *n_fallback_calls = idx->n_fallback_calls;
+    return SR_OK;
+}
+
+// Work counters of the query-block kernel (measurement hook, like sr_sparse_index_profile): while enabled every workgroup adds
+// what it loads and applies to 6 device counters; the call returns them and resets them.  out[0] dense columns loaded (one =
+// 4096 floats), [1] (column, query) applications (one = 4096 unfused multiply-adds), [2] / [3] postings loaded by the one-step /
+// grouped scatter runs (8 bytes each, one LDS read-modify-write each), [4] plan entries fetched, [5] workgroup-tiles.
+extern "C" int sr_sparse_index_work_counters(sr_sparse_index* idx, int enable, uint64_t* out6) {
+    SR_REQUIRE(idx, "sr_sparse_index_work_counters: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->d_counters) {
+        SR_CHECK_HIP(hipMalloc((void**)&idx->d_counters, 6 * 8));
+        SR_CHECK_HIP(hipMemset(idx->d_counters, 0, 6 * 8));
+    }
+    SR_CHECK_HIP(hipDeviceSynchronize());
+    if (out6) SR_CHECK_HIP(hipMemcpy(out6, idx->d_counters, 6 * 8, hipMemcpyDeviceToHost));
+    SR_CHECK_HIP(hipMemset(idx->d_counters, 0, 6 * 8));
+    idx->count_work = enable != 0;
     return SR_OK;
 }
 
@@ -1236,6 +1279,7 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 b.blk_base = (qb / q_batch) * blocks_per_batch;
                 b.diag = 0;
                 b.stamps = idx->d_stamps;
+                b.counters = idx->count_work ? idx->d_counters : nullptr;
                 if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
                 b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));
                 const dim3 grid((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)ceil_div64(b.n_sub, SPB_SUBS));

@@ -237,6 +237,15 @@ class SparseIndexHIP:
         _lib.check(self.lib.sr_sparse_index_block_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"dense_terms": a.value, "block_calls": b.value, "fallback_calls": c.value}
 
+    def work_counters(self, enable):
+        """Switch the query-block kernel's work counters on / off; returns what was counted since the last call:
+        {"dense_columns_loaded", "dense_column_applications", "light_postings", "grouped_postings", "plan_entries", "workgroup_tiles"}."""
+        out = (ctypes.c_uint64 * 6)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_sparse_index_work_counters(self._h, 1 if enable else 0, out), "sr_sparse_index_work_counters")
+        keys = ("dense_columns_loaded", "dense_column_applications", "light_postings", "grouped_postings", "plan_entries", "workgroup_tiles")
+        return {k_: int(v) for k_, v in zip(keys, out)}
+
     def search(self, q_indptr, q_cols, q_vals, k, threshold=0.0, id_base=0, id_stride=1):
         """Queries as CSR tensors. Returns (scores [nq,k], ids [nq,k], counts [nq]) cuda tensors."""
         def to_dev(x, dt):

@@ -47,10 +47,6 @@ def run(mode, k, env, reps=2):
 
 for rep in range(2):
     run("fp32_filtered", 1000, {})
-    run("fp32_filtered", 1000, {"SR_SPLIT_PERSIST": "0"})
-    run("fp32_filtered", 1000, {"SR_SPLIT_DIAG": "1"})
+    run("fp32_filtered", 1000, {"SR_SPLIT_DIAG": "4"})
+    run("fp32_filtered", 1000, {"SR_SPLIT_DIAG": "5"})
     run("fp32_filtered", 1000, {"SR_SPLIT_DIAG": "2"})
-    run("fp32_filtered", 1000, {"SR_SPLIT_DIAG": "2", "SR_SPLIT_PERSIST": "0"})
-    run("fp32_filtered", 1000, {"SR_FILTER_KP": "2048"})
-    run("bf16x3", 1000, {})
-    run("bf16x3", 1000, {"SR_SPLIT_PERSIST": "0"})
