@@ -129,9 +129,19 @@ struct TopkWS {
     float* tau = nullptr;           // [nq_cap]     score of the current k-th best (-inf until k kept)
     uint64_t* cand_keys = nullptr;  // [nq_cap, cand_cap]
     int* cand_count = nullptr;      // [nq_cap]
+    // Segmented candidate slots (dense_split.hip): the tail [seg_off, seg_off + seg_n * SR_SEG_P) of a query's candidate
+    // buffer is cut into seg_n segments of SR_SEG_P slots, one per (doc tile of the launch, producer lane group); a producer
+    // with at most SR_SEG_P survivors stores them in ITS segment and its count in seg_cnt - no atomic, no memory round trip -
+    // and topk_compact_kernel gathers the segments behind the atomically appended candidates.  seg_n = 0: not in use.
+    unsigned char* seg_cnt = nullptr;   // [nq_cap, seg_n]
+    int64_t seg_off = 0;
+    int seg_n = 0;
     int ensure(int64_t nq, int k, int64_t cand_cap);
+    int ensure_segments(int64_t nq, int k, int64_t dense_cap, int seg_n);     // cand_cap = dense_cap + seg_n * SR_SEG_P
     void release();
 };
+#define SR_SEG_P 4          // slots per segment
+#define SR_SEG_PROD 8       // producer lane groups per (query, 256-doc tile) of dense_split_kernel
 // tau := -inf, counts := 0 for the first nq queries
 int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s);
 // merge candidates into the running top-k (per query), update tau, clear candidates

@@ -606,7 +606,11 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
         }
         if (np == 0) SR_TRY(launch_filter_queries(d_queries, nq, idx->dim, idx->qpl[0], idx->qa, s));     // idx->qa: dense_search_filtered
         else SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
-        SR_TRY(ws.ensure(nq, k, chunk));
+        // segmented candidate slots: one segment per (256-doc tile of a launch, producer lane group), see common.h
+        bool use_seg = true;
+        if (const char* e = sr_dev_getenv("SR_SPLIT_SEG")) use_seg = atoi(e) != 0;       // A/B switch: 0 = atomic appends only
+        if (use_seg) SR_TRY(ws.ensure_segments(nq, k, chunk, (int)(chunk / TM) * SR_SEG_PROD));
+        else SR_TRY(ws.ensure(nq, k, chunk));
         SR_TRY(topk_reset(ws, nq, s));
         int64_t step = ceil_div64((int64_t)k + 1024, TM) * TM;   // short first launches, see below
         if (step < TM * ceil_div64(256, qtiles)) step = TM * ceil_div64(256, qtiles);
@@ -636,6 +640,7 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                 a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
                 a.tau = ws.tau; a.cand_keys = ws.cand_keys; a.cand_count = ws.cand_count;
                 a.cand_cap = ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
+                a.seg_cnt = ws.seg_n > 0 ? ws.seg_cnt : nullptr; a.seg_n = ws.seg_n; a.seg_off = ws.seg_off;
                 idx->prof.begin(s);
                 SR_TRY(launch_dense_split(a, s));
                 idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);

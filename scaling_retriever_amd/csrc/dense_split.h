@@ -14,6 +14,10 @@ struct DenseSplitArgs {
     int* cand_count;
     int64_t cand_cap;
     uint32_t id_base, id_stride;
+    // segmented candidate slots (common.h TopkWS): null = every survivor is appended through the atomic counter
+    unsigned char* seg_cnt;
+    int seg_n;
+    int64_t seg_off;
     // upper_bound = 1 (dense_filter.hip): fp16 planes of power-of-two scaled operands; the key of (q, j) is not the plane
     // product but U = acc / (sq sd) + e(q, j), an upper bound of the exact fp32 score:
     //   U' = acc + qa[q].x * dxy[j].x + qa[q].y * dxy[j].y   (scaled domain),   U = U' * qa[q].w * isd
@@ -24,6 +28,7 @@ struct DenseSplitArgs {
     // filled by launch_dense_split: workgroup -> tile mapping (dense_split.hip split_tile_of)
     int xcd_order, grid_qt, grid_dt, grid_bq, grid_bd, grid_nbq, grid_total;
     int diag;                    // dev switch SR_SPLIT_DIAG (timing only)
+    unsigned long long* stamps;  // dev switch SR_SPLIT_STAMPS
 };
 // p1 and p2 may be null (fewer planes)
 int launch_split_bf16(const float* src, unsigned short* p0, unsigned short* p1, unsigned short* p2, int64_t n_elems, hipStream_t s);

@@ -69,7 +69,7 @@ __device__ __forceinline__ f32x4 split_mma(const mfma_bf16x8& w, const mfma_bf16
 // compared with tau[q] * sq * sd (a power of two: exact); a survivor's key carries U = U' / (sq sd).
 template <bool UB, int NB, int MB>
 __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&acc)[NB][MB], int64_t row0, int q0, int wn, int wm,
-                                               int frow, int fg, const float* xy_s, const float* qa_s) {
+                                               int frow, int fg, const float* xy_s, const float* qa_s, const float* tau_s) {
 #pragma clang fp contract(off)
     // the workgroup is persistent: without this hipcc hoists the 32 per-register row indices, id offsets and slots of this
     // epilogue out of the tile loop and carries (spills) them through the k-loop
@@ -95,65 +95,84 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
                     acc[i][j][r] = __builtin_fmaf(qa[j][0], x[r], __builtin_fmaf(qa[j][1], y[r], acc[i][j][r]));
         }
     }
-    // Survivors: the four queries of a lane are counted first and their four slot reservations (one atomic each) are issued
-    // together - one memory round trip per tile instead of four in a row (the epilogue was 10 % of the pass, most of it
-    // waiting for those) - then the keys are stored.
+    // Survivors.  In-kernel stamps showed this epilogue at 10 us of a 60 us tile - not waiting for memory, but executing: a
+    // wave runs the per-element `if (score >= tau) store` code of a query (128 exec-masked micro-branches) whenever ANY of its
+    // 64 lanes keeps something, which is nearly always, although a wave keeps only a handful of documents per tile.  So: per
+    // (query j, block of 4 rows) one lane-local maximum and a WAVE-uniform skip; the few blocks that hold a survivor store it
+    // straight into the lane's own segment of the query's candidate buffer (common.h TopkWS: no atomic, no second pass), the
+    // count goes to seg_cnt.  A (lane, query) pair with more than SR_SEG_P survivors (the first launches of a search, before
+    // tau has risen) or a launch without segments takes the counted path behind one atomic reservation.
+    if (a.diag & 8) {                         // timing only: the error term alone
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 1.2345e-30f) a.cand_count[0] = 1;
+        return;
+    }
+    const int seg_idx = (int)((row0 - a.row_begin) / SP_BN) * SR_SEG_PROD + wn * 4 + fg;
+    const bool seg_ok = a.seg_cnt != nullptr && seg_idx < a.seg_n;
+    const bool full = rows_valid == SP_BN;
+    bool slow[MB];
     float tq[MB], out_scale[MB];
-    int cnt[MB], pos[MB];
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int q = q0 + wm * MB * 16 + j * 16 + frow;
-        tq[j] = q < a.nq ? a.tau[q] : INFINITY;          // a query beyond the batch keeps nothing
+        tq[j] = q < a.nq ? tau_s[wm * MB * 16 + j * 16 + frow] : INFINITY;          // a query beyond the batch keeps nothing
         out_scale[j] = 1.f;
         if constexpr (UB) {
             tq[j] = tq[j] * (qa[j][2] * a.sd);           // scaled-domain threshold (-inf stays -inf)
             out_scale[j] = qa[j][3] * a.isd;
         }
-    }
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        // the largest of the lane's 32 values first: most (lane, query) pairs keep nothing once tau has risen
-        float mx = -INFINITY;
+        uint64_t* seg_dst = a.cand_keys + (int64_t)q * a.cand_cap + a.seg_off + (int64_t)seg_idx * SR_SEG_P;
+        int n = 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int lr0 = wn * NB * 16 + i * 16 + fg * 4;
-            if (lr0 + 3 < rows_valid) {
-                mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
-            } else {
+            float m4 = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
+            if (!full) {
+                m4 = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (lr0 + r < rows_valid) mx = fmaxf(mx, acc[i][j][r]);
+                    if (lr0 + r < rows_valid) m4 = fmaxf(m4, acc[i][j][r]);
+            }
+            if (__ballot(m4 >= tq[j]) == 0) continue;                  // wave-uniform: nobody keeps anything of this block
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = acc[i][j][r];
+                if (lr0 + r < rows_valid && sc >= tq[j]) {
+                    if (seg_ok && n < SR_SEG_P) seg_dst[n] = sr_make_key(UB ? sc * out_scale[j] : sc, gid0 + (uint32_t)(lr0 + r) * a.id_stride);
+                    ++n;
+                }
             }
         }
-        cnt[j] = 0;
-        if (mx >= tq[j]) {
+        slow[j] = n > 0 && (!seg_ok || n > SR_SEG_P);
+        if (n > 0 && !slow[j]) a.seg_cnt[(int64_t)q * a.seg_n + seg_idx] = (unsigned char)n;
+    }
+    if (a.diag & 4) return;                  // timing only: the counted path skipped
+    bool any_slow = false;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) any_slow = any_slow || slow[j];
+    if (__ballot(any_slow) == 0) return;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        if (__ballot(slow[j]) == 0) continue;
+        const int q = q0 + wm * MB * 16 + j * 16 + frow;
+        int cnt = 0;
+        if (slow[j]) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
-                    cnt[j] += (lr < rows_valid && acc[i][j][r] >= tq[j]) ? 1 : 0;
+                    cnt += (lr < rows_valid && acc[i][j][r] >= tq[j]) ? 1 : 0;
                 }
         }
-    }
-    if (a.diag & 4) {                        // timing only: counted, nothing reserved or stored
-        int t = 0;
-#pragma unroll
-        for (int j = 0; j < MB; ++j) t += cnt[j];
-        if (t == 0x7fffffff) a.cand_count[0] = t;
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        const int q = q0 + wm * MB * 16 + j * 16 + frow;
-        pos[j] = cnt[j] ? atomicAdd(&a.cand_count[q], cnt[j]) : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        if (cnt[j] == 0) continue;
-        const int q = q0 + wm * MB * 16 + j * 16 + frow;
+        if (cnt == 0) continue;
+        int p = atomicAdd(&a.cand_count[q], cnt);
         uint64_t* dst = a.cand_keys + (int64_t)q * a.cand_cap;
-        int p = pos[j];
+        const int64_t limit = a.seg_off > 0 ? a.seg_off : a.cand_cap;          // the atomically appended candidates stay in the head
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -161,7 +180,7 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
                 const int lr = wn * NB * 16 + i * 16 + fg * 4 + r;
                 const float sc = acc[i][j][r];
                 if (lr < rows_valid && sc >= tq[j]) {
-                    if (p < a.cand_cap) dst[p] = sr_make_key(UB ? sc * out_scale[j] : sc, gid0 + (uint32_t)lr * a.id_stride);
+                    if (p < limit) dst[p] = sr_make_key(UB ? sc * out_scale[j] : sc, gid0 + (uint32_t)lr * a.id_stride);
                     ++p;
                 }
             }
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* xy_s = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);       // UB: (x, y) of the tile's 256 documents
     float* qa_s = xy_s + 2 * SP_BN;                                        // UB: (A', B', sq, 1 / sq) of the tile's 256 queries
+    float* tau_s = qa_s + 4 * SP_BM;                                       // tau of the tile's 256 queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WAVES_M, wm = wave % WAVES_M;
     const int G = (int)gridDim.x;
@@ -314,6 +334,12 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         // the barrier also ends the previous tile's epilogue reads of xy_s
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const unsigned long long st0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (wave >= 4) {      // tau of the tile's queries: one 4-byte LDS-DMA piece per lane of waves 4-7 (no wait in the epilogue)
+            int q = q0 + (wave - 4) * 64 + lane;
+            q = q < a.nq ? q : a.nq - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.tau + q), (lds_void_ptr)(tau_s + (wave - 4) * 64), 4, 0, 0);
+        }
         if constexpr (UB) {
             // the tile's per-document (x, y): 512 floats, 64 per wave, one 4-byte LDS-DMA piece per lane, and its per-query
             // constants: 256 x 16 bytes, one 16-byte piece per lane of waves 0-3; they land under the k-loop (every k-step
@@ -391,7 +417,19 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             SR_MFMA_HALF(1, wy, a1)
             buf ^= 1;
         }
-        split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s);
+        const unsigned long long st1 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+        split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s, tau_s);
+        if (a.stamps) {          // dev switch SR_SPLIT_STAMPS: 10 ns ticks per tile of wave 0: k-loop, epilogue issue, wait at the next tile's top
+            const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                atomicAdd(&a.stamps[0], st1 - st0);
+                atomicAdd(&a.stamps[1], st2 - st1);
+                atomicAdd(&a.stamps[2], st3 - st2);
+                atomicAdd(&a.stamps[3], 1ull);
+            }
+        }
         if (!has_next) break;
         tile = tile_next;
     }
@@ -404,7 +442,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     SR_REQUIRE(a.H % 64 == 0, "dense_split: dim %d must be a multiple of 64", a.H);
     SR_REQUIRE(a.n_pairs >= 1 && a.n_pairs <= 6 && a.n_pairs * (a.H / 64) >= 2, "dense_split: bad plane-pair count %d", a.n_pairs);
     SR_REQUIRE(!a.upper_bound || (a.n_pairs == 1 && a.dxy && a.qa), "dense_split: the upper-bound pass is one plane product");
-    constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128 + SP_BN * 2 * sizeof(float) + SP_BM * 4 * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(SP_BN + SP_BM) * 128 + SP_BN * 2 * sizeof(float) + SP_BM * 4 * sizeof(float) + SP_BM * sizeof(float);
     static DeviceOnce attr_once;
     bool* attr_slot = attr_once.pending();
     if (attr_slot) {
@@ -419,6 +457,20 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
     b.diag = 0;
     if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only: wrong results
+    b.stamps = nullptr;
+    if (sr_dev_getenv("SR_SPLIT_STAMPS")) {
+        static unsigned long long* d_st = nullptr;
+        static int calls = 0;
+        if (!d_st) { SR_CHECK_HIP(hipMalloc((void**)&d_st, 32)); SR_CHECK_HIP(hipMemset(d_st, 0, 32)); }
+        if (++calls % 272 == 0) {
+            unsigned long long h[4];
+            SR_CHECK_HIP(hipMemcpy(h, d_st, 32, hipMemcpyDeviceToHost));
+            if (h[3]) fprintf(stderr, "[split stamps] tiles %llu: k-loop %.2f us, epilogue issue %.2f us, drain wait %.2f us\n", h[3],
+                              h[0] * 0.01 / h[3], h[1] * 0.01 / h[3], h[2] * 0.01 / h[3]);
+            SR_CHECK_HIP(hipMemset(d_st, 0, 32));
+        }
+        b.stamps = d_st;
+    }
     const SplitGrid sg = split_grid(rows, a.nq, b.xcd_order);
     b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq; b.grid_total = sg.total;
     // one persistent workgroup per CU (130 KB of LDS each); SR_SPLIT_PERSIST=0: one workgroup per tile slot (A/B)

@@ -31,7 +31,8 @@ __global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, i
 // One workgroup (256 threads) per query.  run_keys has 2k slots per query.
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
-                                                           int* __restrict__ cand_count, int k, int64_t cand_cap) {
+                                                           int* __restrict__ cand_count, int k, int64_t cand_cap,
+                                                           unsigned char* __restrict__ seg_cnt, int seg_n, int64_t seg_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int* hist = reinterpret_cast<int*>(smem_raw);          // [256]
     int* scan = hist + 256;                                 // [256]
@@ -41,6 +42,37 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
 
     const int q = blockIdx.x, tid = threadIdx.x;
     int nc = cand_count[q];
+    if (seg_cnt) {
+        // segmented slots (common.h): append every segment's survivors behind the nc atomically appended candidates and
+        // clear the counts for the next launch.  Sources (the buffer's tail) and destinations (its head) are disjoint.
+        uint64_t* cbuf = cand_keys + (int64_t)q * cand_cap;
+        uint32_t* cw = reinterpret_cast<uint32_t*>(seg_cnt + (int64_t)q * seg_n);      // seg_n is a multiple of 4
+        for (int w0 = 0; w0 < seg_n / 4; w0 += 256) {
+            const int wi = w0 + tid;
+            const uint32_t word = wi < seg_n / 4 ? cw[wi] : 0u;
+            const int c[4] = {(int)(word & 255u), (int)((word >> 8) & 255u), (int)((word >> 16) & 255u), (int)(word >> 24)};
+            const int mine = c[0] + c[1] + c[2] + c[3];
+            // workgroup exclusive prefix of `mine`
+            int v = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(v, off);
+                if ((tid & 63) >= off) v += o;
+            }
+            __syncthreads();
+            if ((tid & 63) == 63) hist[tid >> 6] = v;
+            __syncthreads();
+            int base = nc + v - mine;
+            for (int w = 0; w < (tid >> 6); ++w) base += hist[w];
+            const int total = hist[0] + hist[1] + hist[2] + hist[3];
+            if (mine) {
+                for (int e = 0; e < 4; ++e)
+                    for (int n = 0; n < c[e]; ++n) cbuf[base++] = cbuf[seg_off + ((int64_t)wi * 4 + e) * SR_SEG_P + n];
+                cw[wi] = 0u;
+            }
+            nc += total;
+        }
+        __syncthreads();
+    }
     if (nc == 0) return;
     if ((int64_t)nc > cand_cap) nc = (int)cand_cap;  // unreachable by construction (cap >= docs per chunk)
     const int nr = run_count[q];
@@ -222,8 +254,20 @@ static int next_pow2(int v) {
     return p;
 }
 
+int TopkWS::ensure_segments(int64_t nq, int kk, int64_t dense_cap, int sn) {
+    // (re)allocated whenever the shape differs: the segment geometry is part of the kernels' addressing
+    if (nq <= nq_cap && kk <= k && seg_n == sn && seg_off == dense_cap && seg_cnt) return SR_OK;
+    release();
+    SR_TRY(ensure(nq, kk, dense_cap + (int64_t)sn * SR_SEG_P));
+    SR_CHECK_HIP(hipMalloc(&seg_cnt, (size_t)nq * (size_t)sn));
+    SR_CHECK_HIP(hipMemset(seg_cnt, 0, (size_t)nq * (size_t)sn));
+    seg_n = sn;
+    seg_off = dense_cap;
+    return SR_OK;
+}
+
 int TopkWS::ensure(int64_t nq, int kk, int64_t cc) {
-    if (nq <= nq_cap && kk <= k && cc <= cand_cap) return SR_OK;
+    if (nq <= nq_cap && kk <= k && cc <= cand_cap && seg_n == 0) return SR_OK;
     release();
     nq_cap = nq;
     k = kk;
@@ -242,6 +286,10 @@ void TopkWS::release() {
     if (tau) (void)hipFree(tau);
     if (cand_keys) (void)hipFree(cand_keys);
     if (cand_count) (void)hipFree(cand_count);
+    if (seg_cnt) (void)hipFree(seg_cnt);
+    seg_cnt = nullptr;
+    seg_n = 0;
+    seg_off = 0;
     run_keys = cand_keys = nullptr;
     run_count = cand_count = nullptr;
     tau = nullptr;
@@ -264,7 +312,7 @@ int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
     if (nq == 0) return SR_OK;
     const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
-                       ws.cand_keys, ws.cand_count, k, ws.cand_cap);
+                       ws.cand_keys, ws.cand_count, k, ws.cand_cap, ws.seg_n > 0 ? ws.seg_cnt : (unsigned char*)nullptr, ws.seg_n, ws.seg_off);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
