@@ -589,6 +589,20 @@ def main():
         index.set_precision("fp32_filtered")
         fs, fi = index.search(reps_b, args.topk)
         same = bool(torch.equal(es, fs) and torch.equal(ei, fi))
+        if not same:          # say what differs before the run aborts
+            bad = (~((fs == es).all(1) & (fi == ei).all(1))).nonzero()[:, 0]
+            log(f"[parity] {bad.numel()} queries differ: {bad.tolist()[:16]}; stats {index.filter_stats()} {index.filter_query_stats()}")
+            for q_ in bad.tolist()[:4]:
+                d_ = ((fs[q_] != es[q_]) | (fi[q_] != ei[q_])).nonzero()[:, 0]
+                j_ = int(d_[0])
+                log(f"   q {q_}: first diff at rank {j_} of {d_.numel()}: filtered ({float(fs[q_, j_])}, {int(fi[q_, j_])}) exact ({float(es[q_, j_])}, {int(ei[q_, j_])}); "
+                    f"exact id in the filtered list: {bool((fi[q_] == ei[q_, j_]).any())}; filtered id in the exact list: {bool((ei[q_] == fi[q_, j_]).any())}")
+            fs2, fi2 = index.search(reps_b, args.topk)
+            log(f"   second filtered search equals exact: {bool(torch.equal(es, fs2) and torch.equal(ei, fi2))}; equals the first filtered: {bool(torch.equal(fs, fs2) and torch.equal(fi, fi2))}")
+            index.set_precision("fp32")
+            es2, ei2 = index.search(reps_b, args.topk)
+            index.set_precision("fp32_filtered")
+            log(f"   second exact search equals the first exact: {bool(torch.equal(es, es2) and torch.equal(ei, ei2))}; equals the first filtered: {bool(torch.equal(fs, es2) and torch.equal(fi, ei2))}")
         parity = (f"filter + exact re-score vs exact fp32 kernel on this run's {args.n_queries} x {n_local} problem: ids and fp32 scores "
                   + ("bit-identical" if same else "DIFFER"))
         assert same, parity
@@ -693,6 +707,21 @@ def main():
             fi_i.add_device_rows(D)
             fs, fi = fi_i.search(Qr, args.topk)
             same = bool(torch.equal(es, fs) and torch.equal(ei, fi))
+            if not same:
+                bad = (~((fs == es).all(1) & (fi == ei).all(1))).nonzero()[:, 0]
+                log(f"[filter_robustness] {corpus}/{queries}: {bad.numel()} queries differ: {bad.tolist()[:16]}; stats {fi_i.filter_stats()} {fi_i.filter_query_stats()}")
+                for q_ in bad.tolist()[:4]:
+                    d_ = ((fs[q_] != es[q_]) | (fi[q_] != ei[q_])).nonzero()[:, 0]
+                    j_ = int(d_[0])
+                    log(f"   q {q_}: first diff at rank {j_} of {d_.numel()}: filtered ({float(fs[q_, j_])}, {int(fi[q_, j_])}) exact ({float(es[q_, j_])}, {int(ei[q_, j_])}); "
+                        f"exact id in the filtered list: {bool((fi[q_] == ei[q_, j_]).any())}; filtered id in the exact list: {bool((ei[q_] == fi[q_, j_]).any())}")
+                fs2, fi2 = fi_i.search(Qr, args.topk)
+                log(f"   second filtered search equals exact: {bool(torch.equal(es, fs2) and torch.equal(ei, fi2))}; equals the first filtered: {bool(torch.equal(fs, fs2) and torch.equal(fi, fi2))}")
+                ex2 = DenseIndexHIP(H, device=device)
+                ex2.add_device_rows(D)
+                es2, ei2 = ex2.search(Qr, args.topk)
+                log(f"   second exact search equals the first exact: {bool(torch.equal(es, es2) and torch.equal(ei, ei2))}; equals the filtered: {bool(torch.equal(fs, es2) and torch.equal(fi, ei2))}")
+                ex2.close()
             assert same, f"filter_robustness {corpus}/{queries}: results differ from the exact kernel"
             c0, r0_ = fi_i.filter_query_stats()
             torch.cuda.synchronize()

@@ -28,7 +28,21 @@ static inline const char* sr_dev_getenv(const char* name) {
         }                                                                                    \
     } while (0)
 
-#define SR_CHECK_LAUNCH() SR_CHECK_HIP(hipGetLastError())
+// dev switch SR_DEBUG_SYNC=1: every launch is named on stderr and waited for, so that a GPU memory fault (which aborts the
+// process without saying where) is attributed to the last line printed
+static inline bool sr_debug_sync() {
+    static const bool on = [] { const char* e = sr_dev_getenv("SR_DEBUG_SYNC"); return e && atoi(e) != 0; }();
+    return on;
+}
+#define SR_CHECK_LAUNCH()                                                        \
+    do {                                                                         \
+        SR_CHECK_HIP(hipGetLastError());                                         \
+        if (sr_debug_sync()) {                                                   \
+            fprintf(stderr, "[launch] %s:%d\n", __FILE__, __LINE__);             \
+            fflush(stderr);                                                      \
+            SR_CHECK_HIP(hipDeviceSynchronize());                                \
+        }                                                                        \
+    } while (0)
 
 #define SR_REQUIRE(cond, ...)            \
     do {                                 \

@@ -27,12 +27,56 @@ __global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, i
     }
 }
 
+// ---------------------------------------------------------- segment gather ---
+// Segmented candidate slots (common.h TopkWS): one workgroup per query appends every segment's survivors behind the nc
+// atomically appended candidates, updates cand_count and clears the segment counts for the next launch.  Sources (the
+// buffer's tail) and destinations (its head) are disjoint.  A kernel of its own, launched in front of topk_compact_kernel:
+// folded into that kernel (round 3, first version) the compaction produced wrong results and out-of-range writes once in a
+// few hundred launches EVEN with the segment code switched off (same source lines, executed or not: a code generation
+// problem this round could not pin down; tools/micro/exact_stress_plain.py with SR_COMPACT_SEGKERNEL was the A/B) - the
+// compaction kernel is therefore byte for byte round 2's.
+__global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
+                                                                   int64_t cand_cap, unsigned char* __restrict__ seg_cnt, int seg_n,
+                                                                   int64_t seg_off) {
+    __shared__ int wave_tot[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int nc = cand_count[q];
+    uint64_t* cbuf = cand_keys + (int64_t)q * cand_cap;
+    uint32_t* cw = reinterpret_cast<uint32_t*>(seg_cnt + (int64_t)q * seg_n);      // seg_n is a multiple of 4
+    for (int w0 = 0; w0 < seg_n / 4; w0 += 256) {
+        const int wi = w0 + tid;
+        const uint32_t word = wi < seg_n / 4 ? cw[wi] : 0u;
+        const int c[4] = {(int)(word & 255u), (int)((word >> 8) & 255u), (int)((word >> 16) & 255u), (int)(word >> 24)};
+        const int mine = c[0] + c[1] + c[2] + c[3];
+        int v = mine;                               // inclusive prefix inside the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if ((tid & 63) >= off) v += o;
+        }
+        __syncthreads();                            // the previous round's totals have been read
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
+        __syncthreads();
+        int base = nc + v - mine;
+        for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (mine) {
+            for (int e = 0; e < 4; ++e)
+                for (int n = 0; n < c[e]; ++n) {
+                    if (base < seg_off) cbuf[base] = cbuf[seg_off + ((int64_t)wi * 4 + e) * SR_SEG_P + n];
+                    ++base;
+                }
+            cw[wi] = 0u;
+        }
+        nc += total;
+    }
+    if (tid == 0) cand_count[q] = nc < seg_off ? nc : (int)seg_off;
+}
+
 // ---------------------------------------------------------------- compact ---
 // One workgroup (256 threads) per query.  run_keys has 2k slots per query.
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
-                                                           int* __restrict__ cand_count, int k, int64_t cand_cap,
-                                                           unsigned char* __restrict__ seg_cnt, int seg_n, int64_t seg_off) {
+                                                           int* __restrict__ cand_count, int k, int64_t cand_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int* hist = reinterpret_cast<int*>(smem_raw);          // [256]
     int* scan = hist + 256;                                 // [256]
@@ -42,37 +86,6 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
 
     const int q = blockIdx.x, tid = threadIdx.x;
     int nc = cand_count[q];
-    if (seg_cnt) {
-        // segmented slots (common.h): append every segment's survivors behind the nc atomically appended candidates and
-        // clear the counts for the next launch.  Sources (the buffer's tail) and destinations (its head) are disjoint.
-        uint64_t* cbuf = cand_keys + (int64_t)q * cand_cap;
-        uint32_t* cw = reinterpret_cast<uint32_t*>(seg_cnt + (int64_t)q * seg_n);      // seg_n is a multiple of 4
-        for (int w0 = 0; w0 < seg_n / 4; w0 += 256) {
-            const int wi = w0 + tid;
-            const uint32_t word = wi < seg_n / 4 ? cw[wi] : 0u;
-            const int c[4] = {(int)(word & 255u), (int)((word >> 8) & 255u), (int)((word >> 16) & 255u), (int)(word >> 24)};
-            const int mine = c[0] + c[1] + c[2] + c[3];
-            // workgroup exclusive prefix of `mine`
-            int v = mine;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(v, off);
-                if ((tid & 63) >= off) v += o;
-            }
-            __syncthreads();
-            if ((tid & 63) == 63) hist[tid >> 6] = v;
-            __syncthreads();
-            int base = nc + v - mine;
-            for (int w = 0; w < (tid >> 6); ++w) base += hist[w];
-            const int total = hist[0] + hist[1] + hist[2] + hist[3];
-            if (mine) {
-                for (int e = 0; e < 4; ++e)
-                    for (int n = 0; n < c[e]; ++n) cbuf[base++] = cbuf[seg_off + ((int64_t)wi * 4 + e) * SR_SEG_P + n];
-                cw[wi] = 0u;
-            }
-            nc += total;
-        }
-        __syncthreads();
-    }
     if (nc == 0) return;
     if ((int64_t)nc > cand_cap) nc = (int)cand_cap;  // unreachable by construction (cap >= docs per chunk)
     const int nr = run_count[q];
@@ -311,8 +324,13 @@ int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s) {
 int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
     if (nq == 0) return SR_OK;
     const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
+    if (ws.seg_n > 0) {
+        hipLaunchKernelGGL(topk_gather_segments_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.cand_keys, ws.cand_count, ws.cand_cap,
+                           ws.seg_cnt, ws.seg_n, ws.seg_off);
+        SR_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
-                       ws.cand_keys, ws.cand_count, k, ws.cand_cap, ws.seg_n > 0 ? ws.seg_cnt : (unsigned char*)nullptr, ws.seg_n, ws.seg_off);
+                       ws.cand_keys, ws.cand_count, k, ws.cand_cap);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -1,0 +1,35 @@
+import os, sys
+import torch
+import subprocess
+print('host', os.uname().nodename, '|', subprocess.run('rocm-smi --showserial --showuniqueid 2>/dev/null | grep -i "serial\\|unique" | head -4', shell=True, capture_output=True, text=True).stdout.replace(chr(10), ' ; '), flush=True)
+HERE = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, HERE)
+from scaling_retriever_amd.scoring import DenseIndexHIP
+import scaling_retriever_amd._lib as L
+print("lib:", L.LIB_PATH, flush=True)
+dev = torch.device("cuda", 0)
+N, H, k, nq = int(os.environ.get('N_DOCS', '8841823')), 2048, 1000, 6980
+g = torch.Generator(device=dev).manual_seed(1)
+D = torch.empty((N, H), dtype=torch.float32, device=dev)
+for r0 in range(0, N, 1 << 20):
+    D[r0:r0 + (1 << 20)].normal_(0.0, 0.5 / H ** 0.5, generator=g)
+Q = torch.empty((nq, H), dtype=torch.float32, device=dev).normal_(0.0, 0.5 / H ** 0.5, generator=g)
+Dsum0 = [D[r0:r0 + (1 << 20)].double().sum().item() for r0 in range(0, N, 1 << 20)]
+Qsum0 = Q.double().sum().item()
+index = DenseIndexHIP(H, device=dev)
+index.add_device_rows(D)
+ref = None
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
+    s, i = index.search(Q, k)
+    if ref is None:
+        ref = (s.clone(), i.clone())
+    elif not (torch.equal(s, ref[0]) and torch.equal(i, ref[1])):
+        bad = (~((s == ref[0]).all(1) & (i == ref[1]).all(1))).nonzero()[:, 0]
+        print("iteration", it, ":", bad.numel(), "queries differ", bad.tolist()[:10], flush=True)
+Dsum1 = [D[r0:r0 + (1 << 20)].double().sum().item() for r0 in range(0, N, 1 << 20)]
+print("done; 1M-row blocks of D that changed:", [b for b in range(len(Dsum0)) if Dsum0[b] != Dsum1[b]], "| Q unchanged:", Q.double().sum().item() == Qsum0, flush=True)
+import ctypes
+out = (ctypes.c_uint64 * 2)()
+if hasattr(L.load(), "sr_debug_counters"):
+    L.load().sr_debug_counters(out)
+    print("compactions that met non-unique keys:", out[0], flush=True)

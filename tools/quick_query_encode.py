@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Query-encode time at Lion-DS-1B dims for the 6 980 synthetic Dev queries: bf16 regime vs the fp32 regime with 2 / 3
-bf16 planes, per query-batch size.  python tools/quick_query_encode.py [planes ...]"""
+"""Query-encode time at Lion-DS-1B dims for the 6 980 synthetic Dev queries: bf16 regime vs the fp32 regime, per query-batch
+size.  planes: 16 (default) = two fp16 planes of power-of-two scaled rows, 2 / 3 = bf16 planes.
+python tools/quick_query_encode.py [planes ...]"""
 import os
 import sys
 import time
@@ -14,7 +15,7 @@ from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense  # noqa: E40
 dev = torch.device("cuda", 0)
 cfg = dict(bench.LION_1B)
 w = bench.random_weights(cfg, dev, 0)
-for planes in [int(a) for a in sys.argv[1:]] or [3, 2]:
+for planes in [int(a) for a in sys.argv[1:]] or [16]:
     model = LlamaBiDense.from_weights(cfg, dict(w), max_batch_tokens=65536, max_batch_seqs=8192, fp32_planes=planes).to(dev).eval()
     for qb in (512, 2048, 6980):
         batches, lens = bench.synth_batches(6980, qb, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, dev)
