@@ -395,6 +395,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-kernel", action="store_true", help="headline through the exact fp32 MFMA kernel instead of the certified filter")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 / bf16x6 precision-mode measurements")
+    ap.add_argument("--no-shard-leg", action="store_true", help="skip the shard_1of8 leg (one of 8 doc shards with the threshold exchange)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the filter_robustness legs (anisotropic / near-duplicate corpora at full shape)")
     args = ap.parse_args()
 
@@ -417,7 +418,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
 
     from scaling_retriever_amd import _lib
-    from scaling_retriever_amd.distributed import all_gather_query_reps, gather_topk, query_slice, shard_size
+    from scaling_retriever_amd.distributed import all_gather_query_reps, gather_topk, query_slice, shard_size, sharded_dense_search
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     from scaling_retriever_amd.scoring import DenseIndexHIP, topk_merge
     lib = _lib.load()
@@ -454,7 +455,7 @@ def main():
 
     def step():
         reps = encode_queries()
-        s, i = index.search(reps, args.topk)
+        s, i = sharded_dense_search(index, reps, args.topk, world)      # world > 1: + one all-reduce(min) of nq floats
         if world > 1:
             gs, gi = gather_topk(s, i, dst=0)
             if gs is not None:
@@ -583,6 +584,7 @@ def main():
     # ---- the same step through the exact fp32 MFMA kernel (what the filter must reproduce), and the proof on THIS run's data ----
     exact_mode = None
     parity = None
+    parity_ref = None
     if filtered:
         index.set_precision("fp32")
         es, ei = index.search(reps_b, args.topk)
@@ -606,7 +608,8 @@ def main():
         parity = (f"filter + exact re-score vs exact fp32 kernel on this run's {args.n_queries} x {n_local} problem: ids and fp32 scores "
                   + ("bit-identical" if same else "DIFFER"))
         assert same, parity
-        del es, ei, fs, fi
+        parity_ref = (es, ei)
+        del fs, fi
         exact_mode = timed_mode("fp32", 1, "every one of the nq x N products on the fp32 MFMA pipe (dense_score_pipe_kernel); the filtered "
                                 "headline returns the same bits")
         if exact_mode and "roofline" in exact_mode:
@@ -639,10 +642,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import scoring as SC
-        ns, nqs = min(n_local, 2_400_000), min(args.n_queries, 2048)   # 10-20 s of host work on the GPU box
+        ns, nqs = min(n_local, 2_400_000), min(args.n_queries, 2048)   # ~10 s of host work on the GPU box
         Dh = D[:ns].cpu().numpy()
         Qh = encode_queries()[:nqs].cpu().numpy()
-        torch.set_num_threads(os.cpu_count() or 1)
         SC.flat_ip_search_blas_heap(Qh[:256], Dh[:65536], min(args.topk, 1000))       # warm-up: BLAS thread pool, page faults
         st = {}
         tc = time.perf_counter()
@@ -654,11 +656,11 @@ def main():
         except Exception:
             host = "unknown"
         cpu = {"value": round(qps_full, 3), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port", "host_cpu": host,
-               "threads": torch.get_num_threads(), "sgemm_gflops": round(st["sgemm_gflops"], 1),
+               "threads": st["threads"], "sgemm_gflops": round(st["sgemm_gflops"], 1),
                "sgemm_s": round(st["sgemm_s"], 2), "heap_s": round(st["heap_s"], 2),
                "sample": f"scoring stage only (oracle.scoring.flat_ip_search_blas_heap = faiss IndexFlatIP.search as faiss-cpu runs it: "
-                         f"host BLAS sgemm over (query block, database block) pairs through torch.mm on all cores + one heap per query in "
-                         f"C / OpenMP, oracle/score_cpu.c): {nqs} queries x {ns} docs x {H}, top-{args.topk}, took {tc:.2f}s; "
+                         f"host BLAS (OpenBLAS behind numpy) sgemm over (query block, database block) pairs, with the thread count that measured "
+                         f"the best sgemm rate on this host ({st['threads']} of {os.cpu_count()} hardware threads), + one heap per query in C / OpenMP, oracle/score_cpu.c): {nqs} queries x {ns} docs x {H}, top-{args.topk}, took {tc:.2f}s; "
                          f"extrapolated linearly to {args.n_docs} docs; query encoding not included"}
         del Dh, cs, ci
 
@@ -687,11 +689,64 @@ def main():
     # ---- the certified filter on corpora shaped like real embeddings (full shape, search stage only): the headline's data is
     #      isotropic Gaussian with near-constant norms; real LlamaBiDense vectors are anisotropic, their norms spread, and MS MARCO
     #      holds near-duplicate passages.  Every leg is compared with the exact kernel on all queries. ----
+    # ---- BASELINE.json configs[3] on one GPU: what ONE of 8 doc shards does per search, with and without the threshold exchange
+    #      (sr_dense_search_begin / _finish: every shard re-scores only what can reach the global top-k) ----
+    shard_leg = None
+    if filtered and world == 1 and not args.no_shard_leg:
+        from scaling_retriever_amd.scoring import topk_merge
+        index.close()
+        index = None
+        W8 = 8
+        per = (n_local + W8 - 1) // W8
+        shards = []
+        for r_ in range(W8):
+            ix = DenseIndexHIP(H, device=device)
+            ix.set_precision("fp32_filtered")
+            ix.add_device_rows(D[r_ * per:min(n_local, (r_ + 1) * per)], id_base=r_ * per, id_stride=1)
+            shards.append(ix)
+        lowers = torch.stack([ix.search_begin(reps_b, args.topk, W8) for ix in shards])
+        thr_g = lowers.min(0).values
+        outs = [ix.search_finish(reps_b, args.topk, thr_g) for ix in shards]
+        ms_, mi_ = topk_merge(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]))
+        merged_ok = None
+        if parity_ref is not None:
+            merged_ok = bool(torch.equal(ms_, parity_ref[0]) and torch.equal(mi_, parity_ref[1]))
+            assert merged_ok, "shard_1of8: the merge of the 8 shard results differs from the single index"
+        kept = float(torch.stack([(o[1] >= 0).sum(1) for o in outs]).float().mean())
+
+        def t_of(fn, n=3):
+            fn()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / n
+        t_plain = t_of(lambda: shards[0].search(reps_b, args.topk))
+        t_begin = t_of(lambda: shards[0].search_begin(reps_b, args.topk, W8))
+
+        def both():
+            shards[0].search_begin(reps_b, args.topk, W8)
+            shards[0].search_finish(reps_b, args.topk, thr_g)
+        t_both = t_of(both)
+        shard_leg = {"workload": f"one of 8 doc shards ({per} x {H}) of the headline corpus, {args.n_queries} queries, top-{args.topk}",
+                     "search_ms_plain": round(t_plain * 1e3, 1), "search_ms_with_threshold_exchange": round(t_both * 1e3, 1),
+                     "of_which_candidates_pass_ms": round(t_begin * 1e3, 1),
+                     "mean_candidates_returned_per_query_and_shard": round(kept, 1),
+                     "merge_of_8_shards_equals_single_index": merged_ok,
+                     "note": "the all-reduce(min) of nq floats between the two halves is not in these times (one GPU here); "
+                             "scaling over RCCL stays unmeasured on this pool"}
+        log("[shard_1of8]", shard_leg)
+        for ix in shards:
+            ix.close()
+        del shards, outs, lowers
+
     robustness = None
     if filtered and world == 1 and not args.no_robustness:
         import synth
         robustness = []
-        index.close()
+        if index is not None:
+            index.close()
         for corpus, queries in (("aniso", "aniso"), ("aniso_dup", "aniso"), ("aniso_dup", "near_docs")):
             if not robustness or robustness[-1]["corpus"] != corpus:
                 del D
@@ -783,7 +838,7 @@ def main():
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "exact_kernel_mode": exact_mode, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,
-            "filter_robustness": robustness, "encode": encode, "sparse": sparse, "config5_8b": config5,
+            "shard_1of8": shard_leg, "filter_robustness": robustness, "encode": encode, "sparse": sparse, "config5_8b": config5,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -168,7 +168,7 @@ class LocalFaissDenseRetriever(DenseRetriever):
 def retrieval(args):
     from scaling_retriever_amd.dataset.data_collator import LlamaDenseCollectionCollator
     from scaling_retriever_amd.dataset.dataset import MSMARCOQueryDataset
-    from scaling_retriever_amd.distributed import gather_topk
+    from scaling_retriever_amd.distributed import gather_topk, sharded_dense_search
     from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
     from scaling_retriever_amd.scoring import DenseIndexHIP, topk_merge
     from scaling_retriever_amd.utils.utils import obtain_doc_vec_dir_files
@@ -200,7 +200,7 @@ def retrieval(args):
     for fi in range(rank, len(vec_files), world):
         index.add_npy_file(vec_files[fi], id_base=int(offsets[fi]))        # mmap -> pinned ring -> async H2D
     q_reps, qids = generate_query_vecs(model, q_loader, device)
-    scores, idx = index.search(q_reps, args.top_k)
+    scores, idx = sharded_dense_search(index, q_reps, args.top_k, world)
     if world > 1:
         gs, gi = gather_topk(scores, idx, dst=0)
         if gs is not None:

@@ -84,6 +84,18 @@ int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int
  *                       without room for it, or for data that is not finite, the exact kernel is used.            */
 #define SR_PRECISION_FP32_FILTERED 3
 int sr_dense_index_set_precision(sr_dense_index* idx, int mode);
+/* Doc-sharded search in two halves (replaces nothing in the reference, which scores on ONE process: eval_dense.py:191; this
+ * is the multi-GPU row of SURVEY.md 8e).  Every rank calls _begin on its shard: d_lower [nq] receives, per query, a value that
+ * at least ceil(k / share) documents of THIS shard reach exactly (share = number of shards).  The minimum of d_lower over the
+ * shards (one small all-reduce) is therefore not above the global k-th exact score; every rank passes it to _finish as
+ * d_threshold and re-scores only the candidates that can reach the GLOBAL top-k (about k / share of them instead of k).  The
+ * shard's [nq, k] output then holds those (padding: score -FLT_MAX, id -1); sr_topk_merge of the shards' outputs is the global
+ * top-k, bit for bit what one index over all documents returns.  When the certified filter does not apply, d_lower is -inf and
+ * _finish is a plain sr_dense_search (d_threshold may be null).  Do not interleave other searches on the handle between the two. */
+int sr_dense_search_begin(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, int share,
+                          float* d_lower, sr_stream stream);
+int sr_dense_search_finish(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, const float* d_threshold,
+                           float* d_out_scores, int64_t* d_out_ids, sr_stream stream);
 /* searches of more than 64 queries answered by the filter alone / with some (or all) queries re-done by the exact kernel */
 int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback);
 /* the same per query: queries certified by the filter / re-done by the exact kernel so far */

@@ -163,9 +163,9 @@ void oracle_topk_rows(const float* S, int64_t Nq, int64_t N, int k, float* out_s
  * query fed from the block's score rows (HeapBlockResultHandler: a score enters when it beats the heap's worst).  The sgemm
  * is the host BLAS (called from oracle/scoring.py); this is the heap side, one OpenMP thread per query row.
  * heaps: [Nq, k] cand_t min-heaps on (score, then higher doc index = worse), heap_n: [Nq] fill counts. */
-void oracle_heap_block(const float* S, int64_t Nq, int64_t nb, int64_t ld, int64_t base, int k, void* heaps, int32_t* heap_n) {
+void oracle_heap_block(const float* S, int64_t Nq, int64_t nb, int64_t ld, int64_t base, int k, void* heaps, int32_t* heap_n, int threads) {
     cand_t* H = (cand_t*)heaps;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
     for (int64_t q = 0; q < Nq; ++q) {
         cand_t* h = H + q * (int64_t)k;
         int n = heap_n[q];

@@ -52,7 +52,7 @@ def clib():
         L.oracle_topk_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, f32p, i64p]
         L.oracle_heap_block.restype = None
         L.oracle_heap_block.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
-                                        ctypes.c_void_p, i32p]
+                                        ctypes.c_void_p, i32p, ctypes.c_int]
         L.oracle_heap_finish.restype = None
         L.oracle_heap_finish.argtypes = [ctypes.c_void_p, i32p, ctypes.c_int64, ctypes.c_int, f32p, i64p]
     return _LIB
@@ -141,42 +141,62 @@ def flat_ip_search(Q, D, k, block=65536):
     return out_s, out_i
 
 
-def flat_ip_search_blas_heap(Q, D, k, d_block=16384, q_block=4096, stats=None):
+def flat_ip_search_blas_heap(Q, D, k, d_block=16384, q_block=4096, stats=None, threads=None):
     """IndexFlatIP.search the way faiss-cpu runs it (knn_inner_product -> exhaustive_inner_product_blas; the reference calls
     it at /root/reference/scaling_retriever/indexer.py:210-214): sgemm over (query block, database block) pairs - the host
-    BLAS through torch.mm, all cores - and one heap per query fed from the block's scores (oracle/score_cpu.c, OpenMP over
-    queries).  faiss's own blocks are 4096 queries x 1024 vectors; 16 384 vectors per block here keep the threaded sgemm
-    efficient on a many-core host (to the baseline's advantage).  The cpu_baseline of bench.py.  stats (dict): receives the
-    seconds spent in sgemm and in the heaps."""
+    BLAS behind numpy (OpenBLAS), limited to `threads` threads - and one heap per query fed from the block's scores
+    (oracle/score_cpu.c, OpenMP over queries).  faiss's own blocks are 4096 queries x 1024 vectors; 16 384 vectors per block
+    here keep the threaded sgemm efficient on a many-core host (to the baseline's advantage).  threads=None: the thread count
+    with the best sgemm rate on this host among 16 / 32 / 64 / 128 / all (hyper-threaded 256-thread pools run the BLAS at a
+    tenth of its 32-thread rate on the GPU boxes).  The cpu_baseline of bench.py.  stats (dict): receives the seconds spent in
+    sgemm and in the heaps, the sgemm rate and the thread count."""
+    import os
     import time
-    import torch
+    from threadpoolctl import threadpool_limits
     L = clib()
-    Qt = torch.from_numpy(np.ascontiguousarray(Q, np.float32))
-    Dt = torch.from_numpy(np.ascontiguousarray(D, np.float32)) if isinstance(D, np.ndarray) else D
-    Nq, N = Qt.shape[0], Dt.shape[0]
+    Q = np.ascontiguousarray(Q, np.float32)
+    D = np.ascontiguousarray(D, np.float32)
+    Nq, N = Q.shape[0], D.shape[0]
+    H = Q.shape[1]
+    if threads is None:
+        cores = os.cpu_count() or 1
+        best, threads = 0.0, 1
+        pq, pd = Q[:min(Nq, 1024)], D[:min(N, d_block)]
+        for nt in sorted({t for t in (16, 32, 64, 128, cores) if t <= cores}):
+            with threadpool_limits(limits=nt):
+                pq @ pd.T
+                t0 = time.perf_counter()
+                pq @ pd.T
+                rate = 2.0 * pq.shape[0] * pd.shape[0] * H / (time.perf_counter() - t0)
+            if rate > best:
+                best, threads = rate, nt
     out_s = np.empty((Nq, k), np.float32)
     out_i = np.empty((Nq, k), np.int64)
     t_mm = t_heap = 0.0
-    for q0 in range(0, Nq, q_block):
-        Qb = Qt[q0:q0 + q_block]
-        nqb = Qb.shape[0]
-        heaps = np.zeros((nqb, k, 2), np.int64)          # cand_t = {float, int64}: 16 bytes
-        heap_n = np.zeros(nqb, np.int32)
-        S = torch.empty((nqb, d_block), dtype=torch.float32)
-        for b in range(0, N, d_block):
-            nb = min(d_block, N - b)
-            t0 = time.perf_counter()
-            torch.mm(Qb, Dt[b:b + nb].T, out=S[:, :nb])
-            t1 = time.perf_counter()
-            L.oracle_heap_block(ctypes.cast(S.data_ptr(), ctypes.POINTER(ctypes.c_float)), nqb, nb, d_block, b, k,
-                                ctypes.c_void_p(heaps.ctypes.data), _p(heap_n, ctypes.c_int32))
-            t2 = time.perf_counter()
-            t_mm += t1 - t0
-            t_heap += t2 - t1
-        L.oracle_heap_finish(ctypes.c_void_p(heaps.ctypes.data), _p(heap_n, ctypes.c_int32), nqb, k,
-                             _p(out_s[q0:q0 + nqb], ctypes.c_float), _p(out_i[q0:q0 + nqb], ctypes.c_int64))
+    with threadpool_limits(limits=threads):
+        for q0 in range(0, Nq, q_block):
+            Qb = Q[q0:q0 + q_block]
+            nqb = Qb.shape[0]
+            heaps = np.zeros((nqb, k, 2), np.int64)          # cand_t = {float, int64}: 16 bytes
+            heap_n = np.zeros(nqb, np.int32)
+            S = np.empty((nqb, d_block), dtype=np.float32)
+            for b in range(0, N, d_block):
+                nb = min(d_block, N - b)
+                t0 = time.perf_counter()
+                if nb == d_block:
+                    np.matmul(Qb, D[b:b + nb].T, out=S)
+                else:
+                    S[:, :nb] = Qb @ D[b:b + nb].T
+                t1 = time.perf_counter()
+                L.oracle_heap_block(_p(S, ctypes.c_float), nqb, nb, d_block, b, k, ctypes.c_void_p(heaps.ctypes.data),
+                                    _p(heap_n, ctypes.c_int32), int(threads))
+                t2 = time.perf_counter()
+                t_mm += t1 - t0
+                t_heap += t2 - t1
+            L.oracle_heap_finish(ctypes.c_void_p(heaps.ctypes.data), _p(heap_n, ctypes.c_int32), nqb, k,
+                                 _p(out_s[q0:q0 + nqb], ctypes.c_float), _p(out_i[q0:q0 + nqb], ctypes.c_int64))
     if stats is not None:
-        stats.update({"sgemm_s": t_mm, "heap_s": t_heap, "sgemm_gflops": 2.0 * Nq * N * Qt.shape[1] / max(t_mm, 1e-9) / 1e9})
+        stats.update({"sgemm_s": t_mm, "heap_s": t_heap, "sgemm_gflops": 2.0 * Nq * N * H / max(t_mm, 1e-9) / 1e9, "threads": int(threads)})
     return out_s, out_i
 
 

@@ -39,8 +39,12 @@ int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* pla
 // a flagged query is re-done by the exact kernel.
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
                           int64_t nq, int k, int kp, int H, uint64_t* cand_keys, int* cand_count, int64_t cand_cap, int* flags,
-                          unsigned int* xmin, hipStream_t s);
+                          unsigned int* xmin, const float* thr, hipStream_t s);
 int launch_filter_certify(const float* u_scores, const float* x_scores, const float* qa, int64_t nq, int k, int kp, int* flags,
-                          hipStream_t s);
+                          const float* thr, hipStream_t s);
+// doc-sharded search (sr_dense_search_begin): lower[q] = min over the j largest upper bounds of (U - 2e): at least j documents
+// of this index score >= lower[q] exactly.  thr (above, nullable): [nq] values not above the GLOBAL k-th exact score
+int launch_filter_lower_bound(const FilterSegs& segs, const float* u_scores, const int64_t* u_ids, const float* qa, int64_t nq, int kp,
+                              int j, float* lower, hipStream_t s);
 // rows of src [*, width] picked by idx [n] -> dst [n, width] (gather), or dst rows idx[i] <- src row i (scatter); 4-byte elements
 int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t width, void* dst, bool scatter, hipStream_t s);

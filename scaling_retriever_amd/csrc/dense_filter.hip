@@ -162,7 +162,8 @@ int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* pla
 }
 
 __global__ void filter_certify_kernel(const float* __restrict__ u_scores, const float* __restrict__ x_scores,
-                                      const float* __restrict__ qa, int64_t nq, int k, int kp, int* __restrict__ flags) {
+                                      const float* __restrict__ qa, int64_t nq, int k, int kp, int* __restrict__ flags,
+                                      const float* __restrict__ thr) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const float A = qa[q * 4], B = qa[q * 4 + 1];
@@ -172,14 +173,15 @@ __global__ void filter_certify_kernel(const float* __restrict__ u_scores, const 
     // stay strictly below the k-th exact score.  NaN / inf anywhere -> not certified.
     const bool finite = A < INFINITY && B < INFINITY;
     const bool all_docs = ukp <= -3.0e38f;
-    const bool ok = finite && (all_docs || (xk > -3.0e38f && ukp < xk));
+    // doc-sharded search: an outsider is also out if it lies strictly below thr <= the GLOBAL k-th exact score
+    const bool ok = finite && (all_docs || (xk > -3.0e38f && ukp < xk) || (thr && ukp < thr[q]));
     if (!ok) atomicOr(&flags[q], 1);
 }
 
 int launch_filter_certify(const float* u_scores, const float* x_scores, const float* qa, int64_t nq, int k, int kp, int* flags,
-                          hipStream_t s) {
+                          const float* thr, hipStream_t s) {
     hipLaunchKernelGGL(filter_certify_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, u_scores, x_scores, qa, nq, k, kp,
-                       flags);
+                       flags, thr);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
@@ -201,6 +203,51 @@ int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, in
     return SR_OK;
 }
 
+// Doc-sharded search, first half: lower[q] = min over the j candidates with the largest upper bounds of (U - 2 e) - at least j
+// documents of THIS index have an exact score >= lower[q].  With j = ceil(k / W) on each of W shards, the minimum of the W
+// values is not above the global k-th exact score.  One wave per query; -inf when the index holds fewer than j documents.
+__global__ __launch_bounds__(64) void filter_lower_bound_kernel(FilterSegs segs, const float* __restrict__ u_scores,
+                                                                const int64_t* __restrict__ u_ids, const float* __restrict__ qa, int kp,
+                                                                int j, float* __restrict__ lower) {
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    double mn = INFINITY;
+    for (int i = lane; i < j; i += 64) {
+        const int64_t gid = u_ids[q * kp + i];
+        double lb = -INFINITY;
+        if (gid >= 0) {
+            for (int sgi = 0; sgi < segs.count; ++sgi) {
+                const int64_t off = gid - (int64_t)segs.id_base[sgi];
+                if (off >= 0 && off % segs.id_stride[sgi] == 0 && off / segs.id_stride[sgi] < segs.n[sgi]) {
+                    const int64_t r = off / segs.id_stride[sgi];
+                    const double e2 = 2.0 * ((double)qa[q * 4] * (double)segs.xy[sgi][r * 2] + (double)qa[q * 4 + 1] * (double)segs.xy[sgi][r * 2 + 1]) *
+                                      (double)qa[q * 4 + 3] * (double)segs.isd[sgi];
+                    lb = (double)u_scores[q * kp + i] - e2 * 1.001;
+                    break;
+                }
+            }
+        }
+        mn = lb < mn ? lb : mn;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mn, off);
+        mn = o < mn ? o : mn;
+    }
+    if (lane == 0) {
+        float f = (float)mn;
+        if ((double)f > mn) f = nextafterf(f, -INFINITY);          // round down
+        lower[q] = (qa[q * 4] < INFINITY && mn > -INFINITY && mn < INFINITY) ? f : -INFINITY;
+    }
+}
+
+int launch_filter_lower_bound(const FilterSegs& segs, const float* u_scores, const int64_t* u_ids, const float* qa, int64_t nq, int kp,
+                              int j, float* lower, hipStream_t s) {
+    SR_REQUIRE(j >= 1 && j <= kp, "filter(lower bound): j = %d outside [1, %d]", j, kp);
+    hipLaunchKernelGGL(filter_lower_bound_kernel, dim3((unsigned)nq), dim3(64), 0, s, segs, u_scores, u_ids, qa, kp, j, lower);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 // One wave per (query, 64 candidates).  The candidates' rows are gathered 64 columns at a time through LDS (coalesced
 // 256-byte pieces of each row; lane = candidate reads its row conflict-free from the padded tile), the query chunk is a
 // broadcast read, and every lane runs the fp32 fmaf chain of ITS candidate in dense_score_pipe_kernel's k order: per
@@ -210,7 +257,7 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
                                                             const int64_t* __restrict__ u_ids, const float* __restrict__ qa,
                                                             int k, int kp, int H, uint64_t* __restrict__ cand_keys,
                                                             int* __restrict__ cand_count, int64_t cand_cap, int* __restrict__ flags,
-                                                            int j_begin, unsigned int* __restrict__ xmin) {
+                                                            int j_begin, unsigned int* __restrict__ xmin, const float* __restrict__ thr) {
 #pragma clang fp contract(off)
     __shared__ float tile[64][RS_KC + 1];
     __shared__ float qs[RS_KC];
@@ -224,8 +271,11 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     // stage 2: the smallest EXACT score among the k candidates of stage 1 is a lower bound of the exact k-th score; a
     // candidate whose upper bound lies strictly below it cannot reach the top-k, nor tie with its last member.  The list is
     // sorted by U, so what has to be re-scored is a prefix of it.
-    float need = -INFINITY;
-    if (j_begin > 0) need = sr_ord2f(xmin[q]);
+    // thr (doc-sharded search): a value that is provably not above the GLOBAL k-th exact score; a candidate whose upper bound lies
+    // strictly below it cannot be in the global top-k.  With fewer than k candidates at or above thr the stage-1 minimum is no
+    // bound of anything - but then every later candidate is below thr anyway.
+    float need = thr ? thr[q] : -INFINITY;
+    if (j_begin > 0) need = fmaxf(need, sr_ord2f(xmin[q]));
     if (u_scores[q * kp + j0] < need) return;           // the whole wave
     int64_t gid = j < j_end ? u_ids[q * kp + j] : -1;
     if (gid >= 0 && u_scores[q * kp + j] < need) gid = -1;
@@ -300,7 +350,7 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
 
 int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
                           int64_t nq, int k, int kp, int H, uint64_t* cand_keys, int* cand_count, int64_t cand_cap, int* flags,
-                          unsigned int* xmin, hipStream_t s) {
+                          unsigned int* xmin, const float* thr, hipStream_t s) {
     SR_REQUIRE(H % RS_KC == 0, "filter(rescore): dim %d must be a multiple of %d", H, RS_KC);
     SR_REQUIRE(nq <= 0x7fffffff && ceil_div64(kp, 64) <= 65535, "filter(rescore): grid too large");
     // stage 1: the k candidates with the largest upper bounds (and the smallest exact score among them, xmin); stage 2: the
@@ -308,11 +358,11 @@ int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u
     SR_CHECK_HIP(hipMemsetAsync(xmin, 0xff, (size_t)nq * 4, s));
     const int k1 = k < kp ? k : kp;
     hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(k1, 64)), dim3(64), 0, s, segs, Q, u_scores, u_ids,
-                       qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, 0, xmin);
+                       qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, 0, xmin, thr);
     SR_CHECK_LAUNCH();
     if (kp > k1) {
         hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp - k1, 64)), dim3(64), 0, s, segs, Q, u_scores,
-                           u_ids, qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, k1, xmin);
+                           u_ids, qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, k1, xmin, thr);
         SR_CHECK_LAUNCH();
     }
     return SR_OK;

@@ -413,6 +413,7 @@ struct sr_dense_index {
     int64_t redo_cap = 0; int redo_k = 0;
     int64_t n_filtered = 0, n_fallback = 0;   // searches answered by the filter alone / with queries (or all) redone by the exact kernel
     int64_t nq_certified = 0, nq_redone = 0;  // queries answered by the filter / re-done by the exact kernel
+    int64_t pend_nq = 0; int pend_k = 0; const float* pend_q = nullptr;   // sr_dense_search_begin ran for this batch
 };
 
 // bf16 planes of every segment a score mode needs (the certified filter keeps its own fp16 plane, filter_prepare_segment)
@@ -735,8 +736,19 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
 
 // SR_PRECISION_FP32_FILTERED: exact results at 16-bit MFMA speed (dense_filter.hip).  Returns SR_OK with *done = false when
 // the batch has to go through the exact kernel as a whole (filter not applicable to this index / batch).
-static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
-                                 int64_t* d_out_ids, hipStream_t s, bool* done) {
+static int filter_segs_of(sr_dense_index* idx, FilterSegs& fs) {
+    fs.count = (int)idx->segs.size();
+    for (int i = 0; i < fs.count; ++i) {
+        fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
+        fs.xy[i] = idx->segs[i].fxy; fs.isd[i] = idx->segs[i].fisd;
+        fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
+    }
+    return SR_OK;
+}
+
+// First half: the kp documents with the largest upper bounds U per query (idx->a_scores / a_ids / qa).  *done = false: the
+// filter does not apply to this index / batch.
+static int dense_filtered_candidates(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, hipStream_t s, bool* done) {
     *done = false;
     int kp = 3 * k > k + 2048 ? 3 * k : k + 2048;            // candidates per query: k = 1000 -> 3072
     if (const char* e = sr_dev_getenv("SR_FILTER_KP")) kp = atoi(e);
@@ -759,25 +771,29 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
         idx->fq_cap = nq;
         idx->fkp = kp;
     }
-    FilterSegs fs;
-    fs.count = (int)idx->segs.size();
-    for (int i = 0; i < fs.count; ++i) {
-        fs.rows[i] = idx->segs[i].rows; fs.n[i] = idx->segs[i].n;
-        fs.xy[i] = idx->segs[i].fxy; fs.isd[i] = idx->segs[i].fisd;
-        fs.id_base[i] = (uint32_t)idx->segs[i].id_base; fs.id_stride[i] = (uint32_t)idx->segs[i].id_stride;
-    }
     SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
     // 1. the kp documents with the largest upper bounds U (the query planes and constants are made by the pass)
     SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s));
+    *done = true;
+    return SR_OK;
+}
+
+// Second half: exact re-score of the candidates that can still be in the top-k, certificate, exact re-do of the queries without
+// one.  d_thr (nullable, doc-sharded search): per query a value proven not to exceed the GLOBAL k-th exact score.
+static int dense_filtered_finish(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, const float* d_thr, float* d_out_scores,
+                                 int64_t* d_out_ids, hipStream_t s) {
+    const int kp = idx->fkp;
+    FilterSegs fs;
+    SR_TRY(filter_segs_of(idx, fs));
     // 2. exact scores of the candidates that can still be in the top-k -> exact top-k
     SR_TRY(idx->ws2.ensure(nq, k, kp));
     SR_TRY(topk_reset(idx->ws2, nq, s));
     SR_TRY(launch_filter_rescore(fs, d_queries, idx->a_scores, idx->a_ids, idx->qa, nq, k, kp, idx->dim, idx->ws2.cand_keys,
-                                 idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, s));
+                                 idx->ws2.cand_count, idx->ws2.cand_cap, idx->flags, reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, d_thr, s));
     SR_TRY(topk_compact(idx->ws2, nq, k, s));
     SR_TRY(topk_finalize(idx->ws2, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
     // 3. certificate against the k-th exact score
-    SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qa, nq, k, kp, idx->flags, s));
+    SR_TRY(launch_filter_certify(idx->a_scores, d_out_scores, idx->qa, nq, k, kp, idx->flags, d_thr, s));
     // the queries that were not certified are re-done by the exact kernel - those alone (one small D2H per search)
     std::vector<int> h((size_t)nq);
     SR_CHECK_HIP(hipMemcpyAsync(h.data(), idx->flags, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -788,7 +804,6 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
     const int64_t nf = (int64_t)redo.size();
     idx->nq_certified += nq - nf;
     idx->nq_redone += nf;
-    *done = true;
     if (nf == 0) { ++idx->n_filtered; return SR_OK; }
     ++idx->n_fallback;
     if (nf * 2 > nq) {                                         // most of the batch: redo all of it in place
@@ -817,6 +832,13 @@ static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, in
     return SR_OK;
 }
 
+static int dense_search_filtered(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
+                                 int64_t* d_out_ids, hipStream_t s, bool* done) {
+    SR_TRY(dense_filtered_candidates(idx, d_queries, nq, k, s, done));
+    if (!*done) return SR_OK;
+    return dense_filtered_finish(idx, d_queries, nq, k, nullptr, d_out_scores, d_out_ids, s);
+}
+
 extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
                                int64_t* d_out_ids, sr_stream stream) {
     SR_REQUIRE(idx, "sr_dense_search: null index");
@@ -836,6 +858,59 @@ extern "C" int sr_dense_search(sr_dense_index* idx, const float* d_queries, int6
         return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, SR_PRECISION_FP32, s);
     }
     return dense_search_pass(idx, d_queries, nq, k, d_out_scores, d_out_ids, idx->precision, s);
+}
+
+// Doc-sharded search in two halves (distributed.py ShardedDenseRetriever): every rank runs _begin on its shard, the ranks take
+// the minimum of d_lower over the shards (nq floats, one small all-reduce), every rank runs _finish with it.  A shard then
+// re-scores only the candidates that can reach the GLOBAL top-k - about k / W of them instead of k - and returns those (the
+// rest of its [nq, k] output is padding, id -1): the merge of the shards' outputs is the global top-k, bit for bit what one
+// index over all documents returns.  `share` = the number of shards W.  When the certified filter does not apply (exact
+// precision mode, <= 64 queries, no room for the plane) d_lower is -inf and _finish is a plain sr_dense_search.  The pair must
+// not be interleaved with other searches on the same handle.
+extern "C" int sr_dense_search_begin(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, int share, float* d_lower,
+                                     sr_stream stream) {
+    SR_REQUIRE(idx && d_lower, "sr_dense_search_begin: null argument");
+    SR_REQUIRE(nq >= 0 && nq < (1ll << 30) && k >= 1 && k <= SR_MAX_TOPK && share >= 1, "sr_dense_search_begin: bad argument");
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_queries && ((uintptr_t)d_queries & 15) == 0, "sr_dense_search_begin: queries must be non-null and 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    StreamOrder::Scope in_order(idx->order, s);
+    idx->pend_nq = 0;
+    bool done = false;
+    if (idx->precision == SR_PRECISION_FP32_FILTERED) SR_TRY(dense_filtered_candidates(idx, d_queries, nq, k, s, &done));
+    if (!done) {
+        std::vector<float> h((size_t)nq, -INFINITY);
+        SR_CHECK_HIP(hipMemcpyAsync(d_lower, h.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+        SR_CHECK_HIP(hipStreamSynchronize(s));
+        return SR_OK;
+    }
+    FilterSegs fs;
+    SR_TRY(filter_segs_of(idx, fs));
+    int j = (k + share - 1) / share;
+    if (j > idx->fkp) j = idx->fkp;
+    SR_TRY(launch_filter_lower_bound(fs, idx->a_scores, idx->a_ids, idx->qa, nq, idx->fkp, j, d_lower, s));
+    idx->pend_nq = nq; idx->pend_k = k; idx->pend_q = d_queries;
+    return SR_OK;
+}
+
+extern "C" int sr_dense_search_finish(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, const float* d_threshold,
+                                      float* d_out_scores, int64_t* d_out_ids, sr_stream stream) {
+    SR_REQUIRE(idx, "sr_dense_search_finish: null index");
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_queries && d_out_scores && d_out_ids, "sr_dense_search_finish: null pointer");
+    bool pending;
+    {
+        std::lock_guard<std::mutex> lock(idx->mu);
+        pending = idx->pend_nq == nq && idx->pend_k == k && idx->pend_q == d_queries && nq > 0;
+        idx->pend_nq = 0;
+        if (pending) {
+            hipStream_t s = (hipStream_t)stream;
+            StreamOrder::Scope in_order(idx->order, s);
+            return dense_filtered_finish(idx, d_queries, nq, k, d_threshold, d_out_scores, d_out_ids, s);
+        }
+    }
+    return sr_dense_search(idx, d_queries, nq, k, d_out_scores, d_out_ids, stream);
 }
 
 extern "C" int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_t* n_fallback) {

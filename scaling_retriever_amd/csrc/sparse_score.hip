@@ -650,17 +650,28 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
     // (block, sub-tile) keeps a few docs per query for most of the scan: the workgroup-wide scan + serial atomics this replaces
     // cost 6 of a workgroup's 30 us.)
     int cnt[SPB_Q], incl[SPB_Q], base[SPB_Q];
+    const bool full_tile = n_here == SPB_TILE;
 #pragma unroll
     for (int qi = 0; qi < SPB_Q; ++qi) {
         cnt[qi] = 0;
         if (qls[qi] >= 0) {
+            // the lane's largest score first: a wave keeps nothing of a query in most (block, sub-tile) pairs once tau has risen,
+            // and then the 16 three-way comparisons below are skipped wave-wide
+            float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < SPB_DV; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sv = acc[qi][i][e];
-                    cnt[qi] += (4 * SPB_THREADS * i + 4 * tid + e < n_here && sv > thr && sv >= tq[qi]) ? 1 : 0;
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (full_tile || 4 * SPB_THREADS * i + 4 * tid + e < n_here) mx = fmaxf(mx, acc[qi][i][e]);
+            if (__ballot(mx > thr && mx >= tq[qi])) {          // wave-uniform
+#pragma unroll
+                for (int i = 0; i < SPB_DV; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = acc[qi][i][e];
+                        cnt[qi] += (4 * SPB_THREADS * i + 4 * tid + e < n_here && sv > thr && sv >= tq[qi]) ? 1 : 0;
+                    }
+            }
         }
         incl[qi] = cnt[qi];
         if (__ballot(cnt[qi] != 0)) {          // wave-uniform
@@ -676,19 +687,23 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
     for (int qi = 0; qi < SPB_Q; ++qi) {
         if (__ballot(cnt[qi] != 0) == 0) continue;          // wave-uniform: nothing of this query among this wave's docs
         int pos = __builtin_amdgcn_readlane(base[qi], 63) + incl[qi] - cnt[qi];
-        if (cnt[qi] == 0) continue;
         uint64_t* dst = a.cand_keys + (int64_t)qls[qi] * a.cand_cap;
+        // per block of 4 docs a wave-uniform skip: the per-element `if (keep) store` code is 16 exec-masked micro-branches per
+        // query, run by the whole wave for the sake of the one or two lanes that keep something
 #pragma unroll
-        for (int i = 0; i < SPB_DV; ++i)
+        for (int i = 0; i < SPB_DV; ++i) {
+            const float m4 = fmaxf(fmaxf(acc[qi][i][0], acc[qi][i][1]), fmaxf(acc[qi][i][2], acc[qi][i][3]));
+            if (__ballot(cnt[qi] != 0 && m4 > thr && m4 >= tq[qi]) == 0) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float sv = acc[qi][i][e];
                 const int d = 4 * SPB_THREADS * i + 4 * tid + e;
-                if (d < n_here && sv > thr && sv >= tq[qi]) {
+                if (cnt[qi] != 0 && d < n_here && sv > thr && sv >= tq[qi]) {
                     if (pos < a.cand_cap) dst[pos] = sr_make_key(sv, a.id_base + (uint32_t)(doc0 + d) * a.id_stride);
                     ++pos;
                 }
             }
+        }
     }
     stamp(4);
     __syncthreads();       // the slices are re-used by the next sub-tile

@@ -135,6 +135,31 @@ def all_gather_query_csr(row_ptr, cols, vals, n_queries, group=None):
     return q_ptr, torch.cat(all_cols).contiguous(), torch.cat(all_vals).contiguous()
 
 
+def all_reduce_min(values, group=None):
+    """Third (tiny) collective of the doc-sharded dense path: element-wise minimum over the ranks of an fp32 vector (nq floats:
+    28 KB at MS MARCO Dev) - the shards' lower bounds of their ceil(k / W)-th best score, whose minimum bounds the global
+    k-th score from below (sr_dense_search_begin / _finish)."""
+    if _single(group):
+        return values
+    if dist.get_backend(group) == "gloo" and values.is_cuda:
+        t = values.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return t.to(values.device)
+    t = values.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return t
+
+
+def sharded_dense_search(index, queries, k, world_size, group=None):
+    """One rank's part of a doc-sharded dense search on its DenseIndexHIP: candidates + lower bound, all-reduce(min), exact
+    re-score of what can reach the GLOBAL top-k.  Returns this shard's (scores, ids) [nq, k] (possibly padded)."""
+    queries = queries.contiguous()
+    if world_size <= 1 or _single(group):       # no process group: the shard's own bound is NOT a global one - plain search
+        return index.search(queries, k)
+    lower = index.search_begin(queries, k, world_size)
+    return index.search_finish(queries, k, all_reduce_min(lower, group=group))
+
+
 class ShardedSparseRetriever:
     """Doc-sharded inverted-index retrieval: rank r holds the postings of dataset rows r, r + W, ... - exactly what
     `eval_sparse.py --task_name indexing` writes into index_dir_{r} (g_row = local * W + rank,
@@ -181,11 +206,12 @@ class ShardedDenseRetriever:
     """Each rank holds rows rank, rank+W, ... of the corpus in its own HBM (DenseIndexHIP with
     id_base = rank, id_stride = W) and scores the replicated query matrix against them."""
 
-    def __init__(self, hidden_dim, rank=None, world_size=None):
+    def __init__(self, hidden_dim, rank=None, world_size=None, precision="fp32_filtered"):
         from .scoring import DenseIndexHIP
         self.rank = dist.get_rank() if rank is None and dist.is_initialized() else (rank or 0)
         self.world_size = dist.get_world_size() if world_size is None and dist.is_initialized() else (world_size or 1)
         self.index = DenseIndexHIP(hidden_dim)
+        self.index.set_precision(precision)      # the same ids and fp32 scores as "fp32", through the certified filter
 
     def add_local_rows(self, rows):
         """rows: fp32 cuda tensor [n_local, H] = the embeddings of dataset rows rank, rank+W, ..."""
@@ -194,7 +220,7 @@ class ShardedDenseRetriever:
     def search(self, queries, k, dst=0):
         """queries replicated on every rank.  Returns (scores, global ids) on rank dst, (None, None) elsewhere."""
         from .scoring import topk_merge
-        s, i = self.index.search(queries, k)
+        s, i = sharded_dense_search(self.index, queries, k, self.world_size)
         gs, gi = gather_topk(s, i, dst=dst)
         if gs is None:
             return None, None

@@ -185,6 +185,31 @@ class DenseIndexHIP:
                                                 _lib.stream_ptr()), "sr_dense_search")
         return scores, ids
 
+    def search_begin(self, queries, k, share):
+        """First half of a doc-sharded search (include/sr_hip.h sr_dense_search_begin): returns lower [nq] fp32 (cuda) - per
+        query a value at least ceil(k / share) documents of this index reach exactly (-inf where the filter does not apply).
+        `queries` must be the same contiguous tensor that is passed to search_finish."""
+        if queries.dtype != torch.float32 or queries.dim() != 2 or queries.shape[1] != self.dim or not queries.is_cuda or not queries.is_contiguous():
+            raise ValueError(f"expected a contiguous float32 cuda tensor [nq, {self.dim}], got {queries.dtype} {tuple(queries.shape)}")
+        lower = torch.empty((queries.shape[0],), dtype=torch.float32, device=queries.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_dense_search_begin(self._h, _ptr(queries), queries.shape[0], int(k), int(share), _ptr(lower),
+                                                      _lib.stream_ptr()), "sr_dense_search_begin")
+        return lower
+
+    def search_finish(self, queries, k, threshold=None):
+        """Second half: threshold [nq] fp32 = the minimum of search_begin's values over all shards (None: a plain search).
+        Returns (scores [nq, k], ids [nq, k]); rows may end in padding (id -1) - the shard returns what can reach the global top-k."""
+        nq = queries.shape[0]
+        scores = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=queries.device)
+        if threshold is not None:
+            threshold = threshold.to(device=queries.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_dense_search_finish(self._h, _ptr(queries), nq, int(k), _ptr(threshold), _ptr(scores), _ptr(ids),
+                                                       _lib.stream_ptr()), "sr_dense_search_finish")
+        return scores, ids
+
     def close(self):
         if self._h:
             self.lib.sr_dense_index_destroy(self._h)

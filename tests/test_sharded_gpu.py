@@ -75,3 +75,44 @@ def test_bench_multi_rank_path_dry_run():
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
     assert res["fast_mode"]["value"] > 0 and res["small_batch"][0]["nq"] == 1
     assert res["encode"]["value"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_sharded_threshold_exchange_equals_single_index(W):
+    """sr_dense_search_begin / _finish: W shards in one process, each returns a lower bound of its
+    ceil(k / W)-th best exact score; with the minimum over the shards as threshold every shard re-scores only what can reach the
+    GLOBAL top-k, and the merge of the (padded) shard outputs equals the single index bit for bit - ids and fp32 scores - on
+    Gaussian data, on data with near-duplicates around the cut, and with a zero query (re-done exactly on every shard)."""
+    import torch
+    from scaling_retriever_amd.scoring import DenseIndexHIP, topk_merge
+    g = torch.Generator(device="cuda").manual_seed(W)
+    n, h, k, nq = 60001, 256, 300, 130
+    D = torch.randn((n, h), device="cuda", generator=g)
+    D[1000:1400] = D[7] * (1.0 + 1e-6 * torch.arange(400, device="cuda")[:, None])        # 400 near-duplicates of one row
+    Q = torch.randn((nq, h), device="cuda", generator=g)
+    Q[3] = D[7]
+    Q[11] = 0
+    full = DenseIndexHIP(h)
+    full.add_device_rows(D)
+    es, ei = full.search(Q, k)
+    shards = []
+    for r in range(W):
+        ix = DenseIndexHIP(h)
+        ix.set_precision("fp32_filtered")
+        ix.add_device_rows(D[torch.arange(r, n, W, device="cuda")].contiguous(), id_base=r, id_stride=W)
+        shards.append(ix)
+    lowers = torch.stack([ix.search_begin(Q, k, W) for ix in shards])
+    thr = lowers.min(0).values
+    outs = [ix.search_finish(Q, k, thr) for ix in shards]
+    ms, mi = topk_merge(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]))
+    assert torch.equal(mi, ei) and torch.equal(ms, es)
+    # the point of the exchange: a shard returns about k / W candidates, the rest of its rows is padding
+    kept = torch.stack([(o[1] >= 0).sum(1) for o in outs]).float()
+    ok = torch.ones(nq, dtype=torch.bool, device="cuda")
+    ok[11] = False                                   # the zero query is re-done exactly: a full local top-k
+    ok[3] = False                                    # the near-duplicate block sits on the cut of this one
+    assert float(kept[:, ok].mean()) < 0.6 * k if W == 8 else True
+    # without a threshold the pair is a plain search
+    s0, i0 = shards[0].search_finish(Q, k, None)
+    s1, i1 = shards[0].search(Q, k)
+    assert torch.equal(s0, s1) and torch.equal(i0, i1)
