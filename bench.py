@@ -52,7 +52,7 @@ LION_1B = dict(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector peak
 PEAK_BF16_MFMA_TF = 2500.0   # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0       # HBM3E spec peak (about 6300 GB/s is what a streaming copy reaches)
-PEAK_L2_GBPS = 17800.0       # MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 16.8-18.8 TB/s chip-wide out of the XCDs' L2
+PEAK_L2_GBPS = 34500.0       # MI355X_MICROARCH.md 'L2 (per XCD)': 4 MiB per XCD, ~34.5 TB/s aggregate
 PEAK_VALU_F32_OPS = 256 * 4 * 16 * 2 * 2.4e9     # packed fp32 lane-operations per second (a multiply or an add each): 78.6e12
 FLOP_PER_TOKEN_1B = 1.946e9  # 2 x linear params of the 1B body
 
@@ -259,7 +259,7 @@ def sparse_leg(args, device):
                                "frac": round(valu_rate / PEAK_VALU_F32_OPS, 4), "ops_per_pass": valu_ops,
                                "floor_ms_per_pass": round(valu_ops / PEAK_VALU_F32_OPS * 1e3, 1)},
         "l2_bytes_loaded": {"bound": "l2", "achieved": round(l2_rate / 1e9, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s out of L2 (MI355X_MICROARCH.md, "
-                            "rows gathered from the XCD's L2: 16.8-18.8 TB/s chip-wide)", "frac": round(l2_rate / 1e9 / PEAK_L2_GBPS, 4),
+                            "L2 per XCD: ~34.5 TB/s aggregate)", "frac": round(l2_rate / 1e9 / PEAK_L2_GBPS, 4),
                             "bytes_per_pass": bytes_loaded, "floor_ms_per_pass": round(bytes_loaded / (PEAK_L2_GBPS * 1e9) * 1e3, 1),
                             "of_which_dense_columns": 4.0 * TILE * wc["dense_columns_loaded"], "of_which_postings": 8.0 * rmw},
         "lds_scatter": {"bound": "lds", "achieved": rmw / kernel_s, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",

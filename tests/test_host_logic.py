@@ -122,6 +122,10 @@ for nq in (7, 8, 1):                                     # ragged, even and fewe
     Qall = torch.arange(nq * 3, dtype=torch.float32).reshape(nq, 3)
     lo, hi = query_slice(nq, rank, W)
     assert torch.equal(all_gather_query_reps(Qall[lo:hi].contiguous(), nq), Qall), nq
+# the threshold exchange of the doc-sharded dense search: element-wise minimum over the ranks (distributed.all_reduce_min)
+from scaling_retriever_amd.distributed import all_reduce_min
+mine = torch.tensor([1.0 + rank, -2.0 - rank, float("-inf") if rank == 1 else 5.0, 0.25])
+assert torch.equal(all_reduce_min(mine), torch.tensor([1.0, -2.0 - (W - 1), float("-inf"), 0.25]))
 rng = np.random.default_rng(0)
 D = rng.standard_normal((501, 32), dtype=np.float32); Q = rng.standard_normal((6, 32), dtype=np.float32); k = 20
 rows = np.array(list(shard_rows(len(D), rank, W)))
