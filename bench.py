@@ -4,23 +4,29 @@
 
 One step = one pass of the hot path over the whole Dev query set: encode 6 980 synthetic queries with
 the HIP LlamaBiDense encoder (1B dims, random weights), score them against the doc-sharded fp32
-embedding matrix resident in HBM (8 841 823 x 2048, synthetic), fused top-1000, and - for N > 1 - one
-RCCL gather of the per-shard top-k + merge on rank 0.  value = queries / s over the whole job.
+embedding matrix resident in HBM (8 841 823 x 2048, synthetic), fused top-1000, and - for N > 1 - an all-reduce(min)
+of nq floats (the threshold exchange), one RCCL gather of the per-shard top-k + merge on rank 0.  value = queries / s
+over the whole job.
 
 Precision: queries are encoded in the encoder's fp32 regime, as the reference does (eval_dense.py:94-106: no
-autocast) - split-bf16 GEMMs carrying the full fp32 significands - documents in the bf16-autocast regime
-(indexer.py:46-52); scores are exact fp32.
+autocast) - fp16-plane GEMMs carrying the error of an fp32 GEMM - documents in the bf16-autocast regime
+(indexer.py:46-52); scores are exact fp32: a certified fp16 upper-bound filter + exact re-score, bit-identical to the
+exact fp32 MFMA kernel (asserted on the whole problem in every run: `parity`).
 
-Also reported on the same JSON line: `roofline` for the dominant kernel (dense_score_kernel, fp32 MFMA
-bound; durations from HIP events recorded around every launch inside the timed region), `cpu_baseline` (the
-oracle's faiss-style flat IP search on the host cores, bounded sample, rank 0 at N = 1 only), and the two other
-stages of the headline metric:
-  `encode`  passages/s of the corpus-encode task: >= 100 000 synthetic passages through store_embs (token-budget
-            batches -> doc_encode under autocast -> D2H -> embs_*.npy / ids_*.npy / plan.json), with its MFMA roofline;
-  `sparse`  BASELINE.json configs[2] (N = 1 only): queries/s of sr_sparse_search on the MSMARCO-shaped synthetic
-            inverted index, full-size bit-exact check against the oracle, the 32-thread CPU baseline, and the two
-            bounds that describe the kernel (unique index bytes over HBM; LDS read-modify-writes against the
-            microbenchmark tools/micro/lds_rmw.hip).
+Also reported on the same JSON line: `roofline` for the dominant kernel (dense_split_kernel<true>, the filter's
+upper-bound pass, 16-bit MFMA bound; durations from HIP events recorded around every launch inside the timed region),
+`cpu_baseline` (faiss's flat-IP algorithm - host BLAS sgemm blocks + a heap per query - on the host cores, bounded
+sample, rank 0 at N = 1 only), and the other stages / configs of the headline metric:
+  `exact_kernel_mode`  the same step with every product on the fp32 MFMA pipe: the data-independent floor;
+  `filter_robustness`  the search stage on anisotropic / near-duplicate corpora and queries drawn near documents (full shape),
+                       each compared with the exact kernel on all queries, with the certified / re-done query counts;
+  `shard_1of8`         BASELINE.json configs[3] on one GPU: one of 8 doc shards with and without the threshold exchange;
+  `encode`             passages/s of the corpus-encode task: >= 100 000 synthetic passages through store_embs (token-budget
+                       batches -> doc_encode under autocast -> D2H -> embs_*.npy / ids_*.npy / plan.json), MFMA roofline;
+  `sparse`             BASELINE.json configs[2] (N = 1 only): queries/s of sr_sparse_search on the MSMARCO-shaped synthetic
+                       inverted index, all CPU-scored queries compared bit for bit with the oracle, the 32-thread CPU baseline,
+                       and `bounds`: the kernel's VALU / L2 / LDS floors from work counted on the device;
+  `config5_8b`         BASELINE.json configs[4]: one GPU's share at Lion-DS-8B dims.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \

@@ -16,7 +16,7 @@ Here:
   * batches are collated into a ring of pinned host buffers (pad-to-longest, the tokenizer's padding side).
 This is parity-neutral: pads are masked keys that never enter the computation, each passage's embedding depends only on
 its own tokens, and the ids travel with the rows (ids_*.npy records the order), so the artefacts hold the same
-(pid -> vector) content as the sequential loader's (tests/test_pipeline.py, tests/test_pipeline_gpu.py).
+(pid -> vector) content as the sequential loader's (tests/test_pipeline.py on CPU; on the GPU tests/test_eval_drivers.py compares both loaders' artefacts with the oracle).
 """
 import numpy as np
 import torch
