@@ -561,7 +561,7 @@ class HybridIndexer(SparseIndexer):
         self._dense, self._dense_ids, self._chunk_idx = [], [], 0
 
     def _flush_dense(self):
-        embs = torch.cat(self._dense).float().cpu().numpy()
+        embs = torch.cat(self._dense).numpy()
         ids = self._dense_ids
         if isinstance(ids[0], int):
             ids = np.array(ids, dtype=np.int64)
@@ -573,7 +573,9 @@ class HybridIndexer(SparseIndexer):
 
     def _encode_batch(self, inputs, batch_ids):
         sparse, dense = self.model.encode(**inputs)
-        self._dense.append(dense)
+        # to the host batch by batch, as store_embs does (indexer.py:56): a whole chunk of 2 M x H fp32 rows (16 GB at H = 2048,
+        # 32 GB at 4096) would otherwise sit in HBM next to the COO triples of the sparse index
+        self._dense.append(dense.float().cpu())
         self._dense_ids.extend(batch_ids)
         if len(self._dense_ids) >= self.chunk_size:
             self._flush_dense()

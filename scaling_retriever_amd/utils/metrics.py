@@ -95,17 +95,17 @@ def load_and_evaluate(qrel_file_path, run_file_path, metric):
 
 
 def recall_cap_k(run, qrel, k, agg=True):
-    """beir's capped recall R_cap@k [3P beir EvaluateRetrieval.evaluate_custom(metric="r_cap")]: relevant docs among the
-    top k, over min(k, number of relevant docs)."""
+    """beir's capped recall R_cap@k [3P beir==2.0.0 EvaluateRetrieval.evaluate_custom(metric="r_cap") -> custom_metrics.recall_cap,
+    restated from its published source]: for EVERY query of the run, relevant docs among its top k (by score) over
+    min(k, number of relevant docs), averaged over len(run).  As in beir, a query of the run that the qrels do not hold is a
+    KeyError and a query without relevant documents a ZeroDivisionError (the earlier version skipped the former and
+    scored the latter 0, so R_cap@100 could differ from the reference's perf.json when the run held queries outside the split)."""
     per_q = {}
     for q, docs in run.items():
-        if q not in qrel:
-            continue
         rel = {d for d, r in qrel[q].items() if r > 0}
         top = [d for d, _ in sorted(docs.items(), key=lambda kv: kv[1], reverse=True)[:k]]
-        denom = min(len(rel), k)
-        per_q[q] = (len(rel.intersection(top)) / denom) if denom else 0.0
-    return sum(per_q.values()) / max(1, len(per_q)) if agg else per_q
+        per_q[q] = len([d for d in top if qrel[q].get(d, 0) > 0]) / min(len(rel), k)
+    return sum(per_q.values()) / len(run) if agg else per_q
 
 
 def evaluate_beir(args, qrels):

@@ -129,3 +129,10 @@ def test_recall_cap():
     assert recall_k(run, qrel, 2) == pytest.approx(2 / 5)
     assert recall_cap_k(run, qrel, 2) == pytest.approx(2 / 2)      # denominator min(k, #relevant)
     assert recall_cap_k(run, qrel, 4) == pytest.approx(3 / 4)
+    # beir averages over every query of the run and indexes the qrels with it: a query outside the qrels is an error there
+    # too, not a silent skip
+    run2 = dict(run, q2={"d0": 1.0})
+    qrel2 = dict(qrel, q2={"d9": 1})
+    assert recall_cap_k(run2, qrel2, 2) == pytest.approx((2 / 2 + 0.0) / 2)
+    with pytest.raises(KeyError):
+        recall_cap_k(dict(run, stray={"d0": 1.0}), qrel, 2)

@@ -25,7 +25,7 @@ lib = _lib.load()
 
 
 def run(mode, k, env, reps=2):
-    for kk in ("SR_SPLIT_PERSIST", "SR_SPLIT_DIAG", "SR_SPLIT_XCD", "SR_FILTER_KP", "SR_SPLIT_SEG", "SR_SPLIT_STAMPS"):
+    for kk in ("SR_SPLIT_PERSIST", "SR_SPLIT_DIAG", "SR_SPLIT_XCD", "SR_FILTER_KP", "SR_SPLIT_SEG", "SR_SPLIT_STAMPS", "SR_DENSE_LAUNCH_WGS"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     idx.set_precision(mode)
@@ -46,6 +46,6 @@ def run(mode, k, env, reps=2):
 
 
 for rep in range(2):
-    run("fp32_filtered", 1000, {"SR_SPLIT_STAMPS": "1"})
-    run("fp32_filtered", 1000, {"SR_SPLIT_STAMPS": "1", "SR_SPLIT_DIAG": "8"})
-    run("fp32_filtered", 1000, {"SR_SPLIT_STAMPS": "1", "SR_SPLIT_DIAG": "4"})
+    run("fp32_filtered", 1000, {})
+    run("fp32_filtered", 1000, {"SR_DENSE_LAUNCH_WGS": "4096"})
+    run("fp32_filtered", 1000, {"SR_DENSE_LAUNCH_WGS": "1024"})
