@@ -55,6 +55,13 @@ struct SparseArgs {
     int64_t cand_cap;
     uint32_t id_base, id_stride;
     const uint8_t* q_done;     // optional: queries the query-block kernel handles (skipped here)
+    // query-block kernel, wave-owned candidate regions: wave w of the workgroup of (block, sub-tile s) keeps the survivors among ITS
+    // 1024 docs of query q in slots [(s - first sub-tile of the launch) * 4096 + 1024 w, + 1024) of q's candidate buffer - as
+    // many slots as docs, so no reservation is needed - and their number in seg_cnt[q][4 (s - first) + w]; sparse_gather_kernel
+    // packs the regions before the compaction.  Null: one atomic reservation per (wave, query), the round trip of which was
+    // half of the filter phase
+    int* seg_cnt;
+    int seg_n;
 };
 
 // The postings a (query, tile) workgroup has to apply are cut into groups of SP_GROUP postings of ONE term.  The run of
@@ -681,12 +688,18 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
             }
         }
         base[qi] = 0;
-        if (lane == 63 && incl[qi] > 0) base[qi] = atomicAdd(&a.cand_count[qls[qi]], incl[qi]);
+        if (a.seg_cnt) {
+            const int seg = (sub - a.tile_begin * (SP_TILE / SPB_TILE)) * 4 + wave;
+            base[qi] = seg * (SPB_TILE / 4);
+            if (lane == 63 && incl[qi] > 0) a.seg_cnt[(int64_t)qls[qi] * a.seg_n + seg] = incl[qi];
+        } else if (lane == 63 && incl[qi] > 0) {
+            base[qi] = atomicAdd(&a.cand_count[qls[qi]], incl[qi]);
+        }
     }
 #pragma unroll
     for (int qi = 0; qi < SPB_Q; ++qi) {
         if (__ballot(cnt[qi] != 0) == 0) continue;          // wave-uniform: nothing of this query among this wave's docs
-        int pos = __builtin_amdgcn_readlane(base[qi], 63) + incl[qi] - cnt[qi];
+        int pos = (a.seg_cnt ? base[qi] : __builtin_amdgcn_readlane(base[qi], 63)) + incl[qi] - cnt[qi];
         uint64_t* dst = a.cand_keys + (int64_t)qls[qi] * a.cand_cap;
         // per block of 4 docs a wave-uniform skip: the per-element `if (keep) store` code is 16 exec-masked micro-branches per
         // query, run by the whole wave for the sake of the one or two lanes that keep something
@@ -713,6 +726,67 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
         for (int i = 0; i < 7; ++i) atomicAdd(&b.stamps[i], st_t[i]);
         atomicAdd(&b.stamps[7], 1ull);
     }
+}
+
+// Packs the wave-owned candidate regions of one launch (SparseArgs::seg_cnt) to the head of every query's candidate buffer, in
+// place, and sets cand_count: what topk_compact_kernel expects.  One workgroup per query.  A region's keys move DOWN (the packed
+// position of a key is never above its region's start), outputs are produced in ascending rounds of 4096 keys - every round reads
+// all its sources, then a barrier, then writes - so a write can only land on sources that were already read.
+#define SPG_ROUND 4096
+__global__ __launch_bounds__(256) void sparse_gather_kernel(uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count, int64_t cand_cap,
+                                                            int* __restrict__ seg_cnt, int seg_n, int region) {
+    __shared__ int pre[513];                 // exclusive prefix of the region counts (seg_n <= 512)
+    __shared__ int wave_tot[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int* cnt = seg_cnt + (int64_t)q * seg_n;
+    uint64_t* buf = cand_keys + (int64_t)q * cand_cap;
+    int c0 = 0, c1 = 0;
+    if (2 * tid < seg_n) c0 = cnt[2 * tid];
+    if (2 * tid + 1 < seg_n) c1 = cnt[2 * tid + 1];
+    const int mine = c0 + c1;
+    int v = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if ((tid & 63) >= off) v += o;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
+    __syncthreads();
+    int ex = v - mine;
+    for (int w = 0; w < (tid >> 6); ++w) ex += wave_tot[w];
+    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    pre[2 * tid] = ex;
+    pre[2 * tid + 1] = ex + c0;
+    if (tid == 255) pre[512] = total;
+    if (mine) {
+        if (c0) cnt[2 * tid] = 0;
+        if (c1) cnt[2 * tid + 1] = 0;
+    }
+    __syncthreads();
+    if (total == 0) return;                  // cand_count stays 0 (reset by the compaction / topk_reset)
+    for (int p0 = 0; p0 < total; p0 += SPG_ROUND) {
+        uint64_t keep[SPG_ROUND / 256];
+#pragma unroll
+        for (int i = 0; i < SPG_ROUND / 256; ++i) {
+            const int p = p0 + i * 256 + tid;
+            keep[i] = 0;
+            if (p < total) {
+                int lo = 0, hi = 511;        // the region r with pre[r] <= p < pre[r + 1]
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+                }
+                keep[i] = buf[(int64_t)lo * region + (p - pre[lo])];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SPG_ROUND / 256; ++i) {
+            const int p = p0 + i * 256 + tid;
+            if (p < total) buf[p] = keep[i];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) cand_count[q] = total;
 }
 
 // Order of a batch's queries before it is cut into blocks of SPB_Q.  Wave q of a workgroup walks query q's scatter terms
@@ -915,6 +989,8 @@ struct sr_sparse_index {
     int64_t* plan_off = nullptr;
     unsigned long long* d_stamps = nullptr;   // dev switch SR_SPARSE_STAMPS
     unsigned long long* d_counters = nullptr; // sr_sparse_index_work_counters
+    int* seg_cnt = nullptr;                   // wave-owned candidate regions of the query-block kernel: [q_batch][seg_cap]
+    int64_t seg_q_cap = 0; int seg_cap = 0;
     bool count_work = false;
     int32_t* plan_perm = nullptr;     // every batch's queries in block order
     uint8_t* q_done = nullptr;
@@ -1104,6 +1180,7 @@ extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     sparse_free_device(idx);
     if (idx->d_postings) (void)hipFree(idx->d_postings);
     if (idx->d_counters) (void)hipFree(idx->d_counters);
+    if (idx->seg_cnt) (void)hipFree(idx->seg_cnt);
     delete idx;
     return SR_OK;
 }
@@ -1185,6 +1262,15 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
     if (max_tiles > 64) max_tiles = 64;
     if (max_tiles > idx->n_tiles) max_tiles = idx->n_tiles;
     SR_TRY(idx->ws.ensure(q_batch, k, max_tiles * SP_TILE));
+    const int seg_cap = (int)(max_tiles * (SP_TILE / SPB_TILE) * 4);          // regions per query and launch (<= 512)
+    if (idx->seg_q_cap < q_batch || idx->seg_cap < seg_cap) {
+        if (idx->seg_cnt) (void)hipFree(idx->seg_cnt);
+        idx->seg_cnt = nullptr;
+        SR_CHECK_HIP(hipMalloc((void**)&idx->seg_cnt, sizeof(int) * (size_t)q_batch * (size_t)seg_cap));
+        SR_CHECK_HIP(hipMemsetAsync(idx->seg_cnt, 0, sizeof(int) * (size_t)q_batch * (size_t)seg_cap, s));
+        idx->seg_q_cap = q_batch;
+        idx->seg_cap = seg_cap;
+    }
 
     // query-block path: order every batch's queries, cut them into blocks of SPB_Q and plan the blocks, once per call
     bool use_blocks = idx->n_dense > 0;
@@ -1278,6 +1364,12 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             a.id_base = (uint32_t)id_base;
             a.id_stride = (uint32_t)id_stride;
             a.q_done = use_blocks ? idx->q_done : nullptr;
+            // wave-owned regions only when every block runs the query-block kernel (the per-query kernel appends through the
+            // atomic counter into the same buffer); SR_SPARSE_SEG=0: atomic reservations (A/B)
+            bool use_seg = use_blocks && !any_fallback && SPB_Q == 4 && idx->seg_cap <= 512;
+            if (const char* e = sr_dev_getenv("SR_SPARSE_SEG")) use_seg = use_seg && atoi(e) != 0;
+            a.seg_cnt = use_seg ? idx->seg_cnt : nullptr;
+            a.seg_n = idx->seg_cap;
             idx->prof.begin(s);
             if (use_blocks) {
                 SparseBlockArgs b;
@@ -1317,6 +1409,11 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                     hipLaunchKernelGGL(sparse_count_postings_kernel, dim3((unsigned)ceil_div64(nterms, 256)), dim3(256), 0, s,
                                        idx->skip, idx->n_tiles, idx->n_terms, d_q_indptr, d_q_cols, qb, qb + nqb, (int)t0, (int)nt,
                                        idx->d_postings);
+            }
+            if (a.seg_cnt) {
+                hipLaunchKernelGGL(sparse_gather_kernel, dim3((unsigned)nqb), dim3(256), 0, s, idx->ws.cand_keys, idx->ws.cand_count,
+                                   idx->ws.cand_cap, idx->seg_cnt, idx->seg_cap, SPB_TILE / 4);
+                SR_CHECK_LAUNCH();
             }
             SR_TRY(topk_compact(idx->ws, nqb, k, s));
             t0 += nt;
