@@ -447,7 +447,11 @@ static int filter_prepare_segment(sr_dense_index* idx, DenseSegment& seg) {
     SR_TRY(launch_filter_plane(seg.rows, seg.n, idx->dim, seg.fsd, sr_filter_sigma(idx->dim), seg.fpl, seg.fxy,
                                reinterpret_cast<int*>(idx->f_scratch) + 1, nullptr));
     SR_CHECK_HIP(hipMemcpy(h, idx->f_scratch, 8, hipMemcpyDeviceToHost));
-    if (h[1] != 0) return SR_OK;
+    if (h[1] != 0) {                          // a non-finite error term: the segment is not filterable, its plane is of no use
+        (void)hipFree(seg.fpl); (void)hipFree(seg.fxy);
+        seg.fpl = nullptr; seg.fxy = nullptr;
+        return SR_OK;
+    }
     seg.f_state = 1;
     return SR_OK;
 }
