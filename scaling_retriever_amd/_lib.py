@@ -100,6 +100,9 @@ def load():
             raise SrHipError(
                 f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
                 "run `make -C scaling_retriever_amd/csrc` (needs hipcc, targets gfx950).")
+        # torch first: it ships its own libamdhip64; were the system runtime pulled in by our DT_NEEDED before torch's, the
+        # process would hold two HIP runtimes and the second would find "no ROCm-capable device"
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -660,8 +660,9 @@ static void model_free(sr_model* m) {
 
 #define SR_ALLOC(ptr, bytes)                                                                      \
     do {                                                                                          \
-        if (hipMalloc((void**)&(ptr), (size_t)(bytes)) != hipSuccess) {                            \
-            sr_set_error("sr_model_create: hipMalloc of %zu bytes failed", (size_t)(bytes));      \
+        const hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                          \
+        if (e_ != hipSuccess) {                                                                   \
+            sr_set_error("sr_model_create: hipMalloc of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
             model_free(m);                                                                        \
             delete m;                                                                             \
             return SR_ERR_NOMEM;                                                                  \
