@@ -512,7 +512,10 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             pmc2 = json.load(f)
         shape2 = pmc2["dense_split_launch"]
-        if (shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
+        import hashlib
+        with open(os.path.join(ROOT, pmc2["kernel_source"]["file"]), "rb") as f:
+            same_kernel = hashlib.sha256(f.read()).hexdigest() == pmc2["kernel_source"]["sha256"]       # stale once the kernel changes
+        if (same_kernel and shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
                 and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
             split_traffic = pmc2["kernels"]["dense_split_kernel"]["traffic_bytes"]
             split_traffic_src = "profiles/r03_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"

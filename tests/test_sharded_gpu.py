@@ -116,3 +116,46 @@ def test_sharded_threshold_exchange_equals_single_index(W):
     s0, i0 = shards[0].search_finish(Q, k, None)
     s1, i1 = shards[0].search(Q, k)
     assert torch.equal(s0, s1) and torch.equal(i0, i1)
+
+
+def test_eval_dense_driver_two_ranks(golden_dir, tmp_path):
+    """eval_dense.py --task_name write_doc_embeds then retrieval under torchrun with 2 ranks (sharing this GPU, SR_SHARE_GPU=1):
+    each rank encodes its passages and, at retrieval, scores the shard files it loads; the threshold exchange, the gather of the
+    per-shard top-k and the merge give the run of the single-process route (the reference scores on one process,
+    /root/reference/eval_dense.py:191)."""
+    import json
+    import numpy as np
+    from golden_weights import make_weights
+    from test_eval_drivers import _texts, _write_model
+    z = np.load(os.path.join(golden_dir, "enc_tiny_a.npz"))
+    cfg = json.loads(str(z["config_json"]))
+    w = make_weights(cfg, int(z["weight_seed"]))
+    rng = np.random.default_rng(5)
+    models = _write_model(str(tmp_path), cfg, w, rng)
+    lora, _ = models["dense"]
+    docs, queries = _texts(rng, 90, 3, 20), _texts(rng, 7, 2, 6)
+    with open(tmp_path / "corpus.tsv", "w") as f:
+        for i, t in enumerate(docs):
+            f.write(f"d{i}\t{t}\n")
+    with open(tmp_path / "queries.tsv", "w") as f:
+        for i, t in enumerate(queries):
+            f.write(f"q{i}\t{t}\n")
+    env = dict(os.environ, SR_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", TQDM_DISABLE="1")
+    run2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+            "--master-port", "29691", os.path.join(ROOT, "eval_dense.py"), "--model_name_or_path", lora]
+    emb2 = str(tmp_path / "embs2")
+    for extra in (["--task_name", "write_doc_embeds", "--corpus_path", str(tmp_path / "corpus.tsv"), "--doc_embed_dir", emb2,
+                   "--doc_max_length", "16", "--chunk_size", "32", "--token_budget", "64", "--tokenize_workers", "0"],
+                  ["--task_name", "retrieval", "--query_path", str(tmp_path / "queries.tsv"), "--doc_embed_dir", emb2,
+                   "--out_dir", str(tmp_path / "out2"), "--top_k", "10", "--query_max_length", "8"]):
+        out = subprocess.run(run2 + extra, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+    run_sharded = json.load(open(tmp_path / "out2" / "run.json"))
+    # one process over the same shard files
+    sys.path.insert(0, ROOT)
+    import eval_dense
+    eval_dense.main(["--task_name", "retrieval", "--model_name_or_path", lora, "--query_path", str(tmp_path / "queries.tsv"),
+                     "--doc_embed_dir", emb2, "--out_dir", str(tmp_path / "out1"), "--top_k", "10", "--query_max_length", "8"])
+    run_single = json.load(open(tmp_path / "out1" / "run.json"))
+    assert run_sharded == run_single
+    assert all(len(v) == 10 for v in run_sharded.values()) and len(run_sharded) == 7
