@@ -456,7 +456,9 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     b.xcd_order = 1;
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
     b.diag = 0;
-    if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only: wrong results
+#ifdef SR_DIAG_BUILD        // wrong results by design: read only by a diagnostic build (make CXXFLAGS+=-DSR_DIAG_BUILD), never by the product .so
+    if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only
+#endif
     b.stamps = nullptr;
     if (sr_dev_getenv("SR_SPLIT_STAMPS")) {
         static unsigned long long* d_st = nullptr;

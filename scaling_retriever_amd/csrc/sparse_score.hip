@@ -1387,7 +1387,9 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 b.diag = 0;
                 b.stamps = idx->d_stamps;
                 b.counters = idx->count_work ? idx->d_counters : nullptr;
+#ifdef SR_DIAG_BUILD        // wrong results by design: read only by a diagnostic build, never by the product .so
                 if (const char* e = sr_dev_getenv("SR_SPARSE_DIAG")) b.diag = atoi(e);
+#endif
                 b.n_sub = (int)(nt * (SP_TILE / SPB_TILE));
                 const dim3 grid((unsigned)ceil_div64(nqb, SPB_Q), (unsigned)ceil_div64(b.n_sub, SPB_SUBS));
                 hipLaunchKernelGGL(sparse_block_kernel, grid, dim3(SPB_THREADS),
