@@ -456,7 +456,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     b.xcd_order = 1;
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
     b.diag = 0;
-#ifdef SR_DIAG_BUILD        // wrong results by design: read only by a diagnostic build (make CXXFLAGS+=-DSR_DIAG_BUILD), never by the product .so
+#ifdef SR_DIAG_BUILD        // wrong results by design: read only by a diagnostic build (make EXTRA=-DSR_DIAG_BUILD), never by the product .so
     if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only
 #endif
     b.stamps = nullptr;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the certified filter's upper-bound pass (dense_split_kernel<true>) at the full MSMARCO shape: average launch
 duration (HIP events inside the library) under the dev switches.  python3 tools/micro/split_ab.py [n_docs]
-The SR_SPLIT_DIAG runs need a diagnostic build: make -C scaling_retriever_amd/csrc clean all CXXFLAGS+=-DSR_DIAG_BUILD (never shipped)."""
+The SR_SPLIT_DIAG runs need a diagnostic build: make -C scaling_retriever_amd/csrc clean all EXTRA=-DSR_DIAG_BUILD (never shipped)."""
 import ctypes
 import os
 import sys
