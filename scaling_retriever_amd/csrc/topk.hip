@@ -30,11 +30,7 @@ __global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, i
 // ---------------------------------------------------------- segment gather ---
 // Segmented candidate slots (common.h TopkWS): one workgroup per query appends every segment's survivors behind the nc
 // atomically appended candidates, updates cand_count and clears the segment counts for the next launch.  Sources (the
-// buffer's tail) and destinations (its head) are disjoint.  A kernel of its own, launched in front of topk_compact_kernel:
-// folded into that kernel (round 3, first version) the compaction produced wrong results and out-of-range writes once in a
-// few hundred launches EVEN with the segment code switched off (same source lines, executed or not: a code generation
-// problem this round could not pin down; tools/micro/exact_stress_plain.py with SR_COMPACT_SEGKERNEL was the A/B) - the
-// compaction kernel is therefore byte for byte round 2's.
+// buffer's tail) and destinations (its head) are disjoint.  Launched in front of topk_compact_kernel.
 __global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
                                                                    int64_t cand_cap, unsigned char* __restrict__ seg_cnt, int seg_n,
                                                                    int64_t seg_off) {
@@ -118,6 +114,11 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
                 tau[q] = sr_key_score(m);
             }
         }
+        // every wave has read cand_count[q] and run_count[q] before one thread publishes the new values: the waves of a
+        // workgroup do not start together, and without this barrier a late wave could read the counts thread 0 had already
+        // rewritten (round 3: one in ~10^7 workgroups, first seen as wild writes when the run_count load became a slower
+        // vector load; the torn wave ran the select alone on LDS nobody had initialised - DESIGN.md section 0)
+        __syncthreads();
         if (tid == 0) {
             run_count[q] = n;
             cand_count[q] = 0;

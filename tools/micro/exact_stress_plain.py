@@ -16,6 +16,8 @@ for r0 in range(0, N, 1 << 20):
 Q = torch.empty((nq, H), dtype=torch.float32, device=dev).normal_(0.0, 0.5 / H ** 0.5, generator=g)
 Dsum0 = [D[r0:r0 + (1 << 20)].double().sum().item() for r0 in range(0, N, 1 << 20)]
 Qsum0 = Q.double().sum().item()
+DUMP = os.environ.get('DUMP') == '1'
+D0 = D[:1 << 20].clone() if DUMP else None      # to show WHAT was written where if block 0 is corrupted
 index = DenseIndexHIP(H, device=dev)
 index.add_device_rows(D)
 ref = None
@@ -28,6 +30,16 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
         print("iteration", it, ":", bad.numel(), "queries differ", bad.tolist()[:10], flush=True)
 Dsum1 = [D[r0:r0 + (1 << 20)].double().sum().item() for r0 in range(0, N, 1 << 20)]
 print("done; 1M-row blocks of D that changed:", [b for b in range(len(Dsum0)) if Dsum0[b] != Dsum1[b]], "| Q unchanged:", Q.double().sum().item() == Qsum0, flush=True)
+if DUMP:
+    Di, D0i = D[:1 << 20].view(torch.int32), D0.view(torch.int32)
+    rows = torch.cat([(Di[r0:r0 + 65536] != D0i[r0:r0 + 65536]).any(1).nonzero()[:, 0] + r0 for r0 in range(0, 1 << 20, 65536)])
+    print("D base 0x%x; rows of block 0 with changed words: %d: %s" % (D.data_ptr(), rows.numel(), rows.tolist()[:20]), flush=True)
+    shown = 0
+    for r in rows.tolist()[:8]:
+        cols = (Di[r] != D0i[r]).nonzero()[:, 0].tolist()
+        print("  row %d: %d changed words, columns %s" % (r, len(cols), cols[:12]), flush=True)
+        for c in cols[:16]:
+            print("    byte offset 0x%x: 0x%08x -> 0x%08x" % ((r * H + c) * 4, D0i[r, c].item() & 0xffffffff, Di[r, c].item() & 0xffffffff), flush=True)
 import ctypes
 out = (ctypes.c_uint64 * 2)()
 if hasattr(L.load(), "sr_debug_counters"):
