@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __r
 
 // ---------------------------------------------------------------- compact ---
 // One workgroup (256 threads) per query.  run_keys has 2k slots per query.
+#define TOPK_SEL_R 28        // keys per thread the select keeps in registers (unions of up to 7168 keys; 120 VGPRs = 4 workgroups per CU)
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
                                                            int* __restrict__ cand_count, int k, int64_t cand_cap) {
@@ -126,39 +127,79 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
         return;
     }
 
-    // radix select (MSB first, 8 bits per pass) of the k-th largest key of the union
+    // radix select (MSB first, 8 bits per pass) of the k-th largest key of the union.  One selecting workgroup holds up the whole
+    // launch, and its time is memory latency: the union (up to 2k + a launch's survivors, ~50 KB) read from L2 / HBM once per
+    // pass, a key per trip, took ~60 us; a union of at most 256 x TOPK_SEL_R keys is now read ONCE into registers (independent
+    // loads in flight together) and every pass works from there (~15 us); a larger one re-reads it per pass, 8 loads in flight.
+    const bool in_regs = n <= 256 * TOPK_SEL_R;
+    uint64_t kreg[TOPK_SEL_R];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < TOPK_SEL_R; ++j) {
+            const int i = tid + 256 * j;
+            kreg[j] = i < n ? (i < nr ? run[i] : cand[i - nr]) : 0ull;
+        }
+    }
+    // the leading bytes of a query's keys (sign, exponent, first mantissa bits of scores that lie close together) are mostly ONE
+    // value: 64 adds to one LDS word would run one after another, so a wave whose keys agree adds once
+#define TOPK_HIST_ADD(key)                                                                            \
+    do {                                                                                              \
+        const int bin_ = (int)(((key) >> shift) & 255);                                               \
+        const int b0_ = __builtin_amdgcn_readfirstlane(bin_);                                         \
+        const unsigned long long act_ = __ballot(1), same_ = __ballot(bin_ == b0_);                   \
+        if (same_ == act_) {                                                                          \
+            if ((tid & 63) == __ffsll((long long)act_) - 1) atomicAdd(&hist[b0_], __popcll(act_));    \
+        } else {                                                                                      \
+            atomicAdd(&hist[bin_], 1);                                                                \
+        }                                                                                             \
+    } while (0)
     uint64_t prefix = 0;
     int remaining = k;
     for (int pass = 7; pass >= 0; --pass) {
         const int shift = pass * 8;
         hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const uint64_t key = i < nr ? run[i] : cand[i - nr];
-            if (pass == 7 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < TOPK_SEL_R; ++j)
+                if (tid + 256 * j < n && (pass == 7 || (kreg[j] >> (shift + 8)) == prefix)) TOPK_HIST_ADD(kreg[j]);
+        } else {
+            for (int i0 = tid; i0 < n; i0 += 256 * 8) {
+                uint64_t keys[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 256;
+                    keys[u] = i < n ? (i < nr ? run[i] : cand[i - nr]) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * 256 < n && (pass == 7 || (keys[u] >> (shift + 8)) == prefix)) TOPK_HIST_ADD(keys[u]);
+            }
         }
         __syncthreads();
-        // inclusive suffix sum: scan[b] = sum_{b' >= b} hist[b']
-        int v = hist[tid];
-        scan[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            int add = (tid + off < 256) ? scan[tid + off] : 0;
-            __syncthreads();
-            v += add;
-            scan[tid] = v;
-            __syncthreads();
+        // suffix sums of the 256 bins, s = sum_{b >= tid} hist[b]: inside a wave by shuffles, across the four waves through four
+        // LDS words (4 barriers per pass; the 8-step LDS scan this replaces took 21)
+        const int c = hist[tid];
+        int s = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(s, off);
+            if ((tid & 63) + off < 64) s += o;
         }
-        const int above = (tid == 255) ? 0 : scan[tid + 1];
-        if (v >= remaining && above < remaining) {
+        if ((tid & 63) == 0) scan[tid >> 6] = s;
+        __syncthreads();
+        for (int w = (tid >> 6) + 1; w < 4; ++w) s += scan[w];
+        const int above = s - c;
+        if (s >= remaining && above < remaining) {       // exactly one bin: an empty bin has s == above
             ctrl[0] = tid;
             ctrl[1] = remaining - above;
         }
         __syncthreads();
         prefix = (prefix << 8) | (uint64_t)ctrl[0];
         remaining = ctrl[1];
-        __syncthreads();
+        // no barrier here: the next pass rewrites hist after these reads of it (two barriers back), scan[] two barriers and
+        // ctrl[] three barriers further on
     }
+#undef TOPK_HIST_ADD
     const uint64_t T = prefix;  // the k-th largest key (keys are unique)
 
     if (tid == 0) {
@@ -169,21 +210,74 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
     // the k keys >= T end up in run[0, k): slots there that are empty or hold a smaller key are holes, filled from the
     // kept keys of run[k, nr) and of the candidates
     const int extra = nr > k ? nr - k : 0;
-    for (int i = tid; i < k; i += 256) {
-        const bool hole = (i >= nr) || (run[i] < T);
-        if (hole) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;
-    }
-    for (int i = tid; i < extra; i += 256) {
-        if (run[k + i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)i;
-    }
-    for (int i = tid; i < nc; i += 256) {
-        if (cand[i] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(extra + i);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < TOPK_SEL_R; ++j) {
+            const int i = tid + 256 * j;
+            if (i < n) {
+                const bool keep = kreg[j] >= T;
+                if (i < nr) {
+                    if (i < k) {
+                        if (!keep) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;
+                    } else if (keep) {
+                        filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(i - k);
+                    }
+                } else if (keep) {
+                    filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(extra + i - nr);
+                }
+            }
+        }
+        for (int i = nr + tid; i < k; i += 256) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;      // empty slots (nr < k)
+    } else {
+        for (int i0 = tid; i0 < k; i0 += 256 * 4) {
+            uint64_t keys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                keys[u] = i < k && i < nr ? run[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < k && (i >= nr || keys[u] < T)) hole_pos[atomicAdd(&ctrl[2], 1)] = (uint32_t)i;
+            }
+        }
+        for (int i0 = tid; i0 < extra; i0 += 256 * 4) {
+            uint64_t keys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) keys[u] = i0 + u * 256 < extra ? run[k + i0 + u * 256] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < extra && keys[u] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(i0 + u * 256);
+        }
+        for (int i0 = tid; i0 < nc; i0 += 256 * 4) {
+            uint64_t keys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) keys[u] = i0 + u * 256 < nc ? cand[i0 + u * 256] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < nc && keys[u] >= T) filler_idx[atomicAdd(&ctrl[3], 1)] = (uint32_t)(extra + i0 + u * 256);
+        }
     }
     __syncthreads();
     const int nf = ctrl[3] < ctrl[2] ? ctrl[3] : ctrl[2];  // equal by construction
-    for (int j = tid; j < nf; j += 256) {
-        const uint32_t f = filler_idx[j];
-        run[hole_pos[j]] = f < (uint32_t)extra ? run[k + f] : cand[f - (uint32_t)extra];
+    for (int j0 = tid; j0 < nf; j0 += 256 * 4) {             // sources lie at or above slot k, holes below it; 4 loads in flight
+        uint64_t v[4];
+        uint32_t hp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256;
+            v[u] = 0ull;
+            hp[u] = 0u;
+            if (j < nf) {
+                const uint32_t f = filler_idx[j];
+                hp[u] = hole_pos[j];
+                v[u] = f < (uint32_t)extra ? run[k + f] : cand[f - (uint32_t)extra];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u * 256 < nf) run[hp[u]] = v[u];
     }
     if (tid == 0) {
         run_count[q] = k;

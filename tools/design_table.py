@@ -48,7 +48,9 @@ c5 = r.get("config5_8b")
 if c5:
     row("corpus encode, 8B dims (configs[4], one GPU)", f"{c5['encode']['value']:.0f} passages/s = {c5['encode']['roofline']['frac']:.3f} of peak; score stage over the GPU's 1/8 shard at H 4096 through the exact "
         f"kernel: {c5['score_shard']['queries_per_s']:.0f} queries/s ({c5['score_shard']['roofline']['frac']:.3f} of fp32 MFMA peak); one query {c5['score_shard_one_query']['ms']} ms "
-        f"({c5['score_shard_one_query']['roofline']['achieved'] / 1e3:.2f} TB/s)")
+        f"({c5['score_shard_one_query']['roofline']['achieved'] / 1e3:.2f} TB/s)"
+        + (f"; the same shard through the certified filter: **{c5['score_shard_filtered']['queries_per_s']:.0f} queries/s** ({c5['score_shard_filtered']['ms']} ms, "
+           f"{c5['score_shard_filtered']['queries_redone_by_exact_kernel']} queries re-done), bit-identical to the exact kernel" if c5.get("score_shard_filtered") else ""))
 for sb in r.get("small_batch") or []:
     row(f"small-batch dense score, nq = {sb['nq']} (HBM-bound, `dense_stream_kernel`)", f"{sb['achieved'] / 1e3:.2f} TB/s = {sb['frac']:.2f} of the 8 TB/s spec ({sb['ms_per_search']} ms per pass)")
 sp = r.get("sparse")
