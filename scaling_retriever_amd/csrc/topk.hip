@@ -28,44 +28,46 @@ __global__ void topk_reset_kernel(int* run_count, int* cand_count, float* tau, i
 }
 
 // ---------------------------------------------------------- segment gather ---
-// Segmented candidate slots (common.h TopkWS): one workgroup per query appends every segment's survivors behind the nc
-// atomically appended candidates, updates cand_count and clears the segment counts for the next launch.  Sources (the
-// buffer's tail) and destinations (its head) are disjoint.  Launched in front of topk_compact_kernel.
+// Segmented candidate slots (common.h TopkWS): every segment's survivors are appended behind the nc atomically appended
+// candidates of the query, cand_count is updated and the segment counts are cleared for the next launch.  Sources (the
+// buffer's tail, from seg_off) and destinations (its head) are disjoint.  Launched in front of topk_compact_kernel.
+// One WAVE per query (4 queries per workgroup, no barriers, no LDS): a workgroup per query spent its time in two barriers
+// and 3.4 rounds of workgroups over the chip for ~30 keys of work (18-25 us per launch, now one round).
 __global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __restrict__ cand_keys, int* __restrict__ cand_count,
                                                                    int64_t cand_cap, unsigned char* __restrict__ seg_cnt, int seg_n,
-                                                                   int64_t seg_off) {
-    __shared__ int wave_tot[4];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    int nc = cand_count[q];
-    uint64_t* cbuf = cand_keys + (int64_t)q * cand_cap;
-    uint32_t* cw = reinterpret_cast<uint32_t*>(seg_cnt + (int64_t)q * seg_n);      // seg_n is a multiple of 4
-    for (int w0 = 0; w0 < seg_n / 4; w0 += 256) {
-        const int wi = w0 + tid;
-        const uint32_t word = wi < seg_n / 4 ? cw[wi] : 0u;
+                                                                   int64_t seg_off, int64_t nq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;                                  // wave-uniform
+    int nc = cand_count[q];                               // read and rewritten by this wave only
+    uint64_t* cbuf = cand_keys + q * cand_cap;
+    uint32_t* cw = reinterpret_cast<uint32_t*>(seg_cnt + q * seg_n);      // seg_n is a multiple of 4
+    const int n_words = seg_n / 4;
+    uint32_t next = lane < n_words ? cw[lane] : 0u;
+    for (int w0 = 0; w0 < n_words; w0 += 64) {
+        const int wi = w0 + lane;
+        const uint32_t word = next;
+        next = wi + 64 < n_words ? cw[wi + 64] : 0u;      // the next round's counts are on their way during this round's copies
         const int c[4] = {(int)(word & 255u), (int)((word >> 8) & 255u), (int)((word >> 16) & 255u), (int)(word >> 24)};
         const int mine = c[0] + c[1] + c[2] + c[3];
-        int v = mine;                               // inclusive prefix inside the wave
+        int v = mine;                                     // inclusive prefix inside the wave
         for (int off = 1; off < 64; off <<= 1) {
             const int o = __shfl_up(v, off);
-            if ((tid & 63) >= off) v += o;
+            if (lane >= off) v += o;
         }
-        __syncthreads();                            // the previous round's totals have been read
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
-        __syncthreads();
+        const int total = __shfl(v, 63);
         int base = nc + v - mine;
-        for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
-        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         if (mine) {
             for (int e = 0; e < 4; ++e)
-                for (int n = 0; n < c[e]; ++n) {
-                    if (base < seg_off) cbuf[base] = cbuf[seg_off + ((int64_t)wi * 4 + e) * SR_SEG_P + n];
+                for (int j = 0; j < c[e]; ++j) {
+                    if (base < seg_off) cbuf[base] = cbuf[seg_off + ((int64_t)wi * 4 + e) * SR_SEG_P + j];
                     ++base;
                 }
             cw[wi] = 0u;
         }
         nc += total;
     }
-    if (tid == 0) cand_count[q] = nc < seg_off ? nc : (int)seg_off;
+    if (lane == 0) cand_count[q] = nc < seg_off ? nc : (int)seg_off;
 }
 
 // ---------------------------------------------------------------- compact ---
@@ -420,8 +422,8 @@ int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
     if (nq == 0) return SR_OK;
     const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
     if (ws.seg_n > 0) {
-        hipLaunchKernelGGL(topk_gather_segments_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.cand_keys, ws.cand_count, ws.cand_cap,
-                           ws.seg_cnt, ws.seg_n, ws.seg_off);
+        hipLaunchKernelGGL(topk_gather_segments_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, ws.cand_keys, ws.cand_count,
+                           ws.cand_cap, ws.seg_cnt, ws.seg_n, ws.seg_off, nq);
         SR_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
