@@ -9,8 +9,15 @@
 //    8192 x 8192 x 16384  0.388 / 0.407   (32 k-steps per tile -> 256: prologue and epilogue amortised, this is the k-loop)
 // i.e. as written the 4-wave loop reaches 0.41 where the shipped 8-wave loops reach 0.51: with ONE wave per SIMD every wait for an
 // LDS-DMA piece or at the k-step barrier idles that SIMD's MFMA pipe, which the second resident wave of the 8-wave layout covers.
-// Lower LDS traffic alone does not pay; the layout needs deeper static pipelining (LDS-DMA issued per half stage, two k-steps
-// ahead) before it can - round 4 material.
+// Where the time goes (8192 x 8192 x 16384; variants 2-5 are timing diagnostics with wrong results):
+//   4: the MFMAs alone                                   0.758   <- what this chip sustains on the 32x32x16 pipe at all
+//   5: + the fragment reads out of LDS                   0.622
+//   3: + the LDS-DMA of the next k-step (no waits)       0.47
+//   2: + the k-step barrier                              0.41    (1: + the wait for the LDS-DMA pieces: no further change)
+// so the barrier costs 0.06, the LDS-DMA stream 0.15 and the fragment reads 0.14 - none of it waiting for memory.  The conflict-free
+// swizzle for 128-byte rows ((row >> 1) & 7 instead of row & 7) changes nothing: bank conflicts are not what the reads cost.
+// Lower LDS traffic alone does not pay; with one wave per SIMD the loop needs one operand to bypass LDS (direct global -> VGPR
+// fragments) or a second resident wave - round 4 material.
 // build: hipcc --offload-arch=gfx950 -O3 -o gemm4w gemm4w.hip ; run: ./gemm4w [M N K [variant]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,6 +35,9 @@ typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;      // 64 KB
+#ifndef SWZ
+#define SWZ(row) (((row) >> 1) & 7)      // 128-byte rows: a 16-lane group of a ds_read_b128 (16 consecutive rows, one k-chunk) then covers all 16 bank groups;
+#endif                                   // (row & 7) leaves rows r and r + 8 on the same one (2-way conflict)
 
 template <int VARIANT>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
@@ -41,11 +51,12 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __
     const int tm = swz / tiles_n, tn = swz % tiles_n;
     const int64_t a_base = (int64_t)tm * BM * K, b_base = (int64_t)tn * BN * K;
 
-    const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
+    const int srow = lane >> 3;
     int aoff[8], boff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = wave * 64 + i * 8 + srow;
+        const int schunk = (lane & 7) ^ SWZ(r);
         aoff[i] = r * K + schunk * 8;
         boff[i] = r * K + schunk * 8;
     }
@@ -85,8 +96,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int ra = wm * 128 + i * 32 + frow, rb = wn * 128 + i * 32 + frow;
-                    af[i] = *reinterpret_cast<const bf16x8*>(at + ra * 128 + (((kk * 2 + fk) ^ (ra & 7)) * 16));
-                    bfr[i] = *reinterpret_cast<const bf16x8*>(bt + rb * 128 + (((kk * 2 + fk) ^ (rb & 7)) * 16));
+                    af[i] = *reinterpret_cast<const bf16x8*>(at + ra * 128 + (((kk * 2 + fk) ^ SWZ(ra)) * 16));
+                    bfr[i] = *reinterpret_cast<const bf16x8*>(bt + rb * 128 + (((kk * 2 + fk) ^ SWZ(rb)) * 16));
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -105,8 +116,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ra = wm * 128 + i * 32 + frow, rb = wn * 128 + i * 32 + frow;
-                xa[i] = *reinterpret_cast<const bf16x8*>(at + ra * 128 + (((kk * 2 + fk) ^ (ra & 7)) * 16));
-                xb[i] = *reinterpret_cast<const bf16x8*>(bt + rb * 128 + (((kk * 2 + fk) ^ (rb & 7)) * 16));
+                xa[i] = *reinterpret_cast<const bf16x8*>(at + ra * 128 + (((kk * 2 + fk) ^ SWZ(ra)) * 16));
+                xb[i] = *reinterpret_cast<const bf16x8*>(bt + rb * 128 + (((kk * 2 + fk) ^ SWZ(rb)) * 16));
             }
         };
 #define MMA_ALL(SET)                                                                                                      \
@@ -121,6 +132,18 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __
         load_frags(0, 0, fa[0], fb[0]);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (VARIANT >= 4) {          // timing diagnostics (wrong results): 4 = MFMAs only, 5 = MFMAs + fragment reads, no LDS-DMA
+                if constexpr (VARIANT == 5) load_frags(buf, 1, fa[1], fb[1]);
+                MMA_ALL(0)
+                if constexpr (VARIANT == 5) load_frags(buf, 2, fa[0], fb[0]);
+                MMA_ALL(1)
+                if constexpr (VARIANT == 5) load_frags(buf, 3, fa[1], fb[1]);
+                MMA_ALL(0)
+                if constexpr (VARIANT == 5) load_frags(buf ^ 1, 0, fa[0], fb[0]);
+                MMA_ALL(1)
+                buf ^= 1;
+                continue;
+            }
             load_frags(buf, 1, fa[1], fb[1]);
             MMA_ALL(0)
 #pragma unroll
@@ -140,8 +163,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const unsigned short* __
             SGB(0x008, 8, 2);
             __builtin_amdgcn_sched_barrier(0);
             // k-step kt + 1 has landed (every wave waits for its own pieces, then the barrier); all reads of `buf` are done
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (VARIANT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 2, 3: timing diagnostics, wrong results
+            if constexpr (VARIANT != 3) __syncthreads();
             if (kt + 1 < nk) load_frags(buf ^ 1, 0, fa[0], fb[0]);
             if (kt + 2 < nk) stage(buf, (kt + 2) * BK);
             MMA_ALL(1)
@@ -188,10 +211,18 @@ int main(int argc, char** argv) {
     const int tiles_n = N / BN, grid = (M / BM) * tiles_n;
     CK(hipFuncSetAttribute((const void*)gemm4w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int variant = argc > 4 ? atoi(argv[4]) : 1;
     auto launch = [&]() {
         if (variant == 0) hipLaunchKernelGGL(gemm4w_kernel<0>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
-        else hipLaunchKernelGGL(gemm4w_kernel<1>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
+        else if (variant == 1) hipLaunchKernelGGL(gemm4w_kernel<1>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
+        else if (variant == 2) hipLaunchKernelGGL(gemm4w_kernel<2>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
+        else if (variant == 3) hipLaunchKernelGGL(gemm4w_kernel<3>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
+        else if (variant == 4) hipLaunchKernelGGL(gemm4w_kernel<4>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
+        else hipLaunchKernelGGL(gemm4w_kernel<5>, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, tiles_n);
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
