@@ -1,3 +1,4 @@
+"""What the host BLAS behind numpy / torch is and how its sgemm rate moves with the thread count (the CPU baseline picks the best)."""
 import time, os, numpy as np, torch
 from threadpoolctl import threadpool_info, threadpool_limits
 print([ (d.get('internal_api'), d.get('num_threads'), d.get('filepath','')[-40:]) for d in threadpool_info()])

@@ -1,3 +1,6 @@
+"""Repeat one exact (plain fp32) search N times on a fixed corpus and compare every result with the first; reports which 1M-row
+blocks of the corpus changed (a wild write) and, with DUMP=1, what was written where.  The A/B harness of the round-3 compaction
+race: SR_HIP_LIB=<variant .so> N_DOCS=2000000 python3 tools/micro/exact_stress_plain.py 300"""
 import os, sys
 import torch
 import subprocess
