@@ -3,12 +3,17 @@
 //   variant 1: the N-side operand (4 fragments per k32 and wave) loaded straight from global memory into registers, one k-step
 //              ahead; only the M side goes through LDS: 160 KB of LDS traffic per k-step instead of 256 KB
 //   variant 2: as 1 with the N-side operand packed in fragment order (a wave's load is one contiguous KB)
+//   variant 3: packed, one register set per k32 half (see the measurements below)
 // Same schedule in all, so the difference is the data path.
 // Measured (8192 x 8192 x 16384): variant 0 0.436 of 2.5 PFLOP/s (the shipped loops' tuned schedule reaches 0.51 on the same data path);
 // variants 1 / 2 0.141 / 0.101 - NOT a verdict on the data path: 128 accumulators + two prefetch sets of the direct operand (64) +
 // fragments + addresses exceed the 256 registers a wave has at two waves per SIMD, hipcc spills 190-250 bytes per lane inside the
-// k-loop (scratch_load / scratch_store between the MFMAs) and everything waits on that.  A direct operand needs either a 64-column
-// wave tile (half the accumulators) or one prefetch set filled half a k-step ahead - untested.  build: hipcc --offload-arch=gfx950 -O3 -o gemm8w gemm8w.hip
+// k-loop (scratch_load / scratch_store between the MFMAs) and everything waits on that.
+//   variant 3: ONE register set per k32 half of the (packed) direct operand, refilled right behind the MFMAs that consumed it,
+//              counted vmcnt waits: 196 registers, no spills, correct: 0.433 against variant 0's 0.430 in the same run - the direct
+//              operand costs nothing even half a k-step ahead, and with this minimal schedule it gains nothing either: 37 % less LDS
+//              traffic is not what this schedule waits for.  Whether it pays under the shipped loops' pinned schedule (0.51) is
+//              the open question for round 4.  build: hipcc --offload-arch=gfx950 -O3 -o gemm8w gemm8w.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +83,51 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = K / BK;
     stage(0, 0);
-    if constexpr (VARIANT >= 1) gload(0, 0);
+    if constexpr (VARIANT == 1 || VARIANT == 2) gload(0, 0);
+    if constexpr (VARIANT == 3) {
+        // one register set per k32 half of the direct operand (packed layout), each refilled right after the MFMAs that consumed it
+        // were issued: 32 registers instead of 64; counted vmcnt waits (issue order per k-step: nh[1] refill, LDS-DMA, nh[0] refill)
+        bf16x8 nh[2][4];
+        auto gl = [&](int kk, int k0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nh[kk][j] = *reinterpret_cast<const bf16x8*>(Bp + ((((int64_t)(tn * 16 + wm * 4 + j)) * (K / 32) + (k0 / 32 + kk)) * 64 + lane) * 8);
+        };
+        auto mma_half = [&](const unsigned char* at, int kk) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 mf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wn * 128 + (h * 4 + i) * 16 + frow;
+                    mf[i] = *reinterpret_cast<const bf16x8*>(at + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf[i], nh[kk][j], acc[h * 4 + i][j], 0, 0, 0);
+            }
+        };
+        // prologue (stage(0) is already issued above): nh[0], nh[1] of k-step 0
+        gl(0, 0);
+        gl(1, 0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // outstanding, oldest first: LDS-DMA(kt) x4, nh[0](kt) x4, nh[1](kt) x4 -> the first two groups must have landed
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+            const unsigned char* at = smem + buf * STAGE_BYTES;
+            mma_half(at, 0);
+            if (kt + 1 < nk) gl(0, (kt + 1) * BK);
+            // outstanding: nh[1](kt) x4, LDS-DMA(kt + 1) x4, nh[0](kt + 1) x4 -> nh[1](kt) must have landed
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            mma_half(at, 1);
+            if (kt + 1 < nk) gl(1, (kt + 1) * BK);
+            buf ^= 1;
+        }
+    } else {
     // two k-steps per trip so that the register sets of the direct operand are indexed statically (a run-time index would put
     // them in scratch memory); nk is even
 #define KSTEP(KT, CUR, NXT)                                                                                               \
@@ -118,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
         KSTEP(kt + 1, 1, 0)
     }
 #undef KSTEP
+    }
     // element (row = 4 (lane / 16) + r, col = lane % 16) of each 16 x 16 block
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -162,10 +212,12 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
+    CK(hipFuncSetAttribute((const void*)gemm8w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
     auto launch = [&]() {
         if (variant == 0) hipLaunchKernelGGL(gemm8w_kernel<0>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
         else if (variant == 1) hipLaunchKernelGGL(gemm8w_kernel<1>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
-        else hipLaunchKernelGGL(gemm8w_kernel<2>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
+        else if (variant == 2) hipLaunchKernelGGL(gemm8w_kernel<2>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
+        else hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
