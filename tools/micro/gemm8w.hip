@@ -5,15 +5,15 @@
 //   variant 2: as 1 with the N-side operand packed in fragment order (a wave's load is one contiguous KB)
 //   variant 3: packed, one register set per k32 half (see the measurements below)
 // Same schedule in all, so the difference is the data path.
-// Measured (8192 x 8192 x 16384): variant 0 0.436 of 2.5 PFLOP/s (the shipped loops' tuned schedule reaches 0.51 on the same data path);
-// variants 1 / 2 0.141 / 0.101 - NOT a verdict on the data path: 128 accumulators + two prefetch sets of the direct operand (64) +
-// fragments + addresses exceed the 256 registers a wave has at two waves per SIMD, hipcc spills 190-250 bytes per lane inside the
-// k-loop (scratch_load / scratch_store between the MFMAs) and everything waits on that.
-//   variant 3: ONE register set per k32 half of the (packed) direct operand, refilled right behind the MFMAs that consumed it,
-//              counted vmcnt waits: 196 registers, no spills, correct: 0.433 against variant 0's 0.430 in the same run - the direct
-//              operand costs nothing even half a k-step ahead, and with this minimal schedule it gains nothing either: 37 % less LDS
-//              traffic is not what this schedule waits for.  Whether it pays under the shipped loops' pinned schedule (0.51) is
-//              the open question for round 4.  build: hipcc --offload-arch=gfx950 -O3 -o gemm8w gemm8w.hip
+//   variant 4 / 5: the shipped loops' pinned four-phase schedule, both operands through LDS / the N side direct (as variant 3)
+// run: ./gemm8w M N K variant [krep]   (krep > 1: the timing pass walks the k range krep times without the epilogue stores, so that
+// the operands stay L2-resident and the k-loop is compute-bound: 8192 x 8192 x 16384 streams 8.9 GB per GEMM and is HBM-limited at ~0.43)
+// Measured, 8192 x 8192 x 2048 with krep 8 (fraction of 2.5 PFLOP/s; all variants validated against the host on 2000 samples):
+//   0: minimal schedule, LDS both     0.516        4: pinned schedule, LDS both     0.520   <- the shipped loops' 0.51 reproduced
+//   3: minimal schedule, direct N     0.493        5: pinned schedule, direct N     0.517
+//   1 / 2 (two prefetch sets): 190-250 bytes of spills per lane inside the k-loop, 0.10-0.14
+// i.e. taking a third of the LDS traffic away changes NOTHING: LDS bandwidth is not what holds the 8-wave loop at ~0.52 (nor are
+// bank conflicts, gemm4w.hip).  The MFMAs alone sustain 0.76 (gemm4w.hip variant 4); what separates 0.52 from that is not bytes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -33,8 +33,8 @@ constexpr int BM = 256, BN = 256, BK = 64;
 
 template <int VARIANT>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                                        unsigned short* __restrict__ C, int M, int N, int K, int tiles_n, const unsigned short* __restrict__ Bp) {
-    constexpr int STAGE_BYTES = (VARIANT == 0 ? BM + BN : BM) * BK * 2;
+                                                        unsigned short* __restrict__ C, int M, int N, int K, int tiles_n, const unsigned short* __restrict__ Bp, int do_store, int krep) {
+    constexpr int STAGE_BYTES = ((VARIANT == 0 || VARIANT == 4) ? BM + BN : BM) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wm = wave & 3;                       // M halves of 128 rows x N quarters of 64 columns
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void_ptr)(A + a_base + k0 + aoff[i]), (lds_void_ptr)(ab + i * 1024), 16, 0, 0);
-        if constexpr (VARIANT == 0) {
+        if constexpr (VARIANT == 0 || VARIANT == 4) {
             unsigned char* bb = smem + st * STAGE_BYTES + BM * 128 + (wave * 32) * 128;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -81,9 +81,98 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;
+    const int nk1 = K / BK, nk = nk1 * krep;      // krep > 1 (timing only): the k range walked krep times, operands L2-resident
+#define KOF(KT) (((KT) % nk1) * BK)
     stage(0, 0);
     if constexpr (VARIANT == 1 || VARIANT == 2) gload(0, 0);
+    if constexpr (VARIANT == 4 || VARIANT == 5) {
+        // the shipped loops' schedule (dense_split.hip / gemm_bf16.hip): four phases of 16 MFMAs per k-step, fragments of the next
+        // phase read under the current one, one barrier per k-step, LDS-DMA of k-step kt + 2 behind it, issue order pinned.
+        // 4: both operands through LDS; 5: the N side (4 fragments per k32) straight from the packed copy, one register set per half
+        constexpr bool DIRECT = VARIANT == 5;
+        bf16x8 wx[4], wy[4], n0[4], n1[4];
+        auto load_w = [&](int st, int kk, int h, bf16x8 (&wf)[4]) {
+            const unsigned char* at = smem + st * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wn * 128 + (h * 4 + i) * 16 + frow;
+                wf[i] = *reinterpret_cast<const bf16x8*>(at + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
+            }
+        };
+        auto load_n = [&](int st, int kk, int k0, bf16x8 (&nf)[4]) {
+            if constexpr (DIRECT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    nf[j] = *reinterpret_cast<const bf16x8*>(Bp + ((((int64_t)(tn * 16 + wm * 4 + j)) * (K / 32) + (k0 / 32 + kk)) * 64 + lane) * 8);
+            } else {
+                const unsigned char* bt = smem + st * STAGE_BYTES + BM * 128;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wm * 64 + j * 16 + frow;
+                    nf[j] = *reinterpret_cast<const bf16x8*>(bt + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
+                }
+            }
+        };
+#define MMA_HALF(HH, WF, NF)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+            acc[(HH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], NF[j], acc[(HH) * 4 + i][j], 0, 0, 0);
+#define SGB(MASK, CNT, ID) __builtin_amdgcn_sched_group_barrier(MASK, CNT, ID)
+        // prologue: stage(0) was issued above; stage 1, then the first fragments
+        // issue order as in the steady state: n0, LDS-DMA, n1 (the counted waits below rely on it)
+        if constexpr (DIRECT) load_n(0, 0, 0, n0);
+        if (nk > 1) stage(1, KOF(1));
+        if constexpr (DIRECT) load_n(0, 1, 0, n1);
+        if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 landed
+        __syncthreads();
+        load_w(0, 0, 0, wx);
+        if constexpr (!DIRECT) load_n(0, 0, 0, n0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int k0 = KOF(kt), k1 = KOF(kt + 1), k2 = KOF(kt + 2);
+            // P0
+            load_w(buf, 0, 1, wy);
+            if constexpr (!DIRECT) load_n(buf, 1, k0, n1);
+            if constexpr (DIRECT) {      // n0 of this k-step (older than the last LDS-DMA and n1; in the last k-step only n1 is younger)
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            MMA_HALF(0, wx, n0)
+#pragma unroll
+            for (int i = 0; i < (DIRECT ? 4 : 8); ++i) { SGB(0x008, 1, 0); SGB(0x100, 1, 0); }
+            SGB(0x008, DIRECT ? 12 : 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // P1
+            load_w(buf, 1, 0, wx);
+            MMA_HALF(1, wy, n0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 1, 1); SGB(0x100, 1, 1); }
+            SGB(0x008, 12, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // P2 (n0 is free: its refill for the next k-step goes out here)
+            load_w(buf, 1, 1, wy);
+            if constexpr (DIRECT) { if (kt + 1 < nk) load_n(0, 0, k1, n0); }
+            if constexpr (DIRECT) { if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // n1 of this k-step and the LDS-DMA in front of it
+            MMA_HALF(0, wx, n1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 1, 2); SGB(0x100, 1, 2); }
+            SGB(0x008, 12, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // P3
+            if (kt + 1 < nk) {
+                load_w(buf ^ 1, 0, 0, wx);
+                if constexpr (!DIRECT) load_n(buf ^ 1, 0, k1, n0);
+            }
+            if (kt + 2 < nk) stage(buf, k2);
+            MMA_HALF(1, wy, n1)
+            if constexpr (DIRECT) { if (kt + 1 < nk) load_n(0, 1, k1, n1); }
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+#undef MMA_HALF
+#undef SGB
+    } else
     if constexpr (VARIANT == 3) {
         // one register set per k32 half of the direct operand (packed layout), each refilled right after the MFMAs that consumed it
         // were issued: 32 registers instead of 64; counted vmcnt waits (issue order per k-step: nh[1] refill, LDS-DMA, nh[0] refill)
@@ -117,14 +206,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
             // outstanding, oldest first: LDS-DMA(kt) x4, nh[0](kt) x4, nh[1](kt) x4 -> the first two groups must have landed
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+            if (kt + 1 < nk) stage(buf ^ 1, KOF(kt + 1));
             const unsigned char* at = smem + buf * STAGE_BYTES;
             mma_half(at, 0);
-            if (kt + 1 < nk) gl(0, (kt + 1) * BK);
+            if (kt + 1 < nk) gl(0, KOF(kt + 1));
             // outstanding: nh[1](kt) x4, LDS-DMA(kt + 1) x4, nh[0](kt + 1) x4 -> nh[1](kt) must have landed
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             mma_half(at, 1);
-            if (kt + 1 < nk) gl(1, (kt + 1) * BK);
+            if (kt + 1 < nk) gl(1, KOF(kt + 1));
             buf ^= 1;
         }
     } else {
@@ -135,8 +224,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
         __syncthreads();                                                                                                  \
         if ((KT) + 1 < nk) {                                                                                              \
-            stage(NXT, ((KT) + 1) * BK);                                                                                  \
-            if constexpr (VARIANT >= 1) gload(NXT, ((KT) + 1) * BK);                                                      \
+            stage(NXT, KOF((KT) + 1));                                                                                    \
+            if constexpr (VARIANT >= 1) gload(NXT, KOF((KT) + 1));                                                        \
         }                                                                                                                 \
         const unsigned char* at = smem + (CUR) * STAGE_BYTES;                                                             \
         const unsigned char* bt = at + BM * 128;                                                                          \
@@ -168,7 +257,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
     }
 #undef KSTEP
     }
-    // element (row = 4 (lane / 16) + r, col = lane % 16) of each 16 x 16 block
+    // element (row = 4 (lane / 16) + r, col = lane % 16) of each 16 x 16 block; do_store = 0 times the k-loop alone (the 2-byte
+    // scattered stores of this prototype's epilogue are slow), with one store that keeps the accumulators alive
+    if (!do_store) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 1234.5678f) C[0] = 1;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -207,28 +306,34 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dBp, hBp.size() * 2));
     CK(hipMemcpy(dBp, hBp.data(), hBp.size() * 2, hipMemcpyHostToDevice));
     const int variant = argc > 4 ? atoi(argv[4]) : 1;
-    const int lds = 2 * (variant == 0 ? BM + BN : BM) * BK * 2;
+    const int lds = 2 * ((variant == 0 || variant == 4) ? BM + BN : BM) * BK * 2;
     const int tiles_n = N / BN, grid = (M / BM) * tiles_n;
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
+    CK(hipFuncSetAttribute((const void*)gemm8w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
+    CK(hipFuncSetAttribute((const void*)gemm8w_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
+    int do_store = 1, krep = 1;
+    const int krep_timing = argc > 5 ? atoi(argv[5]) : 1;
     auto launch = [&]() {
-        if (variant == 0) hipLaunchKernelGGL(gemm8w_kernel<0>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
-        else if (variant == 1) hipLaunchKernelGGL(gemm8w_kernel<1>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
-        else if (variant == 2) hipLaunchKernelGGL(gemm8w_kernel<2>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
-        else hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp);
+        if (variant == 0) hipLaunchKernelGGL(gemm8w_kernel<0>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 1) hipLaunchKernelGGL(gemm8w_kernel<1>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 2) hipLaunchKernelGGL(gemm8w_kernel<2>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 3) hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 4) hipLaunchKernelGGL(gemm8w_kernel<4>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else hipLaunchKernelGGL(gemm8w_kernel<5>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 3; ++it) launch();
     CK(hipDeviceSynchronize());
     const int reps = 20;
+    float ms, ms_loop;
     CK(hipEventRecord(e0));
     for (int it = 0; it < reps; ++it) launch();
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
-    float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
@@ -242,7 +347,17 @@ int main(int argc, char** argv) {
         const double err = fabs(got - ref) / (fabs(ref) + 1.0);
         if (err > worst) worst = err;
     }
-    const double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12;
-    printf("gemm8w variant %d, %d x %d x %d: %.3f ms, %.1f TFLOP/s = %.3f of 2500; worst sampled relative error %.2e (bf16 output)\n", variant, M, N, K, ms, tf, tf / 2500.0, worst);
+    do_store = 0;
+    krep = krep_timing;
+    for (int it = 0; it < 3; ++it) launch();
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < reps; ++it) launch();
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    CK(hipEventElapsedTime(&ms_loop, e0, e1));
+    ms_loop /= reps;
+    const double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12, tfl = 2.0 * M * N * K * krep / (ms_loop * 1e-3) / 1e12;
+    printf("gemm8w variant %d, %d x %d x %d: %.3f ms, %.1f TFLOP/s = %.3f of 2500 (k-loop alone, no epilogue stores, k range walked %d times: %.3f); worst sampled relative error %.2e (bf16 output)\n",
+           variant, M, N, K, ms, tf, tf / 2500.0, krep, tfl / 2500.0, worst);
     return 0;
 }
