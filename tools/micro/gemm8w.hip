@@ -12,8 +12,16 @@
 //   0: minimal schedule, LDS both     0.516        4: pinned schedule, LDS both     0.520   <- the shipped loops' 0.51 reproduced
 //   3: minimal schedule, direct N     0.493        5: pinned schedule, direct N     0.517
 //   1 / 2 (two prefetch sets): 190-250 bytes of spills per lane inside the k-loop, 0.10-0.14
-// i.e. taking a third of the LDS traffic away changes NOTHING: LDS bandwidth is not what holds the 8-wave loop at ~0.52 (nor are
-// bank conflicts, gemm4w.hip).  The MFMAs alone sustain 0.76 (gemm4w.hip variant 4); what separates 0.52 from that is not bytes.
+//   6: pinned schedule, global_load_dwordx4 -> registers -> ds_write_b128 instead of LDS-DMA     0.484
+// Timing diagnostics of variant 4 (wrong results; variant code 40 + DIAG bits, see the kernel):
+//   no k-step barrier / wait 0.560    no fragment reads 0.566    NO LDS-DMA 0.693    no LDS-DMA + no barrier 0.703
+//   no LDS-DMA + no fragment reads 0.772    MFMAs only 0.778    half the LDS-DMA pieces 0.580    LDS-DMA with the nt policy 0.418
+//   LDS-DMA of a cache-hot source (k = 0 every step) 0.563
+// Reading: the MFMA pipe sustains 0.78 on this chip; fragment reads and the barrier cost 0.04 each; the operand DELIVERY costs 0.17
+// (proportional to the pieces issued, a third of it the L2 / fabric fetch), whichever way it is done - LDS-DMA (best), registers +
+// ds_write (0.484), or half of it as direct fragment loads (0.517: as many vector-memory instructions as before).  Delivered bytes per
+// flop are fixed by the 256 x 256 tile, and a larger tile does not fit the register file: ~0.52 is this chip's ceiling for a bf16
+// GEMM loop fed from memory, not a tuning gap of these kernels.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -31,10 +39,12 @@ typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 constexpr int BM = 256, BN = 256, BK = 64;
 #define SWZ(row) ((row) & 7)
 
-template <int VARIANT>
+// DIAG (variant 4 only, timing diagnostics with wrong results): bit 0 = no k-step barrier and no LDS-DMA wait, bit 1 = no LDS-DMA,
+// bit 2 = no fragment reads (the MFMAs run on whatever the registers hold)
+template <int VARIANT, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
                                                         unsigned short* __restrict__ C, int M, int N, int K, int tiles_n, const unsigned short* __restrict__ Bp, int do_store, int krep) {
-    constexpr int STAGE_BYTES = ((VARIANT == 0 || VARIANT == 4) ? BM + BN : BM) * BK * 2;
+    constexpr int STAGE_BYTES = ((VARIANT == 0 || VARIANT == 4 || VARIANT == 6) ? BM + BN : BM) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wm = wave & 3;                       // M halves of 128 rows x N quarters of 64 columns
@@ -51,16 +61,20 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
         aoff[i] = r * K + schunk * 8;
         boff[i] = r * K + schunk * 8;
     }
+    // DIAG bit 3: half of the LDS-DMA pieces, bit 4: nt policy on them, bit 5: every k-step stages k = 0 (the source stays cache-hot)
     auto stage = [&](int st, int k0) {
+        constexpr int NP = (DIAG & 8) ? 2 : 4;
+        constexpr int AUX = (DIAG & 16) ? 2 : 0;
+        if constexpr ((DIAG & 32) != 0) k0 = 0;
         unsigned char* ab = smem + st * STAGE_BYTES + (wave * 32) * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(A + a_base + k0 + aoff[i]), (lds_void_ptr)(ab + i * 1024), 16, 0, 0);
-        if constexpr (VARIANT == 0 || VARIANT == 4) {
+        for (int i = 0; i < NP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(A + a_base + k0 + aoff[i]), (lds_void_ptr)(ab + i * 1024), 16, 0, AUX);
+        if constexpr (VARIANT == 0 || VARIANT == 4 || VARIANT == 6) {
             unsigned char* bb = smem + st * STAGE_BYTES + BM * 128 + (wave * 32) * 128;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(B + b_base + k0 + boff[i]), (lds_void_ptr)(bb + i * 1024), 16, 0, 0);
+            for (int i = 0; i < NP; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(B + b_base + k0 + boff[i]), (lds_void_ptr)(bb + i * 1024), 16, 0, AUX);
         }
     };
     const int frow = lane & 15, fg = lane >> 4;
@@ -85,12 +99,31 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
 #define KOF(KT) (((KT) % nk1) * BK)
     stage(0, 0);
     if constexpr (VARIANT == 1 || VARIANT == 2) gload(0, 0);
-    if constexpr (VARIANT == 4 || VARIANT == 5) {
-        // the shipped loops' schedule (dense_split.hip / gemm_bf16.hip): four phases of 16 MFMAs per k-step, fragments of the next
-        // phase read under the current one, one barrier per k-step, LDS-DMA of k-step kt + 2 behind it, issue order pinned.
-        // 4: both operands through LDS; 5: the N side (4 fragments per k32) straight from the packed copy, one register set per half
-        constexpr bool DIRECT = VARIANT == 5;
+    if constexpr (VARIANT == 6) {
+        // the pinned schedule with the classic staging: global_load_dwordx4 into registers (issued behind the k-step barrier), written
+        // to LDS by ds_write_b128 one k-step later (in front of the next barrier) - no LDS-DMA
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         bf16x8 wx[4], wy[4], n0[4], n1[4];
+        u32x4 ga[4], gb[4];
+        const int c8 = lane & 7;
+        auto gfetch = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 32 + i * 8 + srow;
+                ga[i] = *reinterpret_cast<const u32x4*>(A + a_base + (int64_t)r * K + k0 + c8 * 8);
+                gb[i] = *reinterpret_cast<const u32x4*>(B + b_base + (int64_t)r * K + k0 + c8 * 8);
+            }
+        };
+        auto lstore = [&](int st) {
+            unsigned char* at = smem + st * STAGE_BYTES;
+            unsigned char* bt = at + BM * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 32 + i * 8 + srow;
+                *reinterpret_cast<u32x4*>(at + r * 128 + ((c8 ^ SWZ(r)) * 16)) = ga[i];
+                *reinterpret_cast<u32x4*>(bt + r * 128 + ((c8 ^ SWZ(r)) * 16)) = gb[i];
+            }
+        };
         auto load_w = [&](int st, int kk, int h, bf16x8 (&wf)[4]) {
             const unsigned char* at = smem + st * STAGE_BYTES;
 #pragma unroll
@@ -99,7 +132,87 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
                 wf[i] = *reinterpret_cast<const bf16x8*>(at + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
             }
         };
+        auto load_n = [&](int st, int kk, bf16x8 (&nf)[4]) {
+            const unsigned char* bt = smem + st * STAGE_BYTES + BM * 128;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wm * 64 + j * 16 + frow;
+                nf[j] = *reinterpret_cast<const bf16x8*>(bt + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
+            }
+        };
+#define MMA_HALF(HH, WF, NF)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+            acc[(HH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], NF[j], acc[(HH) * 4 + i][j], 0, 0, 0);
+#define SGB(MASK, CNT, ID) __builtin_amdgcn_sched_group_barrier(MASK, CNT, ID)
+        // prologue (stage(0) by LDS-DMA was issued above and is simply waited for): k-step 1 goes through the registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nk > 1) gfetch(KOF(1));
+        load_w(0, 0, 0, wx);
+        load_n(0, 0, n0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            load_w(buf, 0, 1, wy);
+            load_n(buf, 1, n1);
+            MMA_HALF(0, wx, n0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1, 0); SGB(0x100, 1, 0); }
+            SGB(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 0, wx);
+            MMA_HALF(1, wy, n0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 1, 1); SGB(0x100, 1, 1); }
+            SGB(0x008, 12, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(buf, 1, 1, wy);
+            if (kt + 1 < nk) lstore(buf ^ 1);           // k-step kt + 1: fetched one k-step ago, nobody reads that buffer now
+            MMA_HALF(0, wx, n1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 1, 2); SGB(0x100, 1, 2); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1, 2); SGB(0x200, 1, 2); }
+            SGB(0x008, 4, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                load_w(buf ^ 1, 0, 0, wx);
+                load_n(buf ^ 1, 0, n0);
+            }
+            if (kt + 2 < nk) gfetch(KOF(kt + 2));
+            MMA_HALF(1, wy, n1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1, 3); SGB(0x100, 1, 3); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1, 3); SGB(0x020, 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+#undef MMA_HALF
+#undef SGB
+    } else
+    if constexpr (VARIANT == 4 || VARIANT == 5) {
+        // the shipped loops' schedule (dense_split.hip / gemm_bf16.hip): four phases of 16 MFMAs per k-step, fragments of the next
+        // phase read under the current one, one barrier per k-step, LDS-DMA of k-step kt + 2 behind it, issue order pinned.
+        // 4: both operands through LDS; 5: the N side (4 fragments per k32) straight from the packed copy, one register set per half
+        constexpr bool DIRECT = VARIANT == 5;
+        bf16x8 wx[4], wy[4], n0[4], n1[4];
+        if constexpr ((DIAG & 4) != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { wx[i] = wy[i] = n0[i] = n1[i] = *reinterpret_cast<const bf16x8*>(A + (lane + 64 * i) * 8); }
+        }
+        auto load_w = [&](int st, int kk, int h, bf16x8 (&wf)[4]) {
+            if constexpr ((DIAG & 4) != 0) return;
+            const unsigned char* at = smem + st * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wn * 128 + (h * 4 + i) * 16 + frow;
+                wf[i] = *reinterpret_cast<const bf16x8*>(at + r * 128 + (((4 * kk + fg) ^ SWZ(r)) * 16));
+            }
+        };
         auto load_n = [&](int st, int kk, int k0, bf16x8 (&nf)[4]) {
+            if constexpr ((DIAG & 4) != 0) return;
             if constexpr (DIRECT) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -157,14 +270,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const unsigned short* __
             for (int i = 0; i < 4; ++i) { SGB(0x008, 1, 2); SGB(0x100, 1, 2); }
             SGB(0x008, 12, 2);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (!DIRECT && (DIAG & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr ((DIAG & 1) == 0) __syncthreads();
             // P3
             if (kt + 1 < nk) {
                 load_w(buf ^ 1, 0, 0, wx);
                 if constexpr (!DIRECT) load_n(buf ^ 1, 0, k1, n0);
             }
-            if (kt + 2 < nk) stage(buf, k2);
+            if constexpr ((DIAG & 2) == 0) { if (kt + 2 < nk) stage(buf, k2); }
             MMA_HALF(1, wy, n1)
             if constexpr (DIRECT) { if (kt + 1 < nk) load_n(0, 1, k1, n1); }
             __builtin_amdgcn_sched_barrier(0);
@@ -306,7 +419,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dBp, hBp.size() * 2));
     CK(hipMemcpy(dBp, hBp.data(), hBp.size() * 2, hipMemcpyHostToDevice));
     const int variant = argc > 4 ? atoi(argv[4]) : 1;
-    const int lds = 2 * ((variant == 0 || variant == 4) ? BM + BN : BM) * BK * 2;
+    const int lds = 2 * ((variant == 0 || variant == 4 || variant == 6 || variant >= 40) ? BM + BN : BM) * BK * 2;
     const int tiles_n = N / BN, grid = (M / BM) * tiles_n;
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
@@ -314,6 +427,10 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
     CK(hipFuncSetAttribute((const void*)gemm8w_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * BK * 2));
+    CK(hipFuncSetAttribute((const void*)gemm8w_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
+#define DIAGATTR(D) CK(hipFuncSetAttribute((const void*)gemm8w_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * BK * 2));
+    DIAGATTR(1) DIAGATTR(2) DIAGATTR(3) DIAGATTR(4) DIAGATTR(6) DIAGATTR(7) DIAGATTR(8) DIAGATTR(16) DIAGATTR(32)
+#undef DIAGATTR
     int do_store = 1, krep = 1;
     const int krep_timing = argc > 5 ? atoi(argv[5]) : 1;
     auto launch = [&]() {
@@ -322,7 +439,11 @@ int main(int argc, char** argv) {
         else if (variant == 2) hipLaunchKernelGGL(gemm8w_kernel<2>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
         else if (variant == 3) hipLaunchKernelGGL(gemm8w_kernel<3>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
         else if (variant == 4) hipLaunchKernelGGL(gemm8w_kernel<4>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
-        else hipLaunchKernelGGL(gemm8w_kernel<5>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 5) hipLaunchKernelGGL(gemm8w_kernel<5>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        else if (variant == 6) hipLaunchKernelGGL(gemm8w_kernel<6>, dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+#define DIAGCASE(D) else if (variant == 40 + D) hipLaunchKernelGGL((gemm8w_kernel<4, D>), dim3(grid), dim3(512), lds, 0, dA, dB, dC, M, N, K, tiles_n, dBp, do_store, krep);
+        DIAGCASE(1) DIAGCASE(2) DIAGCASE(3) DIAGCASE(4) DIAGCASE(6) DIAGCASE(7) DIAGCASE(8) DIAGCASE(16) DIAGCASE(32)
+#undef DIAGCASE
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
