@@ -93,8 +93,12 @@ class Hooks:
         return bf16_round(x) if self.bf16 else x
 
 
-def forward_hidden(weights, cfg, input_ids, attention_mask, hooks=None, final_norm=True):
+def forward_hidden(weights, cfg, input_ids, attention_mask, hooks=None, final_norm=True, tap=None):
     """LlamaModel.forward with the reference's bidirectional mask.
+
+    tap: optional dict whose keys are layer counts d; tap[d] receives a copy of the residual stream after d layers
+    (before the final norm) - the hidden state of the d-layer model built from the first d layers of `weights`
+    (tests/test_encoder_depth_gpu.py measures the error per depth from ONE oracle pass).
 
     input_ids, attention_mask: [B, L] ints.  Returns last_hidden_state [B, L, H]
     float32 for ALL positions (pad query rows included, as in the reference:
@@ -142,6 +146,8 @@ def forward_hidden(weights, cfg, input_ids, attention_mask, hooks=None, final_no
         up = hooks.lin(h, weights[p + "mlp.up_proj.weight"])
         a = hooks.act(hooks.act(_silu(gate)) * up)
         x = x + hooks.lin(a, weights[p + "mlp.down_proj.weight"])
+        if tap is not None and (i + 1) in tap:
+            tap[i + 1] = x.astype(np.float32).copy()
     if final_norm:
         x = _rmsnorm(x, weights["model.norm.weight"], eps)
     return x.astype(np.float32)
@@ -155,7 +161,16 @@ def dense_encode(weights, cfg, input_ids, attention_mask, hooks=None):
     `seq_reps[i, -length:, :]` slice (so with right padding it averages pad
     positions; reproduced, not fixed).  length == 0 gives `[-0:]` = all rows.
     """
-    hs = forward_hidden(weights, cfg, input_ids, attention_mask, hooks)
+    return dense_pool(forward_hidden(weights, cfg, input_ids, attention_mask, hooks), attention_mask)
+
+
+def final_norm(weights, cfg, x):
+    """model.norm over a residual stream taken with forward_hidden(..., tap=...)."""
+    return _rmsnorm(x, weights["model.norm.weight"], cfg.get("rms_norm_eps", 1e-6)).astype(np.float32)
+
+
+def dense_pool(hs, attention_mask):
+    """The pooling half of DecoderOnlyBiDense.encode (llm_encoder.py:430-443) over last_hidden_state [B, L, H]."""
     nrm = np.sqrt((hs * hs).sum(-1, keepdims=True, dtype=np.float32))
     hs = hs / np.maximum(nrm, np.float32(1e-12))
     lens = np.asarray(attention_mask).sum(-1)
@@ -172,7 +187,12 @@ def sparse_encode(weights, cfg, input_ids, attention_mask, hooks=None):
     reps = log(relu(max_L(logits + (1 - mask) * -1e6)) + 1).
     """
     hooks = hooks or Hooks()
-    hs = forward_hidden(weights, cfg, input_ids, attention_mask, hooks)
+    return sparse_pool(weights, cfg, forward_hidden(weights, cfg, input_ids, attention_mask, hooks), attention_mask, hooks)
+
+
+def sparse_pool(weights, cfg, hs, attention_mask, hooks=None):
+    """The head half of DecoderOnlyBiSparse.encode (llm_encoder.py:187-196) over last_hidden_state [B, L, H]."""
+    hooks = hooks or Hooks()
     w = weights.get("lm_head.weight")
     if w is None:
         w = weights["model.embed_tokens.weight"]

@@ -1,0 +1,113 @@
+"""Regression test for run-to-run identity of the scoring kernels.
+
+Round 3 found a race in `topk_compact_kernel` (one thread published the new run_count / cand_count of a query while a late
+wave of the same workgroup still had to read the old ones) that corrupted results - and corpus rows - once in a few
+hundred searches at the full shape; it was found by tools/micro/exact_stress*.py, outside the suite.  A race shows up as
+run-to-run differences long before it moves a result visibly, so this test repeats ONE search many times on a fixed
+index and compares every output with the first bit for bit, and checks that the corpus itself was not written to:
+
+  dense   >= 100 searches through the exact fp32 kernel and >= 100 through the certified filter + exact re-score, >= 1 M
+          documents, a small workspace (short launches: the compaction between launches - where the race lived - runs
+          hundreds of times per search), interleaved with searches of other shapes so workspaces are re-planned;
+  sparse  >= 50 searches of a query batch through sparse_block_kernel / sparse_score_kernel.
+
+What is computed is /root/reference/scaling_retriever/indexer.py:210-214 (IndexFlatIP.search) and :324-344
+(numba_score_float + select_topk); the first result of each series is also checked against the oracle on a sample.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring as SC
+
+pytestmark = pytest.mark.gpu
+
+
+def _differs(a, b):
+    return (~((a[0] == b[0]).all(1) & (a[1] == b[1]).all(1))).nonzero()[:, 0].tolist()
+
+
+def test_dense_search_repeated_100_times_is_bit_identical():
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    dev = torch.device("cuda", 0)
+    N, H, nq, k = 1_200_000, 1024, 1536, 1000
+    g = torch.Generator(device=dev).manual_seed(11)
+    D = torch.empty((N, H), dtype=torch.float32, device=dev)
+    for r0 in range(0, N, 1 << 18):
+        D[r0:r0 + (1 << 18)].normal_(0.0, 0.5 / H ** 0.5, generator=g)
+    Q = torch.randn((nq, H), device=dev, generator=g) * (0.5 / H ** 0.5)
+    Q2 = torch.randn((200, H), device=dev, generator=g) * (0.5 / H ** 0.5)
+    d_sum = [D[r0:r0 + (1 << 18)].double().sum().item() for r0 in range(0, N, 1 << 18)]
+    q_sum = Q.double().sum().item()
+
+    index = DenseIndexHIP(H, device=dev)
+    index.add_device_rows(D)
+    # ~0.4 GB of top-k workspace: launches of a few thousand documents, i.e. several hundred launch + compaction pairs per
+    # search instead of the ~40 of the default plan
+    index.set_workspace_limit(400 << 20)
+    first = {}
+    for mode, rounds in (("fp32", 100), ("fp32_filtered", 100)):
+        index.set_precision(mode)
+        for it in range(rounds):
+            s, i = index.search(Q, k)
+            if mode not in first:
+                first[mode] = (s.clone(), i.clone())
+            else:
+                bad = _differs((s, i), first[mode])
+                assert not bad, f"{mode} search #{it}: queries {bad[:10]} differ from the first run"
+            if it % 10 == 3:                      # another shape in between: workspaces are re-planned, tau buffers reused
+                index.search(Q2, 100)
+            if it % 25 == 7:
+                index.search(Q[:8], 10)           # the streaming kernel
+    # the filter + exact re-score returns the exact kernel's bits
+    assert not _differs(first["fp32_filtered"], first["fp32"])
+    certified, redone = index.filter_query_stats()
+    assert certified > 0.9 * 100 * nq, (certified, redone)
+    # nothing wrote into the corpus or the queries (the round-3 race did: 8-byte stores at wild offsets)
+    assert [D[r0:r0 + (1 << 18)].double().sum().item() for r0 in range(0, N, 1 << 18)] == d_sum
+    assert Q.double().sum().item() == q_sum
+    # and the first run is the oracle's answer: fmaf chain in the kernel's k order, (score desc, index asc) top-k
+    rows = [0, 1, 777, nq - 1]
+    es, ei = SC.topk_rows(SC.dense_scores_fma(Q[rows].cpu().numpy(), D.cpu().numpy(), SC.mfma_korder(H)), k)
+    assert np.array_equal(first["fp32"][1][rows].cpu().numpy(), ei)
+    assert np.array_equal(first["fp32"][0][rows].cpu().numpy(), es)
+
+
+def test_sparse_search_repeated_50_times_is_bit_identical():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    dev = torch.device("cuda", 0)
+    V, N, L0_d, nq, L0_q, k = 30_000, 1_500_000, 48, 512, 24, 1000
+    indptr, doc_ids, vals, _ = synth.build_index(V, N, L0_d, dev, seed=3)
+    q_indptr, q_cols, q_vals = synth.build_queries(V, nq, L0_q, dev, seed=4)
+    ids_sum, vals_sum = doc_ids.long().sum().item(), vals.double().sum().item()
+    index = SparseIndexHIP(indptr, doc_ids, vals, N, device=dev)
+    index.set_workspace_limit(256 << 20)
+    first = None
+    for it in range(50):
+        s, i, c = index.search(q_indptr, q_cols, q_vals, k, threshold=0.0)
+        if first is None:
+            first = (s.clone(), i.clone(), c.clone())
+        else:
+            assert torch.equal(c, first[2]), f"search #{it}: counts differ"
+            bad = _differs((s, i), first)
+            assert not bad, f"search #{it}: queries {bad[:10]} differ from the first run"
+        if it % 10 == 5:
+            index.search(q_indptr[:9], q_cols[:8 * L0_q], q_vals[:8 * L0_q], 50, threshold=0.0)
+    st = index.block_stats()
+    assert st["dense_terms"] > 0 and st["block_calls"] > 0      # the query-block kernel served the batches
+    assert doc_ids.long().sum().item() == ids_sum and vals.double().sum().item() == vals_sum
+    # the first run against the oracle's C port of numba_score_float + select_topk on a few queries
+    h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
+    qi, qc, qv = q_indptr.cpu().numpy(), q_cols.cpu().numpy(), q_vals.cpu().numpy()
+    n_check = 64
+    oi, os_, oc = SC.sparse_retrieve_c(h_indptr, h_ids, h_vals, qi[:n_check + 1], qc[:qi[n_check]], qv[:qi[n_check]], k, 0.0, N,
+                                       q_threads=8, inner_threads=1)
+    for q in range(n_check):
+        n = int(first[2][q].item())
+        assert n == oc[q]
+        assert np.array_equal(first[1][q, :n].cpu().numpy(), oi[q, :n]), q
+        assert np.array_equal(first[0][q, :n].cpu().numpy(), os_[q, :n]), q
