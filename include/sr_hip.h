@@ -222,6 +222,17 @@ int sr_encode_sparse_fp32(sr_model* m, const int64_t* d_input_ids, const int64_t
 int sr_encode_both(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask,
                    int32_t B, int32_t L, int32_t fp32, float* d_out_sparse, float* d_out_dense,
                    sr_stream stream);
+/* Rows of SEVERAL collator batches in one call.  The reference's drivers hand the encoder eval_batch_size rows at a time
+ * (DenseRetriever.generate_query_vecs, eval_dense.py:94-106; SparseRetrieval._generate_query_vecs, indexer.py:382-403; default 128
+ * queries = ~1 100 tokens, far too few rows to fill 256-row GEMM tiles).  The host side lays the batches into ONE [B, L] matrix
+ * (L = the widest batch; a narrower batch gets extra left padding, mask 0) and passes d_row_shift int32 [B]: how many columns row b
+ * moved right.  Positions (RoPE, the dense head's `[-length:]` pooling) are counted from there, i.e. every row keeps the
+ * position_ids it had in its own batch, and its output is bit-identical to encoding that batch alone.  d_row_shift may be NULL
+ * (no shifts).  mode: 0 dense head, 1 sparse head, 2 both; fp32: 0 autocast regime, 1 fp32 regime.  d_out_sparse fp32 [B, vocab]
+ * (modes 1, 2), d_out_dense fp32 [B, hidden] (modes 0, 2).                                                                      */
+int sr_encode_rows(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                   const int32_t* d_row_shift, int32_t mode, int32_t fp32, float* d_out_sparse, float* d_out_dense,
+                   sr_stream stream);
 /* Debug/test hook: last_hidden_state (after the final norm) of the packed
  * tokens of the last encode call, fp32 [n_tokens, hidden]; returns n_tokens
  * through *n_tokens.                                                         */
@@ -242,6 +253,22 @@ int sr_lora_merge(float* d_W, const float* d_A, const float* d_B, int64_t out_fe
 int sr_sparse_compact(const float* d_reps, int64_t B, int64_t V, int64_t* d_row_ptr,
                       int32_t* d_cols, float* d_vals, int64_t capacity, int64_t* h_nnz,
                       sr_stream stream);
+
+/* run.json of the retrieval drivers, written straight from the result arrays (HOST function: every pointer is host memory).
+ * Replaces the per-hit Python loops + json.dump of eval_dense.py:225-241 (`qid_to_rankdata[str(qid)][str(docid)] = float(score)`)
+ * and SparseRetrieval.retrieve, indexer.py:405-474,530-540 (`res[str(qid)][str(doc_ids[id_])] = float(sc)`; `json.dump(res)`):
+ * the file holds byte for byte what Python's json.dump writes for that nested dict - {"qid": {"docid": score, ...}, ...},
+ * ", " / ": " separators, entries in row order, scores as float.__repr__ of the fp32 value widened to double.
+ * h_scores fp32 [nq, k], h_idx int64 [nq, k] = positions in the document id table (negative = padding, skipped), h_counts int32
+ * [nq] or NULL = hits per row (NULL: k).  A query without a hit gets no entry, as in the reference.  Keys: decimal int64
+ * (h_qid_i64 [nq] / h_doc_i64 [n_docs]) or, when the *_i64 pointer is NULL, JSON string bodies already escaped by the caller:
+ * bytes + offsets [n + 1], or - offsets NULL - fixed-width NUL-padded entries of *_width bytes (a numpy 'S' array of ASCII ids
+ * that need no escaping).  Keys are assumed distinct (the caller checks; a dict would merge duplicates).
+ * n_threads <= 0: all hardware threads.  *bytes_written (nullable) = file size.                                             */
+int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx, const int32_t* h_counts,
+                      const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off, int64_t qid_width,
+                      const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off, int64_t doc_width,
+                      int64_t n_docs, int32_t n_threads, int64_t* bytes_written);
 
 /* ----------------------------------------------------- building blocks ---
  * The two MFMA kernels of the encoder, exported for per-kernel parity tests and

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnF32Args a) {
     const int t0 = a.cu_seqlens[b];
     const int S = a.cu_seqlens[b + 1] - t0;
     const int r0 = blockIdx.z * AF_ROWS;
-    if (r0 >= S) return;
+    if (r0 >= S || S <= a.only_gt) return;
     const int G = a.nh / a.nkv, kvh = h / G;
     const int ld = (a.nh + 2 * a.nkv) * HD;
     const int koff = a.nh * HD + kvh * HD, voff = (a.nh + a.nkv) * HD + kvh * HD;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * G) void attention_f32_gqa_kernel(AttnF32Args a
     const int t0 = a.cu_seqlens[b];
     const int S = a.cu_seqlens[b + 1] - t0;
     const int r0 = blockIdx.z * AF_ROWS;
-    if (r0 >= S) return;
+    if (r0 >= S || S <= a.only_gt) return;
     const int ld = (a.nh + 2 * a.nkv) * HD;
     const int koff = a.nh * HD + kvh * HD, voff = (a.nh + a.nkv) * HD + kvh * HD;
     const int nrows = (S - r0) < AF_ROWS ? (S - r0) : AF_ROWS;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void attention_f32_mfma_kernel(AttnF32Args a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = a.cu_seqlens[b];
     const int S = a.cu_seqlens[b + 1] - t0;
-    if (S <= 0) return;
+    if (S <= 0 || S > a.only_le) return;
     const int nkb = (S + 15) >> 4;                  // key blocks = q blocks (<= 4)
     const int SP = nkb * 16;
     float* Ks = af_smem;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void attention_f32_mfma_kernel(AttnF32Args a) 
 
 template <int HD>
 static int launch_attention_f32_mfma(const AttnF32Args& a, hipStream_t s) {
-    const int sp = (int)ceil_div64(a.max_seqlen, 16) * 16;
+    const int sp = (int)ceil_div64(a.max_seqlen < 64 ? a.max_seqlen : 64, 16) * 16;
     const size_t lds = sizeof(float) * (size_t)(2 * sp + 4 * 16) * (HD + 1);
     static DeviceOnce attr_once;
     if (bool* slot = attr_once.pending()) {
@@ -368,14 +368,23 @@ static int launch_attention_f32_mfma(const AttnF32Args& a, hipStream_t s) {
     return SR_OK;
 }
 
-int launch_attention_f32(const AttnF32Args& a, hipStream_t s) {
+int launch_attention_f32(const AttnF32Args& a_in, hipStream_t s) {
+    AttnF32Args a = a_in;
     SR_REQUIRE(a.nh % a.nkv == 0, "attention(fp32): num_heads %d not a multiple of num_kv_heads %d", a.nh, a.nkv);
     SR_REQUIRE(a.out_f32 || (a.out_map.n_seg >= 1 && a.out_map.n_seg <= SR_MAX_SEG), "attention(fp32): bad segment map");
     if (a.B == 0 || a.max_seqlen <= 0) return SR_OK;
     const int G = a.nh / a.nkv;
+    a.only_le = 0; a.only_gt = 0;
     const char* env_m = sr_dev_getenv("SR_ATTN_F32_MFMA");    // A/B switch: 0 = the FMA kernels below for every length
-    if (G == 4 && a.max_seqlen <= 64 && (a.hd == 64 || a.hd == 128) && !(env_m && *env_m == '0'))
-        return a.hd == 64 ? launch_attention_f32_mfma<64>(a, s) : launch_attention_f32_mfma<128>(a, s);
+    if (G == 4 && (a.hd == 64 || a.hd == 128) && !(env_m && *env_m == '0')) {
+        // The kernel is chosen PER SEQUENCE: <= 64 tokens -> the fp32-MFMA kernel, longer -> the FMA kernels.  A mixed batch runs
+        // both launches, each skipping the other's sequences (choosing by the batch's longest sequence made the bits
+        // of a short sequence depend on its neighbours).
+        a.only_le = 64;
+        SR_TRY(a.hd == 64 ? launch_attention_f32_mfma<64>(a, s) : launch_attention_f32_mfma<128>(a, s));
+        if (a.max_seqlen <= 64) return SR_OK;
+        a.only_le = 0; a.only_gt = 64;
+    }
     const char* env = sr_dev_getenv("SR_ATTN_F32_GQA");       // A/B switch: 0 = one workgroup per q head
     if (G == 4 && !(env && *env == '0')) {
         const dim3 grid((unsigned)a.B, (unsigned)a.nkv, (unsigned)ceil_div64(a.max_seqlen, AF_ROWS)), block(256);

@@ -42,9 +42,11 @@ int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u
                           unsigned int* xmin, const float* thr, hipStream_t s);
 int launch_filter_certify(const float* u_scores, const float* x_scores, const float* qa, int64_t nq, int k, int kp, int* flags,
                           const float* thr, hipStream_t s);
-// doc-sharded search (sr_dense_search_begin): lower[q] = min over the j largest upper bounds of (U - 2e): at least j documents
-// of this index score >= lower[q] exactly.  thr (above, nullable): [nq] values not above the GLOBAL k-th exact score
-int launch_filter_lower_bound(const FilterSegs& segs, const float* u_scores, const int64_t* u_ids, const float* qa, int64_t nq, int kp,
-                              int j, float* lower, hipStream_t s);
+// doc-sharded search (sr_dense_search_begin): lower[q] = the smallest EXACT score among the j candidates with the largest upper
+// bounds (re-scored by the rescore kernel's fmaf chain): at least j documents of this index reach lower[q], with no appeal to the
+// error model; -inf when there are fewer than j documents or a re-scored pair violates [U - 2e, U] (flags[q] |= 2).
+// thr (above, nullable): [nq] values not above the GLOBAL k-th exact score
+int launch_filter_lower_bound(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
+                              int64_t nq, int kp, int j, int H, int* flags, unsigned int* xmin, float* lower, hipStream_t s);
 // rows of src [*, width] picked by idx [n] -> dst [n, width] (gather), or dst rows idx[i] <- src row i (scatter); 4-byte elements
 int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t width, void* dst, bool scatter, hipStream_t s);

@@ -203,49 +203,21 @@ int launch_filter_gather_rows(const void* src, const int64_t* idx, int64_t n, in
     return SR_OK;
 }
 
-// Doc-sharded search, first half: lower[q] = min over the j candidates with the largest upper bounds of (U - 2 e) - at least j
-// documents of THIS index have an exact score >= lower[q].  With j = ceil(k / W) on each of W shards, the minimum of the W
-// values is not above the global k-th exact score.  One wave per query; -inf when the index holds fewer than j documents.
-__global__ __launch_bounds__(64) void filter_lower_bound_kernel(FilterSegs segs, const float* __restrict__ u_scores,
-                                                                const int64_t* __restrict__ u_ids, const float* __restrict__ qa, int kp,
-                                                                int j, float* __restrict__ lower) {
-    const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    double mn = INFINITY;
-    for (int i = lane; i < j; i += 64) {
-        const int64_t gid = u_ids[q * kp + i];
-        double lb = -INFINITY;
-        if (gid >= 0) {
-            for (int sgi = 0; sgi < segs.count; ++sgi) {
-                const int64_t off = gid - (int64_t)segs.id_base[sgi];
-                if (off >= 0 && off % segs.id_stride[sgi] == 0 && off / segs.id_stride[sgi] < segs.n[sgi]) {
-                    const int64_t r = off / segs.id_stride[sgi];
-                    const double e2 = 2.0 * ((double)qa[q * 4] * (double)segs.xy[sgi][r * 2] + (double)qa[q * 4 + 1] * (double)segs.xy[sgi][r * 2 + 1]) *
-                                      (double)qa[q * 4 + 3] * (double)segs.isd[sgi];
-                    lb = (double)u_scores[q * kp + i] - e2 * 1.001;
-                    break;
-                }
-            }
-        }
-        mn = lb < mn ? lb : mn;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(mn, off);
-        mn = o < mn ? o : mn;
-    }
-    if (lane == 0) {
-        float f = (float)mn;
-        if ((double)f > mn) f = nextafterf(f, -INFINITY);          // round down
-        lower[q] = (qa[q * 4] < INFINITY && mn > -INFINITY && mn < INFINITY) ? f : -INFINITY;
-    }
-}
-
-int launch_filter_lower_bound(const FilterSegs& segs, const float* u_scores, const int64_t* u_ids, const float* qa, int64_t nq, int kp,
-                              int j, float* lower, hipStream_t s) {
-    SR_REQUIRE(j >= 1 && j <= kp, "filter(lower bound): j = %d outside [1, %d]", j, kp);
-    hipLaunchKernelGGL(filter_lower_bound_kernel, dim3((unsigned)nq), dim3(64), 0, s, segs, u_scores, u_ids, qa, kp, j, lower);
-    SR_CHECK_LAUNCH();
-    return SR_OK;
+// Doc-sharded search, first half: lower[q] = the smallest EXACT score (the rescore kernel's fmaf chain) among the j candidates with
+// the largest upper bounds - at least j documents of THIS index reach lower[q] exactly, whatever the filter's error model is worth
+// (round 3 published min(U - 2e), which is a bound only while the model holds: a violation on one shard was caught by that
+// shard's own flag, but the other shards had already pruned with it - ADVICE r03).  With j = ceil(k / W) on each of W shards, the
+// minimum of the W values is not above the global k-th exact score.  -inf when the index holds fewer than j documents, when the
+// query is not filterable, or when a re-scored pair lies outside [U - 2e, U] (flag 2: the query is then re-done exactly by _finish).
+__global__ void filter_lower_exact_kernel(const unsigned int* __restrict__ xmin, const int64_t* __restrict__ u_ids,
+                                          const float* __restrict__ qa, const int* __restrict__ flags, int64_t nq, int kp, int j,
+                                          float* __restrict__ lower) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const bool have_j = u_ids[q * kp + (j - 1)] >= 0;          // the list is sorted by U, pads (id -1) at its end
+    const float x = sr_ord2f(xmin[q]);
+    const bool ok = have_j && qa[q * 4] < INFINITY && flags[q] == 0 && x > -INFINITY && x < INFINITY;
+    lower[q] = ok ? x : -INFINITY;
 }
 
 // One wave per (query, 64 candidates).  The candidates' rows are gathered 64 columns at a time through LDS (coalesced
@@ -257,7 +229,8 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
                                                             const int64_t* __restrict__ u_ids, const float* __restrict__ qa,
                                                             int k, int kp, int H, uint64_t* __restrict__ cand_keys,
                                                             int* __restrict__ cand_count, int64_t cand_cap, int* __restrict__ flags,
-                                                            int j_begin, unsigned int* __restrict__ xmin, const float* __restrict__ thr) {
+                                                            int j_begin, unsigned int* __restrict__ xmin, const float* __restrict__ thr,
+                                                            int lb_j) {
 #pragma clang fp contract(off)
     __shared__ float tile[64][RS_KC + 1];
     __shared__ float qs[RS_KC];
@@ -266,7 +239,9 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
     const int64_t q = blockIdx.x;
     const int j0 = j_begin + blockIdx.y * 64;
     const int j = j0 + lane;
-    const int j_end = j_begin == 0 ? (k < kp ? k : kp) : kp;        // stage 1: the k largest upper bounds; stage 2: the rest
+    // stage 1: the k largest upper bounds; stage 2: the rest; lb_j > 0 (sr_dense_search_begin): only the first lb_j, nothing is
+    // appended - the smallest exact score among them goes to xmin
+    const int j_end = lb_j > 0 ? lb_j : (j_begin == 0 ? (k < kp ? k : kp) : kp);
     if (j0 >= j_end) return;
     // stage 2: the smallest EXACT score among the k candidates of stage 1 is a lower bound of the exact k-th score; a
     // candidate whose upper bound lies strictly below it cannot reach the top-k, nor tie with its last member.  The list is
@@ -342,8 +317,10 @@ __global__ __launch_bounds__(64) void filter_rescore_kernel(FilterSegs segs, con
         // the bound, checked on every pair that is re-scored: S_x in [U - 2e, U]
         const double U = (double)u_scores[q * kp + j];
         if (!((double)acc <= U && (double)acc >= U - e2 * 1.001)) atomicOr(&flags[q], 2);
-        const int pos = atomicAdd(&cand_count[q], 1);
-        if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
+        if (lb_j == 0) {
+            const int pos = atomicAdd(&cand_count[q], 1);
+            if (pos < cand_cap) cand_keys[q * cand_cap + pos] = sr_make_key(acc, (uint32_t)gid);
+        }
         if (j_begin == 0) atomicMin(&xmin[q], sr_f2ord(acc));
     }
 }
@@ -358,12 +335,25 @@ int launch_filter_rescore(const FilterSegs& segs, const float* Q, const float* u
     SR_CHECK_HIP(hipMemsetAsync(xmin, 0xff, (size_t)nq * 4, s));
     const int k1 = k < kp ? k : kp;
     hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(k1, 64)), dim3(64), 0, s, segs, Q, u_scores, u_ids,
-                       qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, 0, xmin, thr);
+                       qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, 0, xmin, thr, 0);
     SR_CHECK_LAUNCH();
     if (kp > k1) {
         hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(kp - k1, 64)), dim3(64), 0, s, segs, Q, u_scores,
-                           u_ids, qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, k1, xmin, thr);
+                           u_ids, qa, k, kp, H, cand_keys, cand_count, cand_cap, flags, k1, xmin, thr, 0);
         SR_CHECK_LAUNCH();
     }
+    return SR_OK;
+}
+
+int launch_filter_lower_bound(const FilterSegs& segs, const float* Q, const float* u_scores, const int64_t* u_ids, const float* qa,
+                              int64_t nq, int kp, int j, int H, int* flags, unsigned int* xmin, float* lower, hipStream_t s) {
+    SR_REQUIRE(j >= 1 && j <= kp, "filter(lower bound): j = %d outside [1, %d]", j, kp);
+    SR_REQUIRE(H % RS_KC == 0, "filter(lower bound): dim %d must be a multiple of %d", H, RS_KC);
+    SR_CHECK_HIP(hipMemsetAsync(xmin, 0xff, (size_t)nq * 4, s));
+    hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)nq, (unsigned)ceil_div64(j, 64)), dim3(64), 0, s, segs, Q, u_scores, u_ids,
+                       qa, j, kp, H, (uint64_t*)nullptr, (int*)nullptr, (int64_t)0, flags, 0, xmin, (const float*)nullptr, j);
+    hipLaunchKernelGGL(filter_lower_exact_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, xmin, u_ids, qa, flags, nq, kp, j,
+                       lower);
+    SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -399,6 +399,8 @@ struct sr_dense_index {
     LaunchProfile prof;
     std::mutex mu;
     // SR_PRECISION_FP32_FILTERED (dense_filter.hip)
+    TopkWS wsf;                       // the 16-bit passes (upper-bound pass, bf16x3 / bf16x6): segmented candidate slots - a workspace of
+                                      // its own, so an index that alternates pass kinds does not free and re-allocate GBs per search
     TopkWS ws2;                       // exact top-k over the re-scored candidates
     TopkWS ws3;                       // exact re-do of the queries without a certificate
     float* qa = nullptr;              // [fq_cap, 4] per query (A', B', sq, 1 / sq)
@@ -538,6 +540,7 @@ extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     }
     for (int p = 0; p < 3; ++p)
         if (idx->qpl[p]) (void)hipFree(idx->qpl[p]);
+    idx->wsf.release();
     idx->ws2.release();
     idx->ws3.release();
     if (idx->qa) (void)hipFree(idx->qa);
@@ -572,7 +575,9 @@ extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
 // one pass in the given arithmetic (SR_PRECISION_FP32 | _BF16X3 | _BF16X6); caller holds idx->mu
 static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
                              int64_t* d_out_ids, int precision, hipStream_t s, bool force_tiled = false) {
-    TopkWS& ws = force_tiled ? idx->ws3 : idx->ws;      // the re-do of a few queries keeps its own (differently shaped) workspace
+    const bool pass16 = (planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64;
+    // the re-do of a few queries and the 16-bit passes keep their own (differently shaped) workspaces
+    TopkWS& ws = force_tiled ? idx->ws3 : (pass16 ? idx->wsf : idx->ws);
 
     // tile config by query count; chunk = docs per launch (= candidate capacity per query)
     int cfg;
@@ -597,7 +602,7 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     max_cap = (max_cap / TM) * TM;
     if (max_cap < TM) max_cap = TM;
     if (chunk > max_cap) chunk = max_cap;
-    if ((planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64) {
+    if (pass16) {
         // scores on the 16-bit MFMA pipe (dense_split.hip); same chunking and top-k machinery
         const int np = precision == SR_PASS_FILTER ? 0 : planes_of(precision);
         if (idx->q_cap < nq) {
@@ -893,7 +898,8 @@ extern "C" int sr_dense_search_begin(sr_dense_index* idx, const float* d_queries
     SR_TRY(filter_segs_of(idx, fs));
     int j = (k + share - 1) / share;
     if (j > idx->fkp) j = idx->fkp;
-    SR_TRY(launch_filter_lower_bound(fs, idx->a_scores, idx->a_ids, idx->qa, nq, idx->fkp, j, d_lower, s));
+    SR_TRY(launch_filter_lower_bound(fs, d_queries, idx->a_scores, idx->a_ids, idx->qa, nq, idx->fkp, j, idx->dim, idx->flags,
+                                     reinterpret_cast<unsigned int*>(idx->flags) + nq + 1, d_lower, s));
     idx->pend_nq = nq; idx->pend_k = k; idx->pend_q = d_queries;
     return SR_OK;
 }

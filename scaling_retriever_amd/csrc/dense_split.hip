@@ -15,6 +15,17 @@
 // lane-local and survivors are appended as 64-bit keys exactly as in dense_score.hip.
 #include "dense_split.h"
 
+// Timing-only diagnostics (SR_SPLIT_DIAG: wrong results by design; SR_SPLIT_STAMPS: per-tile s_memrealtime stamps) exist only in a
+// diagnostic build (make EXTRA=-DSR_DIAG_BUILD, tools/micro): in the product library the tests below are compile-time constants
+// and the kernel carries no trace of them.
+#ifdef SR_DIAG_BUILD
+#define SR_SPLIT_DIAG_BIT(a, bit) ((a).diag & (bit))
+#define SR_SPLIT_STAMPS_PTR(a) ((a).stamps)
+#else
+#define SR_SPLIT_DIAG_BIT(a, bit) 0
+#define SR_SPLIT_STAMPS_PTR(a) (static_cast<unsigned long long*>(nullptr))
+#endif
+
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
@@ -77,12 +88,12 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
     const int64_t left = a.row_end - row0;
     const int rows_valid = left < SP_BN ? (int)left : SP_BN;
     const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
-    if (a.diag & 2) return;                   // timing only (SR_SPLIT_DIAG): no epilogue at all
+    if (SR_SPLIT_DIAG_BIT(a, 2)) return;                   // timing only (SR_SPLIT_DIAG): no epilogue at all
     f32x4 qa[MB];
     if constexpr (UB) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) qa[j] = *reinterpret_cast<const f32x4*>(qa_s + (wm * MB * 16 + j * 16 + frow) * 4);
-        if (!(a.diag & 1))                     // timing only (SR_SPLIT_DIAG): plane product without the error term
+        if (!SR_SPLIT_DIAG_BIT(a, 1))                     // timing only (SR_SPLIT_DIAG): plane product without the error term
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const float* p = xy_s + 2 * (wn * NB * 16 + i * 16 + fg * 4);
@@ -102,7 +113,7 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
     // straight into the lane's own segment of the query's candidate buffer (common.h TopkWS: no atomic, no second pass), the
     // count goes to seg_cnt.  A (lane, query) pair with more than SR_SEG_P survivors (the first launches of a search, before
     // tau has risen) or a launch without segments takes the counted path behind one atomic reservation.
-    if (a.diag & 8) {                         // timing only: the error term alone
+    if (SR_SPLIT_DIAG_BIT(a, 8)) {                         // timing only: the error term alone
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -150,7 +161,7 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
         slow[j] = n > 0 && (!seg_ok || n > SR_SEG_P);
         if (n > 0 && !slow[j]) a.seg_cnt[(int64_t)q * a.seg_n + seg_idx] = (unsigned char)n;
     }
-    if (a.diag & 4) return;                  // timing only: the counted path skipped
+    if (SR_SPLIT_DIAG_BIT(a, 4)) return;                  // timing only: the counted path skipped
     bool any_slow = false;
 #pragma unroll
     for (int j = 0; j < MB; ++j) any_slow = any_slow || slow[j];
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         // the barrier also ends the previous tile's epilogue reads of xy_s
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const unsigned long long st0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+        const unsigned long long st0 = SR_SPLIT_STAMPS_PTR(a) ? __builtin_amdgcn_s_memrealtime() : 0;
         if (wave >= 4) {      // tau of the tile's queries: one 4-byte LDS-DMA piece per lane of waves 4-7 (no wait in the epilogue)
             int q = q0 + (wave - 4) * 64 + lane;
             q = q < a.nq ? q : a.nq - 1;
@@ -417,9 +428,9 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             SR_MFMA_HALF(1, wy, a1)
             buf ^= 1;
         }
-        const unsigned long long st1 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+        const unsigned long long st1 = SR_SPLIT_STAMPS_PTR(a) ? __builtin_amdgcn_s_memrealtime() : 0;
         split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s, tau_s);
-        if (a.stamps) {          // dev switch SR_SPLIT_STAMPS: 10 ns ticks per tile of wave 0: k-loop, epilogue issue, wait at the next tile's top
+        if (SR_SPLIT_STAMPS_PTR(a)) {          // dev switch SR_SPLIT_STAMPS: 10 ns ticks per tile of wave 0: k-loop, epilogue issue, wait at the next tile's top
             const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
@@ -460,6 +471,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
     if (const char* e = sr_dev_getenv("SR_SPLIT_DIAG")) b.diag = atoi(e);         // timing only
 #endif
     b.stamps = nullptr;
+#ifdef SR_DIAG_BUILD
     if (sr_dev_getenv("SR_SPLIT_STAMPS")) {
         static unsigned long long* d_st = nullptr;
         static int calls = 0;
@@ -473,6 +485,7 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
         }
         b.stamps = d_st;
     }
+#endif
     const SplitGrid sg = split_grid(rows, a.nq, b.xcd_order);
     b.grid_qt = sg.qt; b.grid_dt = sg.dt; b.grid_bq = sg.bq; b.grid_bd = sg.bd; b.grid_nbq = sg.nbq; b.grid_total = sg.total;
     // one persistent workgroup per CU (130 KB of LDS each); SR_SPLIT_PERSIST=0: one workgroup per tile slot (A/B)

@@ -26,8 +26,11 @@
 // ---- plan: per-row span ------------------------------------------------------
 // mode 0 (dense) and 2 (both heads): span = [min(first1, L - len), L); pool_start = L - len (0 if len == 0)
 // mode 1 (sparse): span = [first1, last1 + 1)
+// row_shift (nullable, sr_encode_rows): row b sits row_shift[b] columns further right than in the batch it came from; positions
+// (RoPE, pooling) are counted from there, so the row gets the position_ids it had in its own batch.
 __global__ void plan_rows_kernel(const int64_t* __restrict__ mask, int B, int L, int mode, int* __restrict__ span_start,
-                                 int* __restrict__ span_len, int* __restrict__ pool_start, int* __restrict__ row_len) {
+                                 int* __restrict__ span_len, int* __restrict__ pool_start, int* __restrict__ row_len,
+                                 const int* __restrict__ row_shift) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x;  // 64 threads
     int len = 0, first = L, last = -1;
@@ -59,7 +62,7 @@ __global__ void plan_rows_kernel(const int64_t* __restrict__ mask, int B, int L,
         }
         span_start[b] = st;
         span_len[b] = ln;
-        pool_start[b] = ps;
+        pool_start[b] = ps - (row_shift ? row_shift[b] : 0);     // compared with pos[], which carries the same shift
         row_len[b] = len;
     }
 }
@@ -88,15 +91,16 @@ __global__ void plan_scan_kernel(const int* __restrict__ span_len, int B, int* _
 __global__ void plan_tokens_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int L,
                                    const int* __restrict__ span_start, const int* __restrict__ cu, int* __restrict__ tok_id,
                                    int* __restrict__ pos, unsigned char* __restrict__ key_valid, int* __restrict__ seq_of,
-                                   int vocab, int mode) {
+                                   int vocab, int mode, const int* __restrict__ row_shift) {
     const int b = blockIdx.x;
     const int t0 = cu[b], n = cu[b + 1] - t0, st = span_start[b];
+    const int shift = row_shift ? row_shift[b] : 0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const int p = st + j;
         int64_t id = ids[(int64_t)b * L + p];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // clamp (HF would raise an index error)
         tok_id[t0 + j] = (int)id;
-        pos[t0 + j] = p;
+        pos[t0 + j] = p - shift < 0 ? 0 : p - shift;     // a shift beyond the row's span start is a caller error: stay in the tables
         const bool valid = mask[(int64_t)b * L + p] != 0;
         key_valid[t0 + j] = valid ? 1 : 0;
         // sparse head: masked positions inside the span take no part in the max (-2 = skip row)
@@ -871,6 +875,9 @@ extern "C" int sr_model_finalize(sr_model* m) {
     SR_REQUIRE(!m->cfg.has_lm_head || m->have_lm_head, "sr_model_finalize: lm_head.weight missing");
     for (int i = 0; i < m->cfg.num_layers; ++i)
         SR_REQUIRE(m->layers[i].have == 511, "sr_model_finalize: layer %d is missing tensors (mask 0x%x)", i, m->layers[i].have);
+    // sr_model_set_weight converted the planes on the CALLER's streams; a non-blocking stream does not order with the null
+    // stream the reduction below runs on, and a cmax read from half-written planes would let EPI_SWIGLU_SPLIT_H overflow fp16
+    SR_CHECK_HIP(hipDeviceSynchronize());
     if (m->cfg.fp32_planes == SR_FP32_PLANES_F16) {      // row bound of every layer's SwiGLU output (EPI_SWIGLU_SPLIT_H)
         for (int i = 0; i < m->cfg.num_layers; ++i) {
             LayerW& l = m->layers[i];
@@ -934,7 +941,7 @@ static int launch_rmsnorm_split(float* x, const float* embed, const int* tok_id,
 }
 
 static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mask, int B, int L, int mode, int prec,
-                         hipStream_t s, int* T_out) {
+                         hipStream_t s, int* T_out, const int32_t* d_shift = nullptr) {
     const sr_model_config& c = m->cfg;
     SR_REQUIRE(m->finalized, "encode: sr_model_finalize was not called");
     SR_REQUIRE(B >= 1 && L >= 1, "encode: bad batch shape [%d, %d]", B, L);
@@ -946,7 +953,7 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     const int nq = c.num_heads * c.head_dim, nkv = c.num_kv_heads * c.head_dim;
 
     hipLaunchKernelGGL(plan_rows_kernel, dim3(B), dim3(64), 0, s, d_mask, B, L, mode, m->span_start, m->span_len,
-                       m->pool_start, m->row_len);
+                       m->pool_start, m->row_len, d_shift);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(256), 0, s, m->span_len, B, m->cu);
     SR_CHECK_LAUNCH();
     SR_CHECK_HIP(hipMemcpyAsync(m->h_cu, m->cu, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -961,7 +968,7 @@ static int model_forward(sr_model* m, const int64_t* d_ids, const int64_t* d_mas
     m->last_T = T;
     if (T == 0) return SR_OK;
     hipLaunchKernelGGL(plan_tokens_kernel, dim3(B), dim3(128), 0, s, d_ids, d_mask, L, m->span_start, m->cu, m->tok_id,
-                       m->pos, m->key_valid, m->seq_of, c.vocab_size, mode);
+                       m->pos, m->key_valid, m->seq_of, c.vocab_size, mode, d_shift);
     SR_CHECK_LAUNCH();
 
     if (prec == PREC_FP32 && c.fp32_planes == SR_FP32_PLANES_F16) {
@@ -1132,11 +1139,11 @@ static int head_sparse(sr_model* m, int B, int T, int prec, float* d_out, hipStr
 
 // mode 0: dense head, 1: sparse head, 2: both from ONE backbone pass (the hybrid model)
 static int encode_any(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L, int mode,
-                      int prec, float* d_dense, float* d_sparse, hipStream_t s) {
+                      int prec, float* d_dense, float* d_sparse, hipStream_t s, const int32_t* d_shift = nullptr) {
     std::lock_guard<std::mutex> lock(m->mu);
     StreamOrder::Scope in_order(m->order, s);
     int T = 0;
-    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, mode, prec, s, &T));
+    SR_TRY(model_forward(m, d_input_ids, d_attention_mask, B, L, mode, prec, s, &T, d_shift));
     if (mode != 1) SR_TRY(head_dense(m, B, T, prec, d_dense, s));     // first: its scratch is the sparse head's GEMM input
     if (mode != 0) SR_TRY(head_sparse(m, B, T, prec, d_sparse, s));
     return SR_OK;
@@ -1184,6 +1191,23 @@ extern "C" int sr_encode_both(sr_model* m, const int64_t* d_input_ids, const int
     SR_REQUIRE(m->cfg.has_lm_head, "sr_encode_both: model was created without an lm_head (LlamaBiModel)");
     return encode_any(m, d_input_ids, d_attention_mask, B, L, 2, fp32 ? PREC_FP32 : PREC_BF16, d_out_dense, d_out_sparse,
                       (hipStream_t)stream);
+}
+
+// Rows of SEVERAL left-padded batches in one call (the drop-in drivers hand the encoder eval_batch_size rows at a time,
+// eval_dense.py:94-106 / indexer.py:382-403; 128 queries are ~1 100 tokens - far too few rows for 256-row GEMM tiles): the caller
+// lays the batches into one [B, L] matrix (L = the widest batch, narrower batches get extra left padding) and passes, per row, how far
+// it moved right.  Positions are counted from there, so every row is computed with the position_ids it had in its own batch and its
+// output is bit-identical to encoding that batch alone (the kernels do not depend on batch composition).
+extern "C" int sr_encode_rows(sr_model* m, const int64_t* d_input_ids, const int64_t* d_attention_mask, int32_t B, int32_t L,
+                              const int32_t* d_row_shift, int32_t mode, int32_t fp32, float* d_out_sparse, float* d_out_dense,
+                              sr_stream stream) {
+    SR_REQUIRE(m, "sr_encode_rows: null model");
+    SR_REQUIRE(mode >= 0 && mode <= 2, "sr_encode_rows: mode %d (0 dense, 1 sparse, 2 both)", mode);
+    SR_REQUIRE(mode == 1 || d_out_dense, "sr_encode_rows: null dense output");
+    SR_REQUIRE(mode == 0 || d_out_sparse, "sr_encode_rows: null sparse output");
+    SR_REQUIRE(mode == 0 || m->cfg.has_lm_head, "sr_encode_rows: model was created without an lm_head (LlamaBiModel)");
+    return encode_any(m, d_input_ids, d_attention_mask, B, L, mode, fp32 ? PREC_FP32 : PREC_BF16, d_out_dense, d_out_sparse,
+                      (hipStream_t)stream, d_row_shift);
 }
 
 extern "C" int sr_model_last_hidden(sr_model* m, float* d_out, int64_t capacity_rows, int64_t* n_tokens, sr_stream stream) {

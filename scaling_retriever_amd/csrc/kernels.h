@@ -104,5 +104,8 @@ struct AttnF32Args {
     float scale;
     int max_seqlen;         // longest sequence of the batch (grid sizing)
     SplitMap out_map;
+    // set by launch_attention_f32: a kernel serves the sequences with only_gt < S and (only_le == 0 or S <= only_le), so the kernel
+    // - and with it the bits - of a sequence depends on ITS length, never on what else shares the batch
+    int only_le = 0, only_gt = 0;
 };
 int launch_attention_f32(const AttnF32Args& a, hipStream_t s);

@@ -1,0 +1,211 @@
+// run.json straight from the result arrays (host code; no kernel in this file).
+//
+// The reference's retrieval drivers turn the top-k arrays into a nested dict with a per-hit Python loop and json.dump it:
+//   eval_dense.py:225-241          qid_to_rankdata[str(qid)][str(docid)] = float(score); ujson.dump(...)
+//   scaling_retriever/indexer.py:405-474,530-540   res[str(qid)][str(doc_ids[id_])] = float(sc); json.dump(res, handler)
+// At MS MARCO Dev (6 980 queries x 1 000 hits) that loop is 7 M dict insertions + a 217 MB dump: ~15 s of host time behind a
+// 0.25 s search.  sr_write_run_json writes the same file from the arrays the search returns - byte for byte what Python's
+// json.dump writes for that dict (", " / ": " separators, keys in row order, float repr of the fp32 score widened to double:
+// shortest round-trip digits, exponent form outside 1e-4 <= |x| < 1e16, "NaN" / "Infinity" / "-Infinity") - formatting the
+// queries in parallel into per-thread buffers and writing them in order.
+#include "common.h"
+
+#include <cerrno>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// float.__repr__ (CPython format_float_short, mode 'r', Py_DTSF_ADD_DOT_0) of v
+inline char* py_float_repr(char* out, double v) {
+    if (std::isnan(v)) { memcpy(out, "NaN", 3); return out + 3; }
+    if (std::isinf(v)) {
+        if (v < 0) { memcpy(out, "-Infinity", 9); return out + 9; }
+        memcpy(out, "Infinity", 8);
+        return out + 8;
+    }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX, shortest round trip
+    const char* p = sci;
+    if (*p == '-') { *out++ = '-'; ++p; }
+    char digits[24];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    int ex = 0;
+    {
+        const char* q = p + 1;
+        const bool neg = *q == '-';
+        ++q;
+        for (; q < r.ptr; ++q) ex = ex * 10 + (*q - '0');
+        if (neg) ex = -ex;
+    }
+    while (nd > 1 && digits[nd - 1] == '0') --nd;        // to_chars does not pad, but stay safe
+    const int decpt = ex + 1;                              // value = 0.d1 d2 ... x 10^decpt
+    if (decpt <= -4 || decpt > 16) {                       // exponent form: d[.ddd]e[+-]XX (at least two exponent digits)
+        *out++ = digits[0];
+        if (nd > 1) {
+            *out++ = '.';
+            memcpy(out, digits + 1, (size_t)nd - 1);
+            out += nd - 1;
+        }
+        *out++ = 'e';
+        int e = decpt - 1;
+        *out++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        char eb[8];
+        int ne = 0;
+        do { eb[ne++] = (char)('0' + e % 10); e /= 10; } while (e);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) *out++ = eb[--ne];
+        return out;
+    }
+    if (decpt <= 0) {
+        *out++ = '0';
+        *out++ = '.';
+        for (int i = 0; i < -decpt; ++i) *out++ = '0';
+        memcpy(out, digits, (size_t)nd);
+        return out + nd;
+    }
+    if (decpt >= nd) {
+        memcpy(out, digits, (size_t)nd);
+        out += nd;
+        for (int i = 0; i < decpt - nd; ++i) *out++ = '0';
+        *out++ = '.';
+        *out++ = '0';
+        return out;
+    }
+    memcpy(out, digits, (size_t)decpt);
+    out += decpt;
+    *out++ = '.';
+    memcpy(out, digits + decpt, (size_t)(nd - decpt));
+    return out + (nd - decpt);
+}
+
+inline char* put_i64(char* out, int64_t v) {
+    const auto r = std::to_chars(out, out + 24, v);
+    return r.ptr;
+}
+
+struct Keys {
+    const int64_t* i64;      // decimal keys, or
+    const char* bytes;       // body of a JSON string per key (already escaped): offsets off[i] .. off[i + 1], or - off == NULL -
+    const int64_t* off;      // fixed-width entries of `width` bytes, NUL-padded (a numpy 'S' array of ASCII ids)
+    int64_t width;
+    inline size_t max_len(int64_t i) const { return i64 ? 21 : (off ? (size_t)(off[i + 1] - off[i]) : (size_t)width); }
+    inline char* put(char* out, int64_t i) const {
+        *out++ = '"';
+        if (i64) out = put_i64(out, i64[i]);
+        else if (!off) {
+            const char* p = bytes + i * width;
+            for (int64_t c = 0; c < width && p[c]; ++c) *out++ = p[c];
+        } else {
+            const size_t n = (size_t)(off[i + 1] - off[i]);
+            memcpy(out, bytes + off[i], n);
+            out += n;
+        }
+        *out++ = '"';
+        return out;
+    }
+};
+
+}  // namespace
+
+extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
+                                 const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
+                                 int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
+                                 int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written) {
+    SR_REQUIRE(path && nq >= 0 && k >= 0, "sr_write_run_json: bad argument");
+    SR_REQUIRE(nq == 0 || k == 0 || (h_scores && h_idx), "sr_write_run_json: null result arrays");
+    SR_REQUIRE(nq == 0 || h_qid_i64 || (h_qid_bytes && (h_qid_off || qid_width > 0)), "sr_write_run_json: no query ids");
+    SR_REQUIRE(n_docs >= 0 && (n_docs == 0 || h_doc_i64 || (h_doc_bytes && (h_doc_off || doc_width > 0))),
+               "sr_write_run_json: no document ids");
+    const Keys qk{h_qid_i64, h_qid_bytes, h_qid_off, qid_width}, dk{h_doc_i64, h_doc_bytes, h_doc_off, doc_width};
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        sr_set_error("sr_write_run_json: cannot open %s: %s", path, strerror(errno));
+        return SR_ERR_INVALID;
+    }
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    if ((int64_t)nt > nq) nt = nq > 0 ? (int)nq : 1;
+    // queries are formatted in blocks of `nt` slabs at a time: thread t formats a contiguous run of queries into its own buffer,
+    // the buffers are written in order.  A slab = 256 queries per thread keeps the buffers (~8 MB each at k = 1000) cache-friendly.
+    const int64_t slab = 256;
+    std::vector<std::string> bufs((size_t)nt);
+    std::vector<int> bad((size_t)nt, 0);
+    int64_t total = 0;
+    bool ok = fputc('{', f) != EOF;
+    total += 1;
+    for (int64_t q0 = 0; q0 < nq && ok; q0 += slab * nt) {
+        auto work = [&](int t) {
+            const int64_t a = q0 + (int64_t)t * slab, b = a + slab < nq ? a + slab : nq;
+            std::string& s = bufs[(size_t)t];
+            s.clear();
+            if (a >= b) return;
+            size_t used = 0;
+            for (int64_t q = a; q < b; ++q) {
+                const int64_t n = h_counts ? (h_counts[q] < k ? (h_counts[q] < 0 ? 0 : h_counts[q]) : k) : k;
+                // worst case of this query's text
+                size_t need = qk.max_len(q) + 8;
+                for (int64_t j = 0; j < n; ++j) {
+                    const int64_t d = h_idx[q * k + j];
+                    if (d >= 0 && d < n_docs) need += dk.max_len(d) + 2 + 2 + 26 + 2;
+                }
+                if (s.size() < used + need) s.resize((used + need) * 2);
+                char* const o_begin = &s[used];
+                char* o = o_begin;
+                *o++ = ','; *o++ = ' ';                        // the writer drops the separator of the file's first entry
+                o = qk.put(o, q);
+                *o++ = ':'; *o++ = ' '; *o++ = '{';
+                bool first = true;
+                for (int64_t j = 0; j < n; ++j) {
+                    const int64_t d = h_idx[q * k + j];
+                    if (d < 0) continue;                       // padding (fewer than k hits)
+                    if (d >= n_docs) { bad[(size_t)t] = 1; continue; }
+                    if (!first) { *o++ = ','; *o++ = ' '; }
+                    first = false;
+                    o = dk.put(o, d);
+                    *o++ = ':'; *o++ = ' ';
+                    o = py_float_repr(o, (double)h_scores[q * k + j]);
+                }
+                *o++ = '}';
+                // a query without a hit has no entry: the reference creates qid's dict with its first hit (eval_dense.py:228-234,
+                // indexer.py:431-432)
+                if (!first) used = (size_t)(o - s.data());
+            }
+            s.resize(used);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (int t = 0; t < nt && ok; ++t) {
+            const std::string& s = bufs[(size_t)t];
+            if (s.empty()) continue;
+            const size_t skip = total == 1 ? 2 : 0;
+            ok = fwrite(s.data() + skip, 1, s.size() - skip, f) == s.size() - skip;
+            total += (int64_t)(s.size() - skip);
+        }
+    }
+    ok = ok && fputc('}', f) != EOF;
+    total += 1;
+    ok = (fclose(f) == 0) && ok;
+    for (int t = 0; t < nt; ++t)
+        if (bad[(size_t)t]) {
+            sr_set_error("sr_write_run_json: a result index lies outside the document id table of %lld entries", (long long)n_docs);
+            return SR_ERR_INVALID;
+        }
+    if (!ok) {
+        sr_set_error("sr_write_run_json: write to %s failed: %s", path, strerror(errno));
+        return SR_ERR_INVALID;
+    }
+    if (bytes_written) *bytes_written = total;
+    return SR_OK;
+}

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""The vendor reference point for the encoder's GEMM loop: gemm_bf16_kernel (through the C ABI's
+sr_gemm_bf16) and hipBLASLt (through torch.matmul) on the four Lion-1B layer shapes at M = 9 600 / 16 384 / 38 400 / 60 841
+token rows, in ONE process on ONE box, the two alternating shape by shape (same thermal / clock state), same random bf16
+operands.  The product never calls the vendor library; this is a measurement aid.
+
+  python3 tools/gemm_vs_hipblaslt.py [out.json]          ->  profiles/r04_gemm_vs_hipblaslt.json
+"""
+import json
+import os
+import sys
+
+os.environ["SR_DEV_SWITCHES"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from scaling_retriever_amd import _lib as L  # noqa: E402
+
+lib = L.load()
+SHAPES = [("qkv", 3072, 2048), ("o_proj", 2048, 2048), ("gate_up", 16384, 2048), ("down", 2048, 8192)]
+MS = [9600, 16384, 38400, 60841]
+ITERS = 30
+
+
+def timed(fn):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(ITERS):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / ITERS
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_gemm_vs_hipblaslt.json")
+    rows = []
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for M in MS:
+        for name, N, K in SHAPES:
+            A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+            W = (torch.randn((N, K), device="cuda", generator=g) * 0.02).bfloat16()
+            C = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+            Cv = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+            Wt = W.T
+
+            def ours():
+                L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 0, C.data_ptr(), None, L.stream_ptr()))
+
+            def vendor():
+                torch.matmul(A, Wt, out=Cv)
+            fl = 2.0 * M * N * K
+            best = {"ours": 0.0, "vendor": 0.0}
+            for _ in range(3):                         # alternate: neither side always runs on the hotter chip
+                best["ours"] = max(best["ours"], fl / timed(ours) / 1e9)
+                best["vendor"] = max(best["vendor"], fl / timed(vendor) / 1e9)
+            # same operands, same product: the comparison is between two results of the same GEMM
+            err = float((C.float() - Cv.float()).abs().max() / Cv.float().abs().max())
+            row = {"M": M, "shape": name, "N": N, "K": K, "gemm_bf16_kernel_TF": round(best["ours"], 1),
+                   "hipBLASLt_TF": round(best["vendor"], 1), "vendor_over_ours": round(best["vendor"] / best["ours"], 3),
+                   "max_rel_diff": err}
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+    worst = max(r["vendor_over_ours"] for r in rows)
+    summary = {"what": "bf16 GEMM, fp32 accumulate, bf16 output, no fused epilogue on either side; best of 3 alternating rounds "
+                       f"of {ITERS} launches; TFLOP/s; peak 2 500 dense bf16",
+               "device": torch.cuda.get_device_name(0), "rows": rows, "worst_vendor_over_ours": worst,
+               "layer_TF": {str(M): {k: round(sum(2.0 * M * N * K for _, N, K in SHAPES) /
+                                              sum(2.0 * M * r["N"] * r["K"] / r[k] for r in rows if r["M"] == M), 1)
+                                     for k in ("gemm_bf16_kernel_TF", "hipBLASLt_TF")} for M in MS}}
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps({"worst_vendor_over_ours": worst, "layer_TF": summary["layer_TF"]}))
+
+
+if __name__ == "__main__":
+    main()
