@@ -120,14 +120,18 @@ def write_doc_embeds(args):
         dist.barrier()
 
 
-def generate_query_vecs(model, dataloader, device):
-    """DenseRetriever.generate_query_vecs (eval_dense.py:94-106)."""
+def generate_query_vecs(model, dataloader, device, group_rows=16384):
+    """DenseRetriever.generate_query_vecs (eval_dense.py:94-106): no autocast, i.e. the fp32 regime.  The loader's batches
+    (--eval_batch_size rows each, 128 by default: ~1 100 query tokens) are encoded group-wise, one engine pass per group
+    (LlamaBiDense.encode_batches: every row keeps the positions of its own batch, so the vectors are the ones batch-by-batch
+    query_encode calls return, bit for bit), and come back in loader order."""
+    from scaling_retriever_amd.indexer import batch_groups, encode_group
     reps, qids = [], []
-    for batch in dataloader:
-        inputs = {k: v.to(device) for k, v in batch.items() if k != "ids"}
+    for group in batch_groups(dataloader, group_rows):
         with torch.no_grad():
-            reps.append(model.query_encode(**inputs))
-        qids.extend(batch["ids"])
+            reps.append(encode_group(model, group, device, which="query_encode"))
+        for batch in group:
+            qids.extend(batch["ids"])
     return torch.cat(reps), qids
 
 
@@ -159,10 +163,18 @@ class LocalFaissDenseRetriever(DenseRetriever):
         print("size of doc reps indexed: ", total)
 
     def get_top_docs(self, dataloader, top_docs):
-        query_reps, qids = self.generate_query_vecs(dataloader)
+        query_reps, qids = generate_query_vecs(self.model, dataloader, self.device)      # stays on the device
         top_doc_ids, top_scores = self.index.search_knn(query_reps, top_docs)
         assert len(qids) == len(query_reps), (len(qids), len(query_reps))
         return qids, top_doc_ids, top_scores
+
+    def write_run(self, dataloader, top_docs, path):
+        """get_top_docs + the run.json loop of eval_dense.py:225-241 in one go, without materialising a Python object per hit:
+        encode, search, and sr_write_run_json over the result arrays.  Returns (number of queries, file size)."""
+        from scaling_retriever_amd.utils.run_file import write_run_json
+        query_reps, qids = generate_query_vecs(self.model, dataloader, self.device)
+        scores, positions = self.index.search_arrays(query_reps, top_docs)
+        return len(qids), write_run_json(path, qids, scores, positions, self.index.run_table())
 
 
 def retrieval(args):
@@ -206,14 +218,10 @@ def retrieval(args):
         if gs is not None:
             scores, idx = topk_merge(gs, gi)
     if rank == 0:
+        # run.json (eval_dense.py:225-241) straight from the result arrays: the bytes json.dump of the reference's nested dict gives
+        from scaling_retriever_amd.utils.run_file import write_run_json
         doc_ids = np.concatenate([np.load(f) for f in id_files])
-        scores, idx = scores.cpu().numpy(), idx.cpu().numpy()
-        run = {}
-        for qid, row_i, row_s in zip(qids, idx, scores):
-            keep = row_i >= 0
-            run[str(qid)] = {str(doc_ids[j]): float(s) for j, s in zip(row_i[keep], row_s[keep])}
-        with open(os.path.join(args.out_dir, "run.json"), "w") as fout:
-            json.dump(run, fout)
+        write_run_json(os.path.join(args.out_dir, "run.json"), qids, scores.cpu().numpy(), idx.cpu().numpy(), doc_ids)
     if world > 1:
         dist.barrier()
 

@@ -47,22 +47,61 @@ def unpack_topk(packed):
     return scores, ids
 
 
-def gather_topk(scores, ids, dst=0, group=None):
-    """The single collective of doc-sharded retrieval.  Every rank passes its local (scores, global ids)
-    [nq, k]; rank `dst` gets (scores [W,nq,k], ids [W,nq,k]), the others (None, None)."""
+def gather_topk(scores, ids, dst=0, group=None, compact=True):
+    """The single data collective of doc-sharded retrieval.  Every rank passes its local (scores, global ids) [nq, k]; rank `dst`
+    gets (scores [W, nq, k], ids [W, nq, k]), the others (None, None).
+
+    compact: ship only the VALID slots.  With the threshold exchange a dense shard returns what can reach the global top-k -
+    193 of 1 000 slots per query on average at W = 8 - and the rest of its [nq, k] output is padding (id -1); a sparse shard pads
+    rows with fewer than k hits.  A rank's payload is one int64 buffer [nq + cap]: per-row counts, then the packed valid entries
+    in row order; cap = the largest payload over the ranks (one 8-byte all-gather sizes it).  Rank dst lays the entries back into
+    padded [nq, k] rows (valid entries first), which is what sr_topk_merge takes.  When compaction would save less than a quarter
+    of the bytes the full [nq, k] buffer travels instead (no size exchange then is not possible - the ranks must agree - so the
+    decision is taken on the all-gathered sizes)."""
     if _single(group):
         return scores.unsqueeze(0), ids.unsqueeze(0)
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     packed = pack_topk(scores, ids)
     device = packed.device
-    if dist.get_backend(group) == "gloo" and packed.is_cuda:
-        packed = packed.cpu()        # gloo (CPU tests, or several ranks sharing one GPU) has no CUDA gather
-    bufs = [torch.empty_like(packed) for _ in range(W)] if rank == dst else None
-    dist.gather(packed, gather_list=bufs, dst=dst, group=group)
+    use_cpu = dist.get_backend(group) == "gloo"       # gloo (CPU tests, or several ranks sharing one GPU) has no CUDA collectives
+    nq, k = packed.shape
+    if compact:
+        valid = ids >= 0
+        counts = valid.sum(1).to(torch.int64)
+        n_local = counts.sum().reshape(1)
+        sizes = [torch.zeros(1, dtype=torch.int64, device="cpu" if use_cpu else device) for _ in range(W)]
+        dist.all_gather(sizes, n_local.cpu() if use_cpu else n_local, group=group)
+        cap = max(int(t.item()) for t in sizes)
+        compact = (nq + cap) * 4 <= nq * k * 3
+    if not compact:
+        payload = packed.cpu() if use_cpu and packed.is_cuda else packed
+        bufs = [torch.empty_like(payload) for _ in range(W)] if rank == dst else None
+        dist.gather(payload, gather_list=bufs, dst=dst, group=group)
+        if rank != dst:
+            return None, None
+        s, i = zip(*[unpack_topk(b.to(device)) for b in bufs])
+        return torch.stack(s), torch.stack(i)
+    buf = torch.zeros(nq + cap, dtype=torch.int64, device=device)
+    buf[:nq] = counts
+    buf[nq:nq + int(n_local.item())] = packed[valid]
+    payload = buf.cpu() if use_cpu and buf.is_cuda else buf
+    bufs = [torch.empty_like(payload) for _ in range(W)] if rank == dst else None
+    dist.gather(payload, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
         return None, None
-    s, i = zip(*[unpack_topk(b.to(device)) for b in bufs])
-    return torch.stack(s), torch.stack(i)
+    out = torch.full((W, nq, k), -1 << 32, dtype=torch.int64, device=device)      # id -1, score bits 0: padding
+    rows_all = torch.arange(nq, device=device)
+    for r, b in enumerate(bufs):
+        b = b.to(device)
+        c = b[:nq]
+        n = int(c.sum().item())
+        if n == 0:
+            continue
+        rows = torch.repeat_interleave(rows_all, c)
+        cols = torch.arange(n, device=device) - (torch.cumsum(c, 0) - c)[rows]
+        out[r, rows, cols] = b[nq:nq + n]
+    s, i = unpack_topk(out)
+    return s, i
 
 
 def query_slice(n_queries, rank, world_size):
@@ -154,8 +193,9 @@ def sharded_dense_search(index, queries, k, world_size, group=None):
     """One rank's part of a doc-sharded dense search on its DenseIndexHIP: candidates + lower bound, all-reduce(min), exact
     re-score of what can reach the GLOBAL top-k.  Returns this shard's (scores, ids) [nq, k] (possibly padded)."""
     queries = queries.contiguous()
-    if world_size <= 1 or _single(group):       # no process group: the shard's own bound is NOT a global one - plain search
+    if (world_size <= 1 and not FORCE_COLLECTIVES) or _single(group):   # no process group: the shard's own bound is NOT a global one
         return index.search(queries, k)
+    world_size = max(1, world_size)             # FORCE_COLLECTIVES on a world of one (tests): share = 1, the bound is the k-th score
     lower = index.search_begin(queries, k, world_size)
     return index.search_finish(queries, k, all_reduce_min(lower, group=group))
 

@@ -27,6 +27,7 @@ from tqdm import tqdm
 from . import _lib
 from .scoring import DenseIndexHIP, SparseIndexHIP
 from .utils.inverted_index import IndexDictOfArray
+from .utils.run_file import IdTable, RunResult
 from .utils.utils import get_rank, get_world_size, is_first_worker, to_list
 
 logger = logging.getLogger()
@@ -34,6 +35,34 @@ logger = logging.getLogger()
 
 def _unwrap(model):
     return model.module if hasattr(model, "module") else model
+
+
+def batch_groups(loader, max_rows=16384):
+    """Consecutive collator batches of `loader`, grouped until `max_rows` rows: one LlamaBi*.encode_batches call per group.
+    The reference's query loaders yield eval_batch_size (128) rows at a time (eval_dense.py:219-220, eval_sparse.py:125-127);
+    the engine wants tens of thousands of tokens per pass."""
+    group, rows = [], 0
+    for batch in loader:
+        n = len(batch["ids"])
+        if group and rows + n > max_rows:
+            yield group
+            group, rows = [], 0
+        group.append(batch)
+        rows += n
+    if group:
+        yield group
+
+
+def encode_group(model, group, device, which="encode"):
+    """Encode one group of collator batches: encode_batches when the model has it (bit-identical rows, one engine pass),
+    else batch by batch like the reference."""
+    inputs = [{k: v.to(device) for k, v in batch.items() if k != "ids"} for batch in group]
+    if len(inputs) > 1 and hasattr(model, "encode_batches"):
+        return model.encode_batches(inputs)
+    outs = [getattr(model, which)(**i) for i in inputs]
+    if isinstance(outs[0], tuple):
+        return tuple(torch.cat(o) for o in zip(*outs))
+    return torch.cat(outs) if len(outs) > 1 else outs[0]
 
 
 # =============================================================== dense: corpus encode
@@ -156,6 +185,26 @@ class DenseIndexer(object):
         self.index_id_to_db_id.extend(db_ids)
         return len(self.index_id_to_db_id)
 
+    def id_table(self):
+        """index_id_to_db_id as one object array (+ a trailing None for faiss' label -1), rebuilt when the list grew: the id
+        mapping of search_knn is ONE numpy take instead of a Python loop over every hit (indexer.py:212-213)."""
+        n = len(self.index_id_to_db_id)
+        cached = getattr(self, "_id_table", None)
+        if cached is None or len(cached) != n + 1:
+            cached = np.empty(n + 1, dtype=object)
+            cached[:n] = self.index_id_to_db_id
+            cached[n] = None
+            self._id_table = cached
+            self._run_table = None
+        return cached
+
+    def run_table(self):
+        """The same ids as an IdTable (typed keys of run.json)."""
+        self.id_table()
+        if getattr(self, "_run_table", None) is None:
+            self._run_table = IdTable(self.index_id_to_db_id)
+        return self._run_table
+
 
 class DenseFlatIndexer(DenseIndexer):
     """indexer.py:191-217 over a flat inner-product index resident in HBM."""
@@ -185,17 +234,21 @@ class DenseFlatIndexer(DenseIndexer):
         return n
 
     def search_knn(self, query_reps, top_docs: int):
+        scores, indexes = self.search_arrays(query_reps, top_docs)
+        # db ids of every hit in ONE take (the reference maps them hit by hit, indexer.py:212-213); label -1 (fewer than k
+        # vectors) -> the trailing None of the table
+        top_doc_ids = self.id_table()[indexes].tolist()
+        return top_doc_ids, scores
+
+    def search_arrays(self, query_reps, top_docs: int):
+        """(scores fp32 [nq, k], index positions int64 [nq, k]; -1 = fewer than k vectors) as host arrays: what search_knn maps
+        to db ids, and what the run.json writer takes as they are (utils/run_file.py)."""
         if isinstance(query_reps, torch.Tensor):
             q = query_reps.to(device=self.index.device, dtype=torch.float32)
         else:
             q = torch.from_numpy(np.ascontiguousarray(query_reps, dtype=np.float32)).to(self.index.device)
         scores, indexes = self.index.search(q, top_docs)
-        scores, indexes = scores.cpu().numpy(), indexes.cpu().numpy()
-        table = np.empty(len(self.index_id_to_db_id) + 1, dtype=object)
-        table[:-1] = self.index_id_to_db_id
-        table[-1] = None                                    # faiss label -1 (fewer than k vectors)
-        top_doc_ids = [list(table[row]) for row in indexes]
-        return top_doc_ids, scores
+        return scores.cpu().numpy(), indexes.cpu().numpy()
 
     def get_index_name(self):
         return "flat_index"
@@ -370,6 +423,76 @@ def _csr_sorted_by_doc(indptr, doc_ids, vals, device):
     return indptr_t, ids_t, vals_t
 
 
+class QueryCSR:
+    """What _generate_query_vecs returns as `sparse_query_vecs`: the reference's list of (cols int32, vals fp32) pairs per query
+    (indexer.py:393-401), held as ONE CSR on the device (row_ptr int64 [nq + 1], cols int32, vals fp32) - the form
+    sr_sparse_search takes.  It still reads like the list (len, indexing, iteration give the per-query numpy pairs, from a host
+    copy made on first use), so callers of the reference's interface keep working; the HIP scorer never leaves the device."""
+
+    def __init__(self, row_ptr, cols, vals):
+        self.row_ptr, self.cols, self.vals = row_ptr, cols, vals
+        self._host = None
+
+    @classmethod
+    def cat(cls, parts):
+        if len(parts) == 1:
+            return parts[0]
+        ptrs, base = [parts[0].row_ptr], int(parts[0].row_ptr[-1])
+        for p_ in parts[1:]:
+            ptrs.append(p_.row_ptr[1:] + base)
+            base += int(p_.row_ptr[-1])
+        return cls(torch.cat(ptrs), torch.cat([p_.cols for p_ in parts]), torch.cat([p_.vals for p_ in parts]))
+
+    def host(self):
+        if self._host is None:
+            self._host = (self.row_ptr.cpu().numpy(), self.cols.cpu().numpy().astype(np.int32), self.vals.cpu().numpy().astype(np.float32))
+        return self._host
+
+    def __len__(self):
+        return int(self.row_ptr.numel()) - 1
+
+    def __getitem__(self, q):
+        ptr, cols, vals = self.host()
+        if isinstance(q, slice):
+            return [self[i] for i in range(*q.indices(len(self)))]
+        if q < 0:
+            q += len(self)
+        return cols[ptr[q]:ptr[q + 1]], vals[ptr[q]:ptr[q + 1]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def mean_l0(self):
+        n = len(self)
+        return float(self.cols.numel()) / n if n else 0.0
+
+
+def _as_query_csr(sparse_query_vecs, device):
+    if isinstance(sparse_query_vecs, QueryCSR):
+        return sparse_query_vecs
+    counts = [len(c) for c, _ in sparse_query_vecs]
+    row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(device)
+    cols = torch.from_numpy(np.concatenate([np.asarray(c, np.int32) for c, _ in sparse_query_vecs]) if counts else np.zeros(0, np.int32)).to(device)
+    vals = torch.from_numpy(np.concatenate([np.asarray(v, np.float32) for _, v in sparse_query_vecs]) if counts else np.zeros(0, np.float32)).to(device)
+    return QueryCSR(row_ptr, cols, vals)
+
+
+def _doc_id_table(doc_ids, n_docs):
+    """doc_ids.pkl (dict: global doc index -> collection id, docs without a posting absent; indexer.py:271-283) as an array over
+    [0, n_docs): one vectorised look-up per result instead of a dict access per hit."""
+    n = max(int(n_docs), (max(doc_ids) + 1) if len(doc_ids) else 0)
+    keys = np.fromiter(doc_ids.keys(), dtype=np.int64, count=len(doc_ids))
+    vals = list(doc_ids.values())
+    if vals and all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in vals):
+        table = np.full(n, -1, dtype=np.int64)
+        table[keys] = np.asarray(vals, dtype=np.int64)
+        return table
+    table = np.empty(n, dtype=object)
+    table[:] = ""
+    table[keys] = np.asarray(vals, dtype=object)
+    return table
+
+
 class SparseRetrieval:
     """indexer.py:311-540."""
 
@@ -454,48 +577,53 @@ class SparseRetrieval:
         order = np.argsort(idx, kind="stable")
         return idx[order].astype(np.int64), -sc[order]
 
+    QUERY_GROUP_ROWS = 2048      # rows per encode_batches call: the [rows, V] fp32 reps of a group live in HBM (1 GB at V = 128 256)
+
     def _generate_query_vecs(self, q_loader):
-        """indexer.py:382-403: encode queries, keep the nonzero (col, value) pairs per query."""
-        sparse_query_vecs, qids = [], []
-        for t, batch in enumerate(tqdm(q_loader, total=len(q_loader), desc="generate query vecs",
-                                       disable=not is_first_worker())):
-            inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
+        """indexer.py:382-403: encode queries, keep the nonzero (col, value) pairs per query.  The loader's batches are encoded
+        group-wise in one engine pass each (encode_batches: same bits as batch by batch) and the pairs stay on the device as ONE
+        CSR (QueryCSR) - no per-batch .cpu(), no per-query slicing."""
+        parts, qids = [], []
+        for group in tqdm(batch_groups(q_loader, self.QUERY_GROUP_ROWS), desc="generate query vecs", disable=not is_first_worker()):
             with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:390-391
-                batch_sparse_reps = self.model.encode(**inputs)
-            qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
-            row_ptr, cols, vals = sparse_reps_to_csr(batch_sparse_reps)
-            row_ptr, cols, vals = row_ptr.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
-            for b in range(len(row_ptr) - 1):
-                sparse_query_vecs.append((cols[row_ptr[b]:row_ptr[b + 1]].astype(np.int32),
-                                          vals[row_ptr[b]:row_ptr[b + 1]].astype(np.float32)))
-        return sparse_query_vecs, qids
+                reps = encode_group(self.model, group, self.device)
+            for batch in group:
+                qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
+            parts.append(QueryCSR(*sparse_reps_to_csr(reps)))
+            del reps
+        if not parts:
+            dev = self._dev
+            return QueryCSR(torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                            torch.zeros(0, dtype=torch.float32, device=dev)), qids
+        return QueryCSR.cat(parts), qids
+
+    def doc_id_table(self):
+        if getattr(self, "_doc_table", None) is None:
+            self._doc_table = IdTable(_doc_id_table(self.doc_ids, self.sparse_index.nb_docs()))
+        return self._doc_table
 
     def _sparse_retrieve_multithreaded(self, sparse_query_vecs, qids, threshold=0., topk=1000):
-        """indexer.py:405-474 runs 4 Python threads x numba; here the whole query set is one batched HIP
-        search (the doc space is tiled across workgroups instead)."""
-        q_indptr = np.concatenate([[0], np.cumsum([len(c) for c, _ in sparse_query_vecs])]).astype(np.int64)
-        q_cols = np.concatenate([c for c, _ in sparse_query_vecs]) if len(sparse_query_vecs) else np.zeros(0, np.int32)
-        q_vals = np.concatenate([v for _, v in sparse_query_vecs]) if len(sparse_query_vecs) else np.zeros(0, np.float32)
-        scores, ids, counts = self.hip_index.search(q_indptr, q_cols, q_vals, topk, threshold=threshold)
-        scores, ids, counts = scores.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()
-        res = defaultdict(dict)
+        """indexer.py:405-474 runs 4 Python threads x numba and fills res[str(qid)][str(doc_ids[id_])] hit by hit; here the
+        whole query set is one batched HIP search (the doc space is tiled across workgroups instead) and `res` is a RunResult
+        over the result arrays: the same mapping, without 7 M dict insertions."""
+        q = _as_query_csr(sparse_query_vecs, self._dev)
+        scores, ids, counts = self.hip_index.search(q.row_ptr, q.cols, q.vals, topk, threshold=threshold)
+        res = RunResult(qids, scores.cpu().numpy(), ids.cpu().numpy(), self.doc_id_table(), counts.cpu().numpy())
         stats = defaultdict(float)
-        for qi, qid in enumerate(qids):
-            r = res[str(qid)]
-            for id_, sc in zip(ids[qi, :counts[qi]], scores[qi, :counts[qi]]):
-                r[str(self.doc_ids[int(id_)])] = float(sc)
-            stats["L0_q"] += len(sparse_query_vecs[qi][0]) / max(1, len(qids))
+        stats["L0_q"] = q.mean_l0()
         return res, stats
 
-    def retrieve(self, q_loader, topk, threshold=0.):
-        sparse_query_vecs, qids = self._generate_query_vecs(q_loader)
-        res, stats = self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
+    def _write_outputs(self, res, stats):
         os.makedirs(self.out_dir, exist_ok=True)
         if self.compute_stats:
             with open(os.path.join(self.out_dir, "q_stats.json"), "w") as handler:
                 json.dump(stats, handler)
-        with open(os.path.join(self.out_dir, "run.json"), "w") as handler:
-            json.dump(res, handler)
+        res.dump(os.path.join(self.out_dir, "run.json"))        # sr_write_run_json: the bytes json.dump(res) writes
+
+    def retrieve(self, q_loader, topk, threshold=0.):
+        sparse_query_vecs, qids = self._generate_query_vecs(q_loader)
+        res, stats = self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
+        self._write_outputs(res, stats)
         return res
 
 
@@ -543,35 +671,22 @@ class ShardedSparseRetrieval(SparseRetrieval):
         `q_loader.replicated` is set."""
         from .distributed import all_gather_query_csr
         import torch.distributed as dist
-        sparse_query_vecs, qids = self._generate_query_vecs(q_loader)
-        dev = self._dev
-        counts = [len(c) for c, _ in sparse_query_vecs]
-        row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(dev)
-        cols = torch.from_numpy(np.concatenate([c for c, _ in sparse_query_vecs]) if counts else np.zeros(0, np.int32)).to(dev)
-        vals = torch.from_numpy(np.concatenate([v for _, v in sparse_query_vecs]) if counts else np.zeros(0, np.float32)).to(dev)
+        q, qids = self._generate_query_vecs(q_loader)
+        row_ptr, cols, vals = q.row_ptr, q.cols, q.vals
         if self.world_size > 1 and not getattr(q_loader, "replicated", False):
             all_qids = [None] * self.world_size
             dist.all_gather_object(all_qids, qids)
-            qids = [q for part in all_qids for q in part]
+            qids = [q_ for part in all_qids for q_ in part]
             row_ptr, cols, vals = all_gather_query_csr(row_ptr, cols, vals, len(qids))
         scores, ids, counts_t = self.sharded.search(row_ptr, cols, vals, topk, threshold=threshold)
         if scores is None:
             return None
-        scores, ids, counts_t = scores.cpu().numpy(), ids.cpu().numpy(), counts_t.cpu().numpy()
         doc_ids = self._all_doc_ids()
-        res = defaultdict(dict)
-        nnz = (row_ptr[1:] - row_ptr[:-1]).cpu().numpy()
-        stats = {"L0_q": float(nnz.mean()) if len(nnz) else 0.0}
-        for qi, qid in enumerate(qids):
-            r = res[str(qid)]
-            for id_, sc in zip(ids[qi, :counts_t[qi]], scores[qi, :counts_t[qi]]):
-                r[str(doc_ids[int(id_)])] = float(sc)
-        os.makedirs(self.out_dir, exist_ok=True)
-        if self.compute_stats:
-            with open(os.path.join(self.out_dir, "q_stats.json"), "w") as handler:
-                json.dump(stats, handler)
-        with open(os.path.join(self.out_dir, "run.json"), "w") as handler:
-            json.dump(res, handler)
+        n_docs = (max(doc_ids) + 1) if len(doc_ids) else 0
+        res = RunResult(qids, scores.cpu().numpy(), ids.cpu().numpy(), IdTable(_doc_id_table(doc_ids, n_docs)), counts_t.cpu().numpy())
+        nnz = (row_ptr[1:] - row_ptr[:-1])
+        stats = {"L0_q": float(nnz.float().mean().item()) if nnz.numel() else 0.0}
+        self._write_outputs(res, stats)
         return res
 
 
@@ -645,30 +760,24 @@ class HybridRetriever(SparseRetrieval):
         print("size of doc reps to index: ", total)
 
     def _generate_query_vecs(self, q_loader):
-        sparse_query_vecs, dense_query_vecs, qids = [], [], []
-        for t, batch in enumerate(tqdm(q_loader, total=len(q_loader), desc="generate query vecs", disable=not is_first_worker())):
-            inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
+        parts, dense_query_vecs, qids = [], [], []
+        for group in tqdm(batch_groups(q_loader, self.QUERY_GROUP_ROWS), desc="generate query vecs", disable=not is_first_worker()):
             with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):      # indexer.py:938-939
-                batch_sparse_reps, batch_dense_reps = self.model.encode(**inputs)
-            qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
+                batch_sparse_reps, batch_dense_reps = encode_group(self.model, group, self.device)
+            for batch in group:
+                qids.extend(batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))
             dense_query_vecs.append(batch_dense_reps)
-            row_ptr, cols, vals = sparse_reps_to_csr(batch_sparse_reps)
-            row_ptr, cols, vals = row_ptr.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
-            for b in range(len(row_ptr) - 1):
-                sparse_query_vecs.append((cols[row_ptr[b]:row_ptr[b + 1]].astype(np.int32),
-                                          vals[row_ptr[b]:row_ptr[b + 1]].astype(np.float32)))
+            parts.append(QueryCSR(*sparse_reps_to_csr(batch_sparse_reps)))
+            del batch_sparse_reps
+        sparse_query_vecs = QueryCSR.cat(parts)
         dense_query_vecs = torch.cat(dense_query_vecs)
         assert len(sparse_query_vecs) == len(dense_query_vecs) == len(qids)
         return sparse_query_vecs, dense_query_vecs, qids
 
     def _dense_retrieve(self, query_reps, qids, topk=1000):
-        res = defaultdict(dict)
-        top_doc_ids, top_scores = self.dense_index.search_knn(query_reps, topk)
-        for qid, docids, scores in zip(qids, top_doc_ids, top_scores):
-            for docid, score in zip(docids, scores):
-                if docid is not None:
-                    res[str(qid)][str(docid)] = float(score)
-        return res
+        """indexer.py:973-982, as a RunResult over the result arrays (label -1 rows = fewer than k vectors are skipped)."""
+        scores, positions = self.dense_index.search_arrays(query_reps, topk)
+        return RunResult(qids, scores, positions, self.dense_index.run_table())
 
     def _sparse_retrieve(self, sparse_query_vecs, qids, threshold=0., topk=1000):
         return self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
@@ -679,8 +788,6 @@ class HybridRetriever(SparseRetrieval):
         dense_res = self._dense_retrieve(dense_query_vecs, qids, topk=topk)
         with open(os.path.join(self.sparse_out_dir, "q_stats.json"), "w") as handler:
             json.dump(sparse_stats, handler)
-        with open(os.path.join(self.sparse_out_dir, "run.json"), "w") as handler:
-            json.dump(sparse_res, handler)
-        with open(os.path.join(self.dense_out_dir, "run.json"), "w") as handler:
-            json.dump(dense_res, handler)
+        sparse_res.dump(os.path.join(self.sparse_out_dir, "run.json"))
+        dense_res.dump(os.path.join(self.dense_out_dir, "run.json"))
         return sparse_res, dense_res

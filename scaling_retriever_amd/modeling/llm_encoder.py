@@ -300,6 +300,49 @@ class HipLlamaBackbone(torch.nn.Module):
                               out[b0:b1].data_ptr(), stream), what)
         return out if src_device == self._device else out.to(src_device)
 
+    def _encode_many(self, batches, sparse):
+        """Several collator batches in ONE pass of the engine (sr_encode_rows).  batches: [(input_ids [B_i, L_i], attention_mask)].
+        The reference's drivers hand the encoder eval_batch_size rows per call (eval_dense.py:94-106, indexer.py:382-403; 128
+        queries = ~1 100 tokens: 5 rows of 256-row GEMM tiles for 256 CUs); here the rows of all batches are laid right-aligned
+        into one [B, L] matrix (a narrower batch gets extra LEFT padding) with a per-row shift, so every row keeps the
+        position_ids it had in its own batch - its output is bit-identical to encoding that batch alone - and the engine
+        cuts the rows by its token budget, not by the loader's batch size.  Returns the rows of all batches, in order."""
+        if not batches:
+            raise ValueError("encode_batches needs at least one batch")
+        for ids, mask in batches:
+            if ids.dim() != 2 or mask.shape != ids.shape:
+                raise ValueError("input_ids and attention_mask must both be [batch, length]")
+        prec = self.resolve_precision()
+        if prec == "fp32" and self.fp32_planes == 0:
+            raise _lib.SrHipError("fp32-regime encode requested (no torch.autocast(bf16) active) but the model was built with fp32_planes=0")
+        self._ensure_engine(batches[0][0])
+        src_device = batches[0][0].device
+        B = sum(int(i.shape[0]) for i, _ in batches)
+        L = max(int(i.shape[1]) for i, _ in batches)
+        dev = self._device
+        ids = torch.zeros((B, L), dtype=torch.int64, device=dev)
+        mask = torch.zeros((B, L), dtype=torch.int64, device=dev)
+        shift = torch.empty((B,), dtype=torch.int32, device=dev)
+        b0 = 0
+        for bi, bm in batches:
+            n, l = int(bi.shape[0]), int(bi.shape[1])
+            ids[b0:b0 + n, L - l:] = bi.to(device=dev, dtype=torch.int64)
+            mask[b0:b0 + n, L - l:] = bm.to(device=dev, dtype=torch.int64)
+            shift[b0:b0 + n] = L - l
+            b0 += n
+        mode = 2 if sparse == "both" else (1 if sparse else 0)
+        out_s = torch.empty((B, self.config.vocab_size), dtype=torch.float32, device=dev) if mode != 0 else None
+        out_d = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=dev) if mode != 1 else None
+        with torch.cuda.device(dev):
+            stream = _lib.stream_ptr()
+            for r0, r1 in self._call_ranges(mask, sparse is True):
+                _lib.check(self._lib.sr_encode_rows(self._h, ids[r0:r1].data_ptr(), mask[r0:r1].data_ptr(), r1 - r0, L,
+                                                    shift[r0:r1].data_ptr(), mode, int(prec == "fp32"),
+                                                    out_s[r0:r1].data_ptr() if out_s is not None else None,
+                                                    out_d[r0:r1].data_ptr() if out_d is not None else None, stream), "sr_encode_rows")
+        outs = tuple(o if src_device == dev else o.to(src_device) for o in (out_s, out_d) if o is not None)
+        return outs if mode == 2 else outs[0]
+
     def _call_ranges(self, mask, sparse):
         """Row ranges [b0, b1) per C call.  The workspace holds max_batch_tokens PACKED tokens (pads are not computed), so
         a batch whose padded size fits goes through in one call; otherwise the rows are cut by the tokens they really
@@ -367,6 +410,15 @@ class LLM2Retriever(torch.nn.Module):
 
     def query_encode(self, **inputs):
         return self.encode(**inputs)
+
+    _HEAD = None        # False dense, True sparse, "both": which head(s) encode() returns
+
+    def encode_batches(self, batches):
+        """MI355X-side extension of the reference API: `encode` over SEVERAL collator batches in one pass of the engine.
+        batches: a list of dicts with "input_ids" / "attention_mask" [B_i, L_i] (other keys ignored).  Returns what
+        torch.cat([self.encode(**b) for b in batches]) returns - the same bits, row for row (every row keeps the positions it
+        has in its own batch) - but the rows are cut by the engine's token budget instead of the loader's batch size."""
+        return self.base_model._encode_many([(b["input_ids"], b["attention_mask"]) for b in batches], self._HEAD)
 
     def forward(self, **inputs):
         raise NotImplementedError("training losses are out of scope of the MI355X inference path")
@@ -490,6 +542,7 @@ class LLM2Retriever(torch.nn.Module):
 class DecoderOnlyBiSparse(LLM2Retriever):
     """llm_encoder.py:175-196."""
     HAS_LM_HEAD = True
+    _HEAD = True
 
     def __init__(self, base_model):
         super().__init__(base_model)
@@ -507,6 +560,7 @@ class DecoderOnlyBiSparse(LLM2Retriever):
 class DecoderOnlyBiDense(LLM2Retriever):
     """llm_encoder.py:370-520."""
     HAS_LM_HEAD = False
+    _HEAD = False
 
     def __init__(self, base_model, T=0.01):
         super().__init__(base_model)
@@ -546,6 +600,8 @@ class DecoderOnlyBiHybrid(DecoderOnlyBiSparse):
     backbone whose ONE forward pass feeds both heads - the sparse head of llm_encoder.py:186-196 and the dense head of
     :424-443.  (The reference ships the retriever classes but no encoder class of this shape; eval_reranker.py:120 names a
     LlamaBiHybridRetrieverForNCE that is not in the tree.)"""
+
+    _HEAD = "both"
 
     def __init__(self, base_model, T=0.01):
         super().__init__(base_model)

@@ -213,3 +213,30 @@ def test_filter_upper_bound_dominates_the_exact_score():
             fs, fi = f.search(q, 50)
             assert torch.equal(fs, es[:, :50]) and torch.equal(fi, ei[:, :50])
             assert f.filter_query_stats() == (128, 0), (H, kind, f.filter_query_stats())      # no pair violated the bound on the device
+
+
+def test_filtered_with_tiny_norm_rows_next_to_a_large_absmax():
+    """the filter's fp16 plane is scaled by ONE power of two per segment (from the segment's absmax), so rows 2^-20 times
+    smaller land in fp16's subnormal range (or flush to zero) - their plane entries carry almost no bits and the bound has to say
+    so through the per-document residual norms.  A segment mixing unit-scale rows, rows at 2^-12 and rows at 2^-20 of the absmax
+    (some of them the best matches of queries that point at them), one huge outlier element: ids and fp32 scores equal the exact
+    kernel's and the oracle's."""
+    rng = np.random.default_rng(77)
+    H, N, nq, k = 256, 20000, 130, 200
+    D = (rng.standard_normal((N, H), dtype=np.float32) * (0.5 / np.sqrt(H))).astype(np.float32)
+    D[1000:6000] *= np.float32(2.0 ** -12)
+    D[6000:12000] *= np.float32(2.0 ** -20)
+    D[17, 3] = 900.0                                   # the segment's absmax: pushes everything else 2^11 further down the plane
+    Q = (rng.standard_normal((nq, H), dtype=np.float32) * (0.5 / np.sqrt(H))).astype(np.float32)
+    Q[:20] = D[6000:6020] * np.float32(2.0 ** 20)      # queries aligned with tiny rows: those rows' scores are tiny but positive
+    Q[20:40] = -Q[20:40] + D[2000:2020] * np.float32(2.0 ** 13)
+    Q[40:50, 3] = -1.0                                 # the outlier row is the worst match for these
+    (es, ei), (fs, fi), filt = _both([D], Q, k)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    cert, redone = filt.filter_query_stats()
+    assert cert + redone == nq
+    os_, oi = O.topk_rows(O.dense_scores_fma(Q[:50], D, O.mfma_korder(H)), k)
+    assert np.array_equal(fi[:50].cpu().numpy(), oi) and np.array_equal(fs[:50].cpu().numpy(), os_)
+    # the same rows as a segment of their own get their own scale: still exact
+    (es2, ei2), (fs2, fi2), _ = _both([D[:6000], D[6000:12000], D[12000:]], Q, k)
+    assert torch.equal(fi2, ei2) and torch.equal(fs2, es2) and torch.equal(es2, es) and torch.equal(ei2, ei)

@@ -127,7 +127,10 @@ def test_sparse_index_then_retrieval(tiny, tmp_path):
     np.testing.assert_array_equal(retr.sparse_index.index_doc_value[t], reps[reps[:, t] != 0, t])
     res = retr.retrieve(FakeLoader(queries, qids, batch_size=4, pad_id=V - 1), topk=10, threshold=0.0)
     run = json.load(open(tmp_path / "out" / "run.json"))
-    assert run == json.loads(json.dumps(res)) and set(run) == set(qids)
+    # `res` is the reference's nested dict as a read-only mapping over the result arrays; the file holds json.dump of that dict
+    assert run == res.to_dict() == dict(res) and set(run) == set(qids)
+    assert open(tmp_path / "out" / "run.json").read() == json.dumps(res.to_dict())
+    assert res[qids[0]] == run[qids[0]] and list(res[qids[0]]) == list(run[qids[0]])
     assert "L0_q" in json.load(open(tmp_path / "out" / "q_stats.json"))
     # oracle: numba_score_float + select_topk on the SAME index and the SAME query vectors
     indptr, ids, vals = retr.sparse_index.csr(V)

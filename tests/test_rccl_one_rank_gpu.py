@@ -27,8 +27,17 @@ SCRIPT = textwrap.dedent("""
     s[3, 7] = float("-inf")
     i = torch.randint(0, 2 ** 32 - 2, (37, 50), device="cuda", generator=g)
     i[5, 9] = -1
-    gs, gi = D.gather_topk(s, i, dst=0)
+    gs, gi = D.gather_topk(s, i, dst=0, compact=False)
     assert gs.shape == (1, 37, 50) and torch.equal(gs[0], s) and torch.equal(gi[0], i)
+    # the compacting gather ships only the valid slots (one row of padding here is too little: the full buffer travels) ...
+    gs, gi = D.gather_topk(s, i, dst=0)
+    assert torch.equal(gs[0], s) and torch.equal(gi[0], i)
+    # ... and with most slots padding (what a shard returns after the threshold exchange) the valid entries come back first, in order
+    i2 = i.clone()
+    i2[:, 9:] = -1
+    i2[4, :] = -1
+    gs, gi = D.gather_topk(s, i2, dst=0)
+    assert gs.shape == (1, 37, 50) and torch.equal(gi[0], i2) and torch.equal(gs[0][:, :9][i2[:, :9] >= 0], s[:, :9][i2[:, :9] >= 0])
     reps = torch.randn((37, 64), device="cuda", generator=g)
     out = D.all_gather_query_reps(reps, 37)
     assert out.shape == (37, 64) and torch.equal(out, reps)
@@ -50,6 +59,19 @@ SCRIPT = textwrap.dedent("""
     ref = DenseIndexHIP(128)
     ref.add_device_rows(rows)
     es, ei = ref.search(q, 20)
+    assert torch.equal(ss, es) and torch.equal(ii, ei)
+    # a batch the certified filter serves (> 64 queries): search_begin -> all-reduce(min) over RCCL -> search_finish -> gather
+    rows2 = torch.randn((40000, 128), device="cuda", generator=g)
+    q2 = torch.randn((160, 128), device="cuda", generator=g)
+    r2 = ShardedDenseRetriever(128)
+    r2.add_local_rows(rows2)
+    c0, _ = r2.index.filter_query_stats()
+    ss, ii = r2.search(q2, 300)
+    c1, redone = r2.index.filter_query_stats()
+    assert c1 - c0 >= 150, (c0, c1, redone)            # the threshold path ran, and the filter certified the batch
+    ref2 = DenseIndexHIP(128)
+    ref2.add_device_rows(rows2)
+    es, ei = ref2.search(q2, 300)
     assert torch.equal(ss, es) and torch.equal(ii, ei)
     dist.barrier()
     dist.destroy_process_group()
