@@ -321,6 +321,190 @@ def sparse_leg(args, device):
                            "best_shape_on_this_host": {"value": round(best["qps"], 3), "threads": best["q_threads"] * best["inner_threads"],
                                                        "host_cores": cores}}
     idx.close()
+    del idx, h_indptr, h_ids, h_vals
+    torch.cuda.empty_cache()
+    if not args.no_drop_in:
+        out["drop_in"] = drop_in_sparse_leg(args, dict(LION_1B), (indptr, doc_ids, vals, N), (q_indptr, q_cols, q_vals, nq), device)
+    return out
+
+
+def _loader_batches(q_batches_dev, qids, batch):
+    """What DataLoader(query_dataset, batch_size=128, collate_fn=LlamaDenseCollectionCollator) yields: CPU tensors, left-padded to
+    the batch's longest row, ids = the query ids (strings, as MSMARCOQueryDataset keeps them)."""
+    out, r0 = [], 0
+    for ids, mask in q_batches_dev:
+        n = ids.shape[0]
+        out.append({"input_ids": ids.cpu(), "attention_mask": mask.cpu(), "ids": qids[r0:r0 + n]})
+        r0 += n
+    assert all(len(b["ids"]) <= batch for b in out)
+    return out
+
+
+def drop_in_dense_leg(args, cfg, model, index, device, n_local):
+    """The reference's own call path at the full shape: DataLoader batches of --eval_batch_size (128) queries ->
+    LocalFaissDenseRetriever.get_top_docs (generate_query_vecs + DenseFlatIndexer.search_knn, eval_dense.py:94-135) -> the run.json
+    of eval_dense.py:225-241.  Wall times of host + device work, inputs as the loader hands them over (CPU tensors)."""
+    import tempfile
+    import eval_dense
+    from scaling_retriever_amd.indexer import DenseFlatIndexer
+    B = 128
+    q_batches, _ = synth_batches(args.n_queries, B, 2.1, 0.35, 4, 64, cfg["vocab_size"], 2, device)
+    qids = [str(1_000_000 + 7 * i) for i in range(args.n_queries)]
+    loader = _loader_batches(q_batches, qids, B)
+    fi = DenseFlatIndexer()
+    fi.hidden_dim, fi.index = cfg["hidden_size"], index                         # the bench's resident index (no second copy of D)
+    fi._update_id_mapping(np.arange(n_local).astype("U8").tolist())             # MS MARCO pids are decimal strings
+    fi.id_table(), fi.run_table()                                               # built once per index, like the id list itself
+    retriever = eval_dense.LocalFaissDenseRetriever(model, device=device, index=fi)
+
+    def wall(fn, n=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, r
+
+    def per_batch_encode():                     # the reference's loop, one query_encode call per loader batch
+        with torch.no_grad():
+            return torch.cat([model.query_encode(input_ids=b["input_ids"].to(device), attention_mask=b["attention_mask"].to(device)) for b in loader])
+    t_pb, reps_pb = wall(per_batch_encode, 1)
+    t_gq, (reps, _) = wall(lambda: eval_dense.generate_query_vecs(model, loader, device))
+    same_bits = bool(torch.equal(reps, reps_pb))
+    t_knn, (top_ids, top_scores) = wall(lambda: fi.search_knn(reps, args.topk))
+    assert isinstance(top_ids[0], list) and len(top_ids) == args.n_queries
+    t_top, _ = wall(lambda: retriever.get_top_docs(loader, args.topk))
+    tmp = tempfile.mkdtemp(prefix="sr_bench_run_")
+    path = os.path.join(tmp, "run.json")
+    try:
+        t_run, (nq_, nbytes) = wall(lambda: retriever.write_run(loader, args.topk, path))
+        # the file is the reference's: parse a slice of it back and compare with search_knn's lists
+        with open(path) as f:
+            head = f.read(1 << 20)
+        first = json.loads(head[:head.index("}") + 1] + "}")
+        q0 = next(iter(first))
+        assert q0 == qids[0] and list(first[q0])[:50] == [str(x) for x in top_ids[0][:50]]
+        assert abs(list(first[q0].values())[0] - float(top_scores[0][0])) == 0.0
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    nq = args.n_queries
+    out = {"workload": f"{nq} Dev-shaped queries in {len(loader)} loader batches of {B} (CPU tensors, as the DataLoader yields them), "
+                       f"top-{args.topk} over {n_local} x {cfg['hidden_size']}, document ids = decimal strings",
+           "generate_query_vecs": {"ms": round(t_gq * 1e3, 1), "queries_per_s": round(nq / t_gq, 1),
+                                   "note": "loader batches coalesced into one engine pass (encode_batches / sr_encode_rows)",
+                                   "bit_identical_to_one_call_per_batch": same_bits,
+                                   "one_query_encode_call_per_loader_batch_ms": round(t_pb * 1e3, 1)},
+           "search_knn": {"ms": round(t_knn * 1e3, 1), "queries_per_s": round(nq / t_knn, 1),
+                          "note": "sr_dense_search + D2H + ONE numpy take for the db ids + .tolist() (returns the reference's list of lists)"},
+           "get_top_docs": {"ms": round(t_top * 1e3, 1), "queries_per_s": round(nq / t_top, 1)},
+           "retrieval_task_with_run_json": {"ms": round(t_run * 1e3, 1), "queries_per_s": round(nq / t_run, 1), "run_json_bytes": int(nbytes),
+                                            "note": "generate_query_vecs + search + sr_write_run_json (the bytes json.dump of the reference's nested "
+                                                    "dict gives, tests/test_run_file.py): what eval_dense.py --task_name retrieval does after the index is resident"}}
+    assert same_bits, "coalesced query encode differs from the per-batch calls"
+    log("[drop_in dense]", out)
+    return out
+
+
+class _SyntheticSparseQueries:
+    """Stands where SparseRetrieval expects the model.  Random-init weights give sparse reps with ~half the vocabulary active, which
+    no trained Lion-SP model does (L0_q ~ 32), so the REAL HIP encoder runs on every batch (its cost is what is timed) and the
+    reps handed on are the synthetic Zipf query vectors of tools/synth.py for those rows."""
+
+    def __init__(self, model, q_indptr, q_cols, q_vals, V, rows_of):
+        self.model, self.V, self.rows_of = model, V, rows_of
+        self.q_indptr, self.q_cols, self.q_vals = q_indptr, q_cols, q_vals
+        self.vocab_size = V
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def _reps(self, first_row, n):
+        dev = self.q_cols.device
+        lo, hi = int(self.q_indptr[first_row]), int(self.q_indptr[first_row + n])
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), self.q_indptr[first_row + 1:first_row + n + 1] - self.q_indptr[first_row:first_row + n])
+        reps = torch.zeros((n, self.V), dtype=torch.float32, device=dev)
+        reps[rows, self.q_cols[lo:hi].long()] = self.q_vals[lo:hi]
+        return reps
+
+    def encode(self, **inputs):
+        self.model.encode(**inputs)
+        return self._reps(self.rows_of[inputs["input_ids"].data_ptr()], inputs["input_ids"].shape[0])
+
+    def encode_batches(self, batches):
+        self.model.encode_batches(batches)
+        first = self.rows_of[batches[0]["input_ids"].data_ptr()]
+        return self._reps(first, sum(b["input_ids"].shape[0] for b in batches))
+
+
+def drop_in_sparse_leg(args, cfg_model, idx_parts, q_parts, device):
+    """SparseRetrieval.retrieve (indexer.py:530-540) at the full shape: loader batches of 128 -> _generate_query_vecs (real HIP sparse
+    encoder at Lion-SP-1B dims on every batch; see _SyntheticSparseQueries) -> sr_sparse_search -> q_stats.json + run.json."""
+    import shutil
+    import tempfile
+    from scaling_retriever_amd.indexer import SparseRetrieval
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiSparse
+    from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+    indptr, doc_ids, vals, N = idx_parts
+    q_indptr, q_cols, q_vals, nq = q_parts
+    V, B = cfg_model["vocab_size"], 128
+    model = LlamaBiSparse.from_weights(cfg_model, random_weights(cfg_model, device, seed=9), max_batch_tokens=32768, max_batch_seqs=4096,
+                                       fp32_planes=0).to(device).eval()
+    q_batches, _ = synth_batches(nq, B, 2.1, 0.35, 4, 64, V, 2, device)
+    qids = [str(1_000_000 + 7 * i) for i in range(nq)]
+    loader = _loader_batches(q_batches, qids, B)
+
+    class _Loader(list):
+        pass
+    # SparseRetrieval moves a batch to the device before encode(): remember which rows a batch holds by its position
+    rows_of, r0 = {}, 0
+    dev_loader = _Loader()
+    for b in loader:
+        db = {"input_ids": b["input_ids"].to(device), "attention_mask": b["attention_mask"].to(device), "ids": b["ids"]}
+        rows_of[db["input_ids"].data_ptr()] = r0
+        r0 += len(b["ids"])
+        dev_loader.append(db)
+    stub = _SyntheticSparseQueries(model, q_indptr, q_cols, q_vals, V, rows_of)
+    container = IndexDictOfArray(dim_voc=V)
+    container.set_device_csr(indptr, doc_ids, vals, N)
+    index_d = {"index": container, "ids_mapping": {i: str(i) for i in range(N)}, "device_csr": (indptr, doc_ids, vals, N)}
+    tmp = tempfile.mkdtemp(prefix="sr_bench_sprun_")
+    try:
+        retr = SparseRetrieval(stub, {"out_dir": tmp}, V, device, index_d=index_d, compute_stats=True)
+        retr.doc_id_table()                                                  # per index, like doc_ids.pkl itself
+        retr.retrieve(dev_loader, args.topk, threshold=0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = retr.retrieve(dev_loader, args.topk, threshold=0.0)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        qv, _ = retr._generate_query_vecs(dev_loader)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        retr._sparse_retrieve_multithreaded(qv, qids, threshold=0.0, topk=args.topk)
+        torch.cuda.synchronize()
+        t_ret = time.perf_counter() - t0
+        nbytes = os.path.getsize(os.path.join(tmp, "run.json"))
+        with open(os.path.join(tmp, "run.json")) as f:
+            head = f.read(1 << 20)
+        first = json.loads(head[:head.index("}") + 1] + "}")
+        assert next(iter(first)) == qids[0] and first[qids[0]] == res[qids[0]]
+        l0 = json.load(open(os.path.join(tmp, "q_stats.json")))["L0_q"]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        retr.hip_index.close()
+    del model
+    out = {"workload": f"SparseRetrieval.retrieve: {nq} queries in {len(dev_loader)} loader batches of {B}, real HIP LlamaBiSparse encode at 1B dims per "
+                       f"group + the synthetic Zipf query vectors (random weights give no realistic L0), top-{args.topk}, q_stats.json + run.json",
+           "retrieve": {"ms": round(t_all * 1e3, 1), "queries_per_s": round(nq / t_all, 1), "run_json_bytes": int(nbytes), "L0_q": l0},
+           "generate_query_vecs_ms": round(t_gen * 1e3, 1), "search_to_RunResult_ms": round(t_ret * 1e3, 1)}
+    log("[drop_in sparse]", out)
     return out
 
 
@@ -420,6 +604,8 @@ def main():
     ap.add_argument("--exact-kernel", action="store_true", help="headline through the exact fp32 MFMA kernel instead of the certified filter")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 / bf16x6 precision-mode measurements")
     ap.add_argument("--no-shard-leg", action="store_true", help="skip the shard_1of8 leg (one of 8 doc shards with the threshold exchange)")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in legs (the reference's own call path: loader batches of 128 -> "
+                    "get_top_docs / SparseRetrieval.retrieve -> run.json)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the filter_robustness legs (anisotropic / near-duplicate corpora at full shape)")
     args = ap.parse_args()
 
@@ -572,6 +758,11 @@ def main():
     t_search = time.perf_counter() - tb
     breakdown = {"query_encode_ms": round(t_enc * 1e3, 1), "search_ms": round(t_search * 1e3, 1),
                  "query_tokens": int(q_lens.sum()), "query_encode_calls": len(q_batches)}
+
+    # ---- the reference's own call path at the same shape: loader batches of 128 -> get_top_docs -> run.json ----
+    drop_in = None
+    if world == 1 and filtered and not args.no_drop_in:
+        drop_in = drop_in_dense_leg(args, cfg, model, index, device, n_local)
 
     # ---- the same step with the score kernel in split-bf16 arithmetic (opt-in precision modes of sr_dense_search;
     #      fp32 operands split into bf16 planes, 3 / 6 plane products on the bf16 MFMA pipe, fp32 accumulate) ----
@@ -865,7 +1056,7 @@ def main():
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "exact_kernel_mode": exact_mode, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,
-            "shard_1of8": shard_leg, "filter_robustness": robustness, "encode": encode, "sparse": sparse, "config5_8b": config5,
+            "drop_in": drop_in, "shard_1of8": shard_leg, "filter_robustness": robustness, "encode": encode, "sparse": sparse, "config5_8b": config5,
         }
         print(json.dumps(res), flush=True)
     if world > 1:
