@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
@@ -42,8 +43,11 @@ typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 // WAVES_N x WAVES_M waves; each wave owns (16 * NB) features x (16 * MB) tokens.
 // PIPE: fragment double-buffering - the ds_reads of the next half k-step are in flight while the MFMAs of the current
 // half run, stages are issued two k-steps ahead, still one barrier per k-step (placed between the two halves).
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2>
-__global__ __launch_bounds__(64 * WAVES_N * WAVES_M, (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
+// KL = 1: the FOUR-wave k-loop of the 256 x 256 tile (2 x 2 waves of 128 x 128, one wave per SIMD, the 256 accumulator registers of a
+// lane in AGPRs), written instruction by instruction: see the KL == 1 branch below.
+typedef int sr_i32x4 __attribute__((ext_vector_type(4)));
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2, int KL = 0>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_M, KL == 1 ? 1 : (WAVES_N * WAVES_M) / 4 * (WAVES_N * WAVES_M == 4 ? 2 : 1))
 void gemm_bf16_kernel(GemmArgs g) {
     constexpr bool F16 = EPI >= EPI_H_FIRST;          // fp16 plane operands + row scales (fp32 regime), see kernels.h
     constexpr int BEPI = !F16 ? EPI : (EPI == EPI_QKV_ROPE_F32_H ? EPI_QKV_ROPE_F32 : (EPI == EPI_RESID_F32_H ? EPI_RESID_F32
@@ -136,15 +140,36 @@ void gemm_bf16_kernel(GemmArgs g) {
     unsigned long long* stp = g.stamps ? g.stamps + (size_t)blockIdx.x * 64 : nullptr;   // up to 16 tiles x 4 stamps
     int titer = 0;
     if (stamp) stp[0] = __builtin_amdgcn_s_memrealtime();
-    set_tile(tile);
-    stage(0, 0);
-    if constexpr (PIPE) stage(1, G_BK);     // PIPE needs nk >= 2 (checked at launch)
-    if constexpr (PIPE && NS > 2) {
+    if constexpr (KL == 0) {
+        set_tile(tile);
+        stage(0, 0);
+        if constexpr (PIPE) stage(1, G_BK);     // PIPE needs nk >= 2 (checked at launch)
+        if constexpr (PIPE && NS > 2) {
 #pragma unroll
-        for (int st = 2; st < NS; ++st) stage(st, st * G_BK);     // NS stages need nk >= NS (checked at launch)
+            for (int st = 2; st < NS; ++st) stage(st, st * G_BK);     // NS stages need nk >= NS (checked at launch)
+        }
+        __syncthreads();
     }
-    __syncthreads();
     int buf = 0;
+    // ---- KL == 1 state (see the branch in the tile loop) ----
+    // LDS-DMA through buffer loads: a buffer descriptor per operand (base = the tile's first row, bounds = its valid rows: rows past
+    // the end of the matrix read as zeros - their outputs are never stored), a per-lane byte offset (piece, row inside the 8-row
+    // piece, swizzled 16-byte chunk: the same 8 registers for every tile and both operands; it is what gfx9 range-checks) and ONE
+    // scalar offset, the k position inside the rows, which advances by 128 bytes per k-step: no vector instruction computes an
+    // address inside the k-loop
+    [[maybe_unused]] sr_i32x4 srd_w, srd_a;
+    [[maybe_unused]] uint32_t kl_koff = 0, kl_m0 = 0, kl_bw0 = 0, kl_bw1 = 0, kl_ba0 = 0, kl_ba1 = 0;
+    [[maybe_unused]] uint32_t kl_voff[8];
+    [[maybe_unused]] auto kl_rebase = [&](int t) {        // descriptors of tile slot t, k = 0
+        int tn_i, tm_i;
+        (void)slot_tile(t, tn_i, tm_i);
+        const int tn0 = tn_i * BN, tm0 = tm_i * BM;
+        const uint64_t pw = reinterpret_cast<uint64_t>(g.W + (int64_t)tn0 * K), pa = reinterpret_cast<uint64_t>(g.A + (int64_t)tm0 * K);
+        const int rows_w = (g.N - tn0) < BN ? (g.N - tn0) : BN, rows_a = (g.M - tm0) < BM ? (g.M - tm0) : BM;
+        srd_w[0] = (int)(uint32_t)pw; srd_w[1] = (int)(uint32_t)(pw >> 32); srd_w[2] = rows_w * K * 2; srd_w[3] = 0x00020000;
+        srd_a[0] = (int)(uint32_t)pa; srd_a[1] = (int)(uint32_t)(pa >> 32); srd_a[2] = rows_a * K * 2; srd_a[3] = 0x00020000;
+        kl_koff = 0;
+    };
     auto load_frags = [&](int st, int kk, mfma_bf16x8 (&wf)[NB], mfma_bf16x8 (&af)[MB]) {
         const unsigned char* wt = smem + st * STAGE_BYTES;
         const unsigned char* at = wt + W_BYTES;
@@ -163,8 +188,22 @@ void gemm_bf16_kernel(GemmArgs g) {
             for (int j = 0; j < MB; ++j)
                 acc[i][j] = sr_mma<F16>(wf[i], af[j], acc[i][j]);
     };
+    if constexpr (KL == 1) {
+        const uint32_t lds0 = (uint32_t)(size_t)(lds_void_ptr)smem;
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kl_voff[i] = (uint32_t)(((wave_s * 8 + i) * 8 + srow) * K * 2 + schunk * 16);
+        kl_m0 = lds0 + (uint32_t)wave_s * 8192u;                          // this wave's 8 pieces of stage 0's weight rows
+        // fragment addresses: row (wave's first + frow) of block 0, k-half 0 / 1; blocks are 2048 bytes apart (immediates)
+        const uint32_t c0 = (uint32_t)((fg ^ (frow & 7)) * 16), c1 = (uint32_t)(((4 + fg) ^ (frow & 7)) * 16);
+        kl_bw0 = lds0 + (uint32_t)((wn * 128 + frow) * 128) + c0;
+        kl_bw1 = lds0 + (uint32_t)((wn * 128 + frow) * 128) + c1;
+        kl_ba0 = lds0 + (uint32_t)W_BYTES + (uint32_t)((wm * 128 + frow) * 128) + c0;
+        kl_ba1 = lds0 + (uint32_t)W_BYTES + (uint32_t)((wm * 128 + frow) * 128) + c1;
+    }
     // Persistent over tiles (grid <= one round of resident workgroups): the first k-tile(s) of the NEXT output tile are
     // prefetched during the last k-step(s) of the current one, so only the epilogue's stores stay exposed between tiles.
+    [[maybe_unused]] bool kl_first = true;
     for (; tile < slot_limit;) {
     int tn_i, tm_i;
     (void)slot_tile(tile, tn_i, tm_i);
@@ -185,7 +224,146 @@ void gemm_bf16_kernel(GemmArgs g) {
     }
     if (stamp && titer < 16) stp[titer * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (stamp && titer == 1) stp[62] = __builtin_amdgcn_s_memtime();        // shader-clock ticks at the start of tile 1's k-loop
-    if constexpr (PIPE && NS > 2) {
+    if constexpr (KL == 1) {
+        // 256 x 256 tile on FOUR waves (2 x 2, wave tile 128 features x 128 tokens, v_mfma_f32_16x16x32: 8 x 8 blocks = 256
+        // accumulator registers per lane, one wave per SIMD).  Per k-step of 64 a CU then reads 128 KB of fragments out of LDS
+        // instead of the 8-wave layout's 192 KB (+ 64 KB of LDS-DMA writes either way): 1 536 LDS cycles against 2 048 MFMA cycles
+        // instead of 2 048 against 2 048 - the 8-wave loops sit where both pipes saturate together (0.48-0.52 of the MFMA peak).
+        // It is the configuration the vendor library runs on these shapes (hipBLASLt's MT256x256x64 MI16x16x1 kernel: 256
+        // threads, 130 KB of LDS, accumulators in AGPRs; 1.1-1.28x the 8-wave loop, profiles/r04_gemm_vs_hipblaslt.json).  With ONE
+        // wave per SIMD nothing hides a stall and hipcc's register allocator shuffles the 256 accumulators between VGPRs and
+        // AGPRs when it is left to place them, so the k-step is written instruction by instruction (volatile asm statements are
+        // emitted in program order; "+a" pins an accumulator to its AGPR quad for the whole loop):
+        //   * two register sets of fragments (k-half 0 / 1: 8 + 8 ds_read_b128 each), every read issued under the MFMAs of the
+        //     k-half before its first use, one read per 2 MFMAs;
+        //   * the LDS-DMA pieces of k-step kt + 2 go into the stage k-step kt is read from as soon as a barrier says every wave
+        //     has read it (40 MFMAs into the k-step) - a piece has ~1.6 k-steps to land, not < 1 - one piece per 3 MFMAs;
+        //   * a second barrier behind a COUNTED vmcnt (the 16 pieces just issued stay in flight) publishes k-step kt + 1 in the
+        //     other stage 24 MFMAs into k-half 1, and the first fragments of k-step kt + 1 are read under the remaining 40;
+        //   * the last two k-steps of a tile fetch the NEXT tile's first two, and the very last one already reads its first
+        //     fragments: the loop runs across tile boundaries, only the epilogue sits in between.
+        // Every output element is the same k-ordered MFMA chain as in the other tile configurations: bit-identical results.
+        static_assert(PIPE && NS == 2 && NW == 4 && NB == 8 && MB == 8 && WAVES_N == 2, "KL = 1 is the 2 x 2 x (128 x 128) configuration");
+        sr_i32x4 w0[8], a0[8], w1[8], a1[8];      // fragments (16 bytes = 8 bf16 / fp16 per lane), k-half 0 and 1
+        // accumulators of weight row blocks 0-6 in AGPRs (224 of the 256), those of row block 7 in VGPRs: with every AGPR pinned
+        // the register allocator has no room for a single copy and spills accumulators to scratch inside the loop
+#define KL_MMA(C, WF, AF, INV)                                                                                      \
+        do {                                                                                                        \
+            if constexpr (F16) {                                                                                    \
+                if (INV) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(C) : "v"(WF), "v"(AF)); \
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(C) : "v"(WF), "v"(AF));              \
+            } else {                                                                                                \
+                if (INV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C) : "v"(WF), "v"(AF)); \
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(WF), "v"(AF));             \
+            }                                                                                                       \
+        } while (0)
+#define KL_DSR(DST, BASE, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "n"(OFF))
+#define KL_DMA(SRD, VOFF, KOFF, M0B, M0OFF)                                                                         \
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(KOFF), "s"(M0B), "n"(M0OFF) : "memory", "scc")
+        // MFMA number n (0..63) of a k-half: row block n / 8 of the weights x token block n % 8
+#define KL_MMA_N(n, WS, AS) KL_MMA(acc[(n) >> 3][(n) & 7], WS[(n) >> 3], AS[(n) & 7], (((n) >> 3) == 7))
+        // fragment read number r (0..15): 0-7 weight blocks, 8-15 token blocks, of k-half KH
+#define KL_DSR_N(r, WS, AS, BW, BA)                                                 \
+        do {                                                                         \
+            if ((r) < 8) KL_DSR(WS[(r) & 7], BW, ((r) & 7) * 2048);                  \
+            else KL_DSR(AS[(r) & 7], BA, ((r) & 7) * 2048);                          \
+        } while (0)
+        auto kstep = [&]() {
+            // the descriptors and offsets are wave-uniform, but they are loop-carried through the tile switch and the register
+            // allocator is free to keep them in VGPRs: readfirstlane pins what the buffer instructions need in SGPRs
+            sr_i32x4 sw, sa;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sw[c] = __builtin_amdgcn_readfirstlane(srd_w[c]);
+                sa[c] = __builtin_amdgcn_readfirstlane(srd_a[c]);
+            }
+            const uint32_t koff = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_koff);
+            const uint32_t m0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_m0);
+            // ---- k-half 0: 64 MFMAs on (w0, a0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {          // MFMAs 0-31 + the 16 fragment reads of k-half 1 (this stage)
+                KL_MMA_N(2 * r, w0, a0);
+                KL_MMA_N(2 * r + 1, w0, a0);
+                KL_DSR_N(r, w1, a1, kl_bw1, kl_ba1);
+            }
+#pragma unroll
+            for (int n = 32; n < 40; ++n) KL_MMA_N(n, w0, a0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read all of this stage
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {           // MFMAs 40-63 + the 8 weight pieces of the k-step two ahead
+                KL_MMA_N(40 + 3 * r, w0, a0);
+                KL_MMA_N(41 + 3 * r, w0, a0);
+                KL_MMA_N(42 + 3 * r, w0, a0);
+                KL_DMA(sw, kl_voff[r], koff, m0b, r * 1024);
+            }
+            // ---- k-half 1: 64 MFMAs on (w1, a1)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {           // MFMAs 0-23 + the 8 activation pieces
+                KL_MMA_N(3 * r, w1, a1);
+                KL_MMA_N(3 * r + 1, w1, a1);
+                KL_MMA_N(3 * r + 2, w1, a1);
+                KL_DMA(sa, kl_voff[r], koff, m0b, W_BYTES + r * 1024);
+            }
+            // the 16 pieces of the NEXT k-step were issued one k-step ago: they have landed once at most the 16 just issued are
+            // outstanding; the barrier publishes every wave's share
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            // the other stage from here on
+            kl_bw0 ^= 0x10000u; kl_bw1 ^= 0x10000u; kl_ba0 ^= 0x10000u; kl_ba1 ^= 0x10000u;
+            kl_m0 ^= 0x10000u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {          // MFMAs 24-55 + the 16 fragment reads of the next k-step's k-half 0
+                KL_MMA_N(24 + 2 * r, w1, a1);
+                KL_MMA_N(25 + 2 * r, w1, a1);
+                KL_DSR_N(r, w0, a0, kl_bw0, kl_ba0);
+            }
+#pragma unroll
+            for (int n = 56; n < 64; ++n) KL_MMA_N(n, w1, a1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        if (kl_first) {       // the workgroup's first tile: k-steps 0 and 1 into the two stages, first fragments
+            kl_first = false;
+            kl_rebase(tile);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                sr_i32x4 sw, sa;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sw[c] = __builtin_amdgcn_readfirstlane(srd_w[c]);
+                    sa[c] = __builtin_amdgcn_readfirstlane(srd_a[c]);
+                }
+                const uint32_t koff = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_koff);
+                const uint32_t m0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_m0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) KL_DMA(sw, kl_voff[r], koff, m0b, r * 1024);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) KL_DMA(sa, kl_voff[r], koff, m0b, W_BYTES + r * 1024);
+                kl_koff += 128;
+                kl_m0 ^= 0x10000u;
+            }
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) KL_DSR_N(r, w0, a0, kl_bw0, kl_ba0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // invariant at the top of k-step kt: (w0, a0) hold its k-half 0; stage kt % 2 (kl_b*, kl_m0) holds it, the other stage
+        // k-step kt + 1 (landed or landing); the descriptors + kl_koff point at k-step kt + 2
+        // ONE copy of the k-step in the code (the accumulators keep their registers): the last two k-steps of the workgroup's last
+        // tile issue their pieces against empty descriptors - every lane is out of range, nothing is fetched, zeros land in a
+        // stage nobody reads again
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 == nk) {
+                if (has_next) kl_rebase(tile_next);
+                else { srd_w[2] = 0; srd_a[2] = 0; }
+            }
+            kstep();
+            kl_koff += 128;
+        }
+#undef KL_MMA
+#undef KL_DSR
+#undef KL_DMA
+#undef KL_MMA_N
+#undef KL_DSR_N
+    } else if constexpr (PIPE && NS > 2) {
         // NS LDS stages (small tiles, where a workgroup has a CU's MFMA pipe to itself or shares it with one other):
         // the LDS-DMA of k-step kt + NS is issued when k-step kt's stage is released, so a piece has NS - 1 k-steps to
         // land and the wait before the barrier only covers pieces issued NS - 1 k-steps ago (counted vmcnt; the barrier is
@@ -648,14 +826,14 @@ void gemm_bf16_kernel(GemmArgs g) {
     }  // tile loop
 }
 
-template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2>
+template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2, int KL = 0>
 static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
     constexpr size_t lds = NS * (size_t)(BN + BM) * 128;
     static DeviceOnce attr_once;
     bool* attr_slot = attr_once.pending();
     if (attr_slot) {
-        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>),
+        SR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS, KL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         *attr_slot = true;
     }
@@ -673,7 +851,7 @@ static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int64_t by_lds = (160 * 1024) / lds;
     const int64_t slots = 256 * (WAVES_N * WAVES_M == 4 ? (by_lds > 3 ? 3 : by_lds) : (WAVES_N * WAVES_M == 1 ? (by_lds > 8 ? 8 : by_lds) : 1));
     if (!(env && *env == '0') && tiles > slots) tiles = slots;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, WAVES_N, WAVES_M, NB, MB, PIPE, NS, KL>), dim3((unsigned)tiles), dim3(64 * WAVES_N * WAVES_M), lds,
                        s, g);
     SR_CHECK_LAUNCH();
     return SR_OK;
@@ -738,6 +916,14 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         }
     }
     const char* env = sr_dev_getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
+    {
+        // SR_GEMM_BIG=8w: the 8-wave loop (A/B); default: the four-wave loop.  Its buffer descriptors address a tile's rows with
+        // 32-bit byte offsets: 256 rows x 2 K bytes must stay below 2^31
+        const char* big = sr_dev_getenv("SR_GEMM_BIG");
+        const bool want8 = big && big[0] == '8';
+        if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && !(env && *env == '0'))
+            return launch_cfg<EPI, 2, 2, 8, 8, true, 2, 1>(g, s);
+    }
     if (g.K / G_BK >= 4 && !(env && *env == '0')) return launch_cfg<EPI, 2, 4, 8, 4, true>(g, s);
     return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);
 }

@@ -492,3 +492,37 @@ def test_gemm_few_token_rows_streaming_configuration(M, monkeypatch):
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     torch.testing.assert_close(got[0], A.float() @ W.float().T, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 800, 256), (16384, 2048, 320), (9000, 3072, 2048), (2100, 16384, 256), (66000, 512, 1024)])
+def test_gemm_four_wave_loop_equals_eight_wave_loop(M, N, K, monkeypatch):
+    """The 256 x 256 tile runs on FOUR waves of 128 x 128 by default (the vendor library's configuration: hand-ordered k-step,
+    accumulators in AGPRs, LDS-DMA through buffer descriptors two k-steps ahead); SR_GEMM_BIG=8w selects the 8-wave loop.  Every
+    output element is the same k-ordered MFMA chain in both: all epilogues bit-identical, on ragged shapes (rows past the matrix
+    read as zeros through the descriptor's bounds), on 4 k-steps (the loop's minimum), an odd count, and on more tiles than
+    resident workgroups (the k-loop runs across tile boundaries: the last two k-steps fetch the next tile's first two)."""
+    monkeypatch.setenv("SR_GEMM_TILE", "256")
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    W = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).bfloat16()
+    seq_of = torch.sort(torch.randint(0, 37, (M,), device="cuda", generator=g)).values.to(torch.int32)
+    seq_of[5:9] = -2
+    X0 = torch.randn((M, N), device="cuda", generator=g)
+
+    def all_epilogues():
+        X = X0.clone()
+        _gemm(A, W, 1, C=X)
+        return [_gemm(A, W, 4), _gemm(A, W, 0), X, _gemm(A, W, 2), _gemm(A, W, 3, seq_of=seq_of, n_seq=37)]
+    monkeypatch.setenv("SR_GEMM_BIG", "8w")
+    ref = all_epilogues()
+    monkeypatch.delenv("SR_GEMM_BIG")
+    for _ in range(2):
+        got = all_epilogues()
+        for name, a, b in zip(("f32", "bf16", "residual", "swiglu", "segmax"), got, ref):
+            assert torch.equal(a, b), name
+    torch.testing.assert_close(got[0][:300], A[:300].float() @ W.float().T, rtol=1e-4, atol=1e-4)
+    # a NaN-filled output: a tile nobody computed cannot go unnoticed
+    L, lib = _lib()
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()), "sr_gemm_bf16")
+    assert torch.equal(C, ref[0])
