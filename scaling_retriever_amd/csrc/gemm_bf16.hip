@@ -268,6 +268,23 @@ void gemm_bf16_kernel(GemmArgs g) {
             if ((r) < 8) KL_DSR(WS[(r) & 7], BW, ((r) & 7) * 2048);                  \
             else KL_DSR(AS[(r) & 7], BA, ((r) & 7) * 2048);                          \
         } while (0)
+        // The k-step as a list of events behind its 128 MFMAs (0-63: k-half 0 on (w0, a0), 64-127: k-half 1 on (w1, a1)):
+        //   reads of k-half 1 (this stage): one per KL_RD1_EVERY MFMAs from the start;
+        //   barrier 1 after MFMA KL_B1_AT: every wave has read all of this stage;
+        //   the 16 LDS-DMA pieces of the k-step two ahead (8 weight, 8 activation) into this stage: one per KL_DMA_EVERY MFMAs;
+        //   barrier 2 after MFMA KL_B2_AT behind vmcnt(16): the NEXT k-step's pieces (issued one k-step ago) have landed;
+        //   reads of the next k-step's k-half 0 (other stage): one per KL_RD2_EVERY MFMAs; lgkmcnt(0) at the end.
+        // The LDS pipe is 75 % busy over a k-step (128 KB of fragment reads + 64 KB of landing pieces against 2 048 MFMA cycles),
+        // so where the reads sit matters: clustered reads make the wait in front of a barrier stall the MFMA stream.
+#ifndef KL_RD1_EVERY
+#define KL_RD1_EVERY 2
+#define KL_B1_AT 39
+#define KL_DMA_EVERY 3
+#define KL_B2_AT 87
+#define KL_RD2_EVERY 2
+#endif
+        static_assert(16 * KL_RD1_EVERY - 1 <= KL_B1_AT && KL_B1_AT + 16 * KL_DMA_EVERY <= KL_B2_AT && KL_B2_AT + 16 * KL_RD2_EVERY <= 127,
+                      "k-step schedule");
         auto kstep = [&]() {
             // the descriptors and offsets are wave-uniform, but they are loop-carried through the tile switch and the register
             // allocator is free to keep them in VGPRs: readfirstlane pins what the buffer instructions need in SGPRs
@@ -279,45 +296,43 @@ void gemm_bf16_kernel(GemmArgs g) {
             }
             const uint32_t koff = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_koff);
             const uint32_t m0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)kl_m0);
-            // ---- k-half 0: 64 MFMAs on (w0, a0)
+            // (short unrolled loops: one 128-iteration loop is unrolled too late for the accumulator array to leave memory)
+#define KL_MMA_G(n)                                        \
+            do {                                           \
+                if ((n) < 64) KL_MMA_N((n) & 63, w0, a0);  \
+                else KL_MMA_N((n) & 63, w1, a1);           \
+            } while (0)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {          // MFMAs 0-31 + the 16 fragment reads of k-half 1 (this stage)
-                KL_MMA_N(2 * r, w0, a0);
-                KL_MMA_N(2 * r + 1, w0, a0);
+            for (int r = 0; r < 16; ++r) {                 // MFMAs 0 .. 16 RD1 - 1, a read of k-half 1 behind every RD1-th
+#pragma unroll
+                for (int t = 0; t < KL_RD1_EVERY; ++t) KL_MMA_G(r * KL_RD1_EVERY + t);
                 KL_DSR_N(r, w1, a1, kl_bw1, kl_ba1);
             }
 #pragma unroll
-            for (int n = 32; n < 40; ++n) KL_MMA_N(n, w0, a0);
+            for (int n = 16 * KL_RD1_EVERY; n <= KL_B1_AT; ++n) KL_MMA_G(n);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read all of this stage
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {           // MFMAs 40-63 + the 8 weight pieces of the k-step two ahead
-                KL_MMA_N(40 + 3 * r, w0, a0);
-                KL_MMA_N(41 + 3 * r, w0, a0);
-                KL_MMA_N(42 + 3 * r, w0, a0);
-                KL_DMA(sw, kl_voff[r], koff, m0b, r * 1024);
-            }
-            // ---- k-half 1: 64 MFMAs on (w1, a1)
+            for (int r = 0; r < 16; ++r) {                 // a piece of the k-step two ahead behind every DMA-th MFMA
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {           // MFMAs 0-23 + the 8 activation pieces
-                KL_MMA_N(3 * r, w1, a1);
-                KL_MMA_N(3 * r + 1, w1, a1);
-                KL_MMA_N(3 * r + 2, w1, a1);
-                KL_DMA(sa, kl_voff[r], koff, m0b, W_BYTES + r * 1024);
+                for (int t = 0; t < KL_DMA_EVERY; ++t) KL_MMA_G(KL_B1_AT + 1 + r * KL_DMA_EVERY + t);
+                if (r < 8) KL_DMA(sw, kl_voff[r & 7], koff, m0b, (r & 7) * 1024);
+                else KL_DMA(sa, kl_voff[r & 7], koff, m0b, W_BYTES + (r & 7) * 1024);
             }
+#pragma unroll
+            for (int n = KL_B1_AT + 1 + 16 * KL_DMA_EVERY; n <= KL_B2_AT; ++n) KL_MMA_G(n);
             // the 16 pieces of the NEXT k-step were issued one k-step ago: they have landed once at most the 16 just issued are
             // outstanding; the barrier publishes every wave's share
             asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            // the other stage from here on
-            kl_bw0 ^= 0x10000u; kl_bw1 ^= 0x10000u; kl_ba0 ^= 0x10000u; kl_ba1 ^= 0x10000u;
+            kl_bw0 ^= 0x10000u; kl_bw1 ^= 0x10000u; kl_ba0 ^= 0x10000u; kl_ba1 ^= 0x10000u;      // the other stage from here on
             kl_m0 ^= 0x10000u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {          // MFMAs 24-55 + the 16 fragment reads of the next k-step's k-half 0
-                KL_MMA_N(24 + 2 * r, w1, a1);
-                KL_MMA_N(25 + 2 * r, w1, a1);
+            for (int r = 0; r < 16; ++r) {                 // a read of the next k-step's k-half 0 behind every RD2-th MFMA
+#pragma unroll
+                for (int t = 0; t < KL_RD2_EVERY; ++t) KL_MMA_G(KL_B2_AT + 1 + r * KL_RD2_EVERY + t);
                 KL_DSR_N(r, w0, a0, kl_bw0, kl_ba0);
             }
 #pragma unroll
-            for (int n = 56; n < 64; ++n) KL_MMA_N(n, w1, a1);
+            for (int n = KL_B2_AT + 1 + 16 * KL_RD2_EVERY; n < 128; ++n) KL_MMA_G(n);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         if (kl_first) {       // the workgroup's first tile: k-steps 0 and 1 into the two stages, first fragments
@@ -362,6 +377,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #undef KL_DSR
 #undef KL_DMA
 #undef KL_MMA_N
+#undef KL_MMA_G
 #undef KL_DSR_N
     } else if constexpr (PIPE && NS > 2) {
         // NS LDS stages (small tiles, where a workgroup has a CU's MFMA pipe to itself or shares it with one other):
@@ -580,7 +596,89 @@ void gemm_bf16_kernel(GemmArgs g) {
         }
     }
     // ---- epilogues: lane owns token m = .. + (lane & 15), features n = .. + 4 * (lane >> 4) + r
-    if constexpr (BEPI == EPI_STORE_BF16 || BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32) {
+#ifdef KL_NO_STAGING
+    constexpr bool KL_STAGED = false;
+#else
+    constexpr bool KL_STAGED = KL == 1 && (BEPI == EPI_STORE_BF16 || BEPI == EPI_SWIGLU || BEPI == EPI_QKV_ROPE);
+#endif
+    if constexpr (KL_STAGED) {
+        // The bf16 outputs of the four-wave tile leave through LDS.  Stored straight from the accumulator layout a lane writes
+        // 8 bytes and an instruction 16 rows x 32 bytes: 4 096 32-byte fragments per tile and CU, 256 CUs finishing their tiles
+        // together - in-kernel stamps put that epilogue at 8 us of a 57 us tile (K = 2048), 0.2 us without the stores.  Here a
+        // wave lays the 16 token rows of one block column into LDS behind the two stages and reads them back as whole rows - 16
+        // bytes per lane, 4 rows x 256 bytes (SwiGLU: 8 rows x 128 bytes) per store instruction: full cache lines, a quarter of
+        // the store instructions (8 -> 4.2 us, +6 % on the layer's GEMMs).  LDS operations of one wave execute in order: no barrier.
+        constexpr int OUT_F = BEPI == EPI_SWIGLU ? 64 : 128;           // output features per token row of this wave
+        constexpr int ROWB = OUT_F * 2, NP = ROWB / 16;                // bytes and 16-byte pieces per staged row
+        // two 4 KB buffers per wave (block columns alternate: the conversion and writes of column j + 1 do not wait for the
+        // reads of column j), rows unpadded with the 16-byte pieces XOR-swizzled by the row: 2 x 4 x 4 KB = the 32 KB the two
+        // stages leave of the CU's 160 KB
+        unsigned char* const stg0 = smem + 2 * STAGE_BYTES + wave * 8192;
+        const int ldc = BEPI == EPI_SWIGLU ? (g.N >> 1) : g.N;
+        const int nb = (BEPI == EPI_SWIGLU ? (n0 >> 1) : n0) + wn * OUT_F;      // first output feature of this wave
+        unsigned char* stg = stg0;
+        auto put = [&](int f_local, const f32x4& v) {                          // 4 consecutive output features of token row frow
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(v[r]);
+            *reinterpret_cast<bf16x4*>(stg + frow * ROWB + (((f_local >> 3) ^ (frow & (NP - 1))) << 4) + ((f_local & 4) << 1)) = o;
+        };
+        const int hd = g.head_dim, hb = hd / 32;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int mrow = m0 + wm * MB * 16 + j * 16;
+            stg = stg0 + (j & 1) * 4096;
+            if constexpr (BEPI == EPI_STORE_BF16) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) put(i * 16 + fg * 4, acc[i][j]);
+            } else if constexpr (BEPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int i = 0; i < NB; i += 2) {
+                    const f32x4 gt = acc[i][j], up = acc[i + 1][j];
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = (gt[r] * __builtin_amdgcn_rcpf(1.f + __expf(-gt[r]))) * up[r];   // as EPI_SWIGLU below
+                    put((i >> 1) * 16 + fg * 4, y);
+                }
+            } else {      // EPI_QKV_ROPE, bf16 output (see the direct-store version below)
+                const int m = mrow + frow;
+                const int p = m < g.M ? g.pos[m] : 0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+                    if (n >= g.N) continue;
+                    if (n < g.n_rope) {
+                        const int d = n % hd;
+                        if (d >= hd / 2) continue;
+                        f32x4 x1 = acc[i][j], x2;
+                        if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
+                        const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
+                        f32x4 y1, y2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            y1[r] = x1[r] * c[r] - x2[r] * sn[r];
+                            y2[r] = x2[r] * c[r] + x1[r] * sn[r];
+                        }
+                        put(i * 16 + fg * 4, y1);
+                        put(i * 16 + fg * 4 + hd / 2, y2);
+                    } else {
+                        put(i * 16 + fg * 4, acc[i][j]);
+                    }
+                }
+            }
+            // rows back out: lane -> (token row, 16-byte piece)
+            constexpr int LPR = OUT_F * 2 / 16;          // lanes per row (16 or 8)
+            constexpr int RPI = 64 / LPR;                // rows per instruction (4 or 8)
+#pragma unroll
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int tok = it * RPI + lane / LPR, pc = lane % LPR;
+                const sr_i32x4 v = *reinterpret_cast<const sr_i32x4*>(stg + tok * ROWB + ((pc ^ (tok & (NP - 1))) << 4));
+                const int m = mrow + tok, n = nb + pc * 8;
+                if (m < g.M && n < ldc) *reinterpret_cast<sr_i32x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n) = v;
+            }
+        }
+    } else if constexpr (BEPI == EPI_STORE_BF16 || BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int m = m0 + wm * MB * 16 + j * 16 + frow;
@@ -596,6 +694,9 @@ void gemm_bf16_kernel(GemmArgs g) {
                     o[1] = (short)f32_to_bf16(v[1]);
                     o[2] = (short)f32_to_bf16(v[2]);
                     o[3] = (short)f32_to_bf16(v[3]);
+#ifdef KL_DIAG_NOSTORE      // timing diagnostic (variant builds only): the epilogue without its stores (one lane keeps the values alive)
+                    if (o[0] == 12345 && o[1] == 23456 && lane == 77)
+#endif
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.N + n) = o;
                 } else if constexpr (BEPI == EPI_STORE_F32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.N + n) = v;
@@ -829,7 +930,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 template <int EPI, int WAVES_N, int WAVES_M, int NB, int MB, bool PIPE = false, int NS = 2, int KL = 0>
 static int launch_cfg(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BN = 16 * NB * WAVES_N, BM = 16 * MB * WAVES_M;
-    constexpr size_t lds = NS * (size_t)(BN + BM) * 128;
+    constexpr size_t lds = NS * (size_t)(BN + BM) * 128 + (KL == 1 ? 4 * 8192 : 0);     // KL = 1: + the waves' output staging (160 KB in all)
     static DeviceOnce attr_once;
     bool* attr_slot = attr_once.pending();
     if (attr_slot) {
@@ -1026,6 +1127,7 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
     SR_REQUIRE(epi != EPI_SWIGLU_SPLIT || (g.out_map.n_seg >= 1 && g.out_map.n_seg <= SR_MAX_SEG), "gemm(swiglu split): bad segment map");
     switch (epi) {
         case EPI_STORE_BF16: return launch_one<EPI_STORE_BF16>(g, s);
+#ifndef SR_GEMM_VARIANT_BUILD      // tools/micro/gemm_variants.sh: k-step schedule variants of the plain-store GEMM only (seconds to build)
         case EPI_RESID_F32: return launch_one<EPI_RESID_F32>(g, s);
         case EPI_SWIGLU: return launch_one<EPI_SWIGLU>(g, s);
         case EPI_SEGMAX: return launch_one<EPI_SEGMAX>(g, s);
@@ -1039,6 +1141,7 @@ int launch_gemm_bf16(GemmEpilogue epi, const GemmArgs& g, hipStream_t s) {
         case EPI_SWIGLU_F32_H: return launch_one<EPI_SWIGLU_F32_H>(g, s);
         case EPI_SEGMAX_H: return launch_one<EPI_SEGMAX_H>(g, s);
         case EPI_SWIGLU_SPLIT_H: return launch_one<EPI_SWIGLU_SPLIT_H>(g, s);
+#endif
         default: break;
     }
     sr_set_error("gemm: unknown epilogue %d", (int)epi);
