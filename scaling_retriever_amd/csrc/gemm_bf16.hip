@@ -35,6 +35,23 @@ __device__ __forceinline__ f32x4 sr_mma(const mfma_bf16x8& w, const mfma_bf16x8&
     else
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
 }
+// RoPE on the accumulators, HF rotate_half layout: first half of a head  x1 c - x2 s,  second half  x2 c + x1 s.  Products and sum
+// rounded separately, as PyTorch's eager `q * cos + rotate_half(q) * sin` does - and so that every epilogue variant (direct or staged
+// stores, any tile configuration) produces the same bits whatever the compiler would otherwise fuse.
+__device__ __forceinline__ f32x4 sr_rope_lo(const f32x4& x1, const f32x4& x2, const f32x4& c, const f32x4& s) {
+#pragma clang fp contract(off)
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float a = x1[r] * c[r], b = x2[r] * s[r]; y[r] = a - b; }
+    return y;
+}
+__device__ __forceinline__ f32x4 sr_rope_hi(const f32x4& x1, const f32x4& x2, const f32x4& c, const f32x4& s) {
+#pragma clang fp contract(off)
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float a = x2[r] * c[r], b = x1[r] * s[r]; y[r] = a + b; }
+    return y;
+}
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
 
@@ -654,14 +671,8 @@ void gemm_bf16_kernel(GemmArgs g) {
                         if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
                         const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
                         const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
-                        f32x4 y1, y2;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            y1[r] = x1[r] * c[r] - x2[r] * sn[r];
-                            y2[r] = x2[r] * c[r] + x1[r] * sn[r];
-                        }
-                        put(i * 16 + fg * 4, y1);
-                        put(i * 16 + fg * 4 + hd / 2, y2);
+                        put(i * 16 + fg * 4, sr_rope_lo(x1, x2, c, sn));
+                        put(i * 16 + fg * 4 + hd / 2, sr_rope_hi(x1, x2, c, sn));
                     } else {
                         put(i * 16 + fg * 4, acc[i][j]);
                     }
@@ -677,6 +688,109 @@ void gemm_bf16_kernel(GemmArgs g) {
                 const int m = mrow + tok, n = nb + pc * 8;
                 if (m < g.M && n < ldc) *reinterpret_cast<sr_i32x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n) = v;
             }
+            // one block column at a time: left alone the scheduler hoists the rope-table loads of all 8 columns to the top (256
+            // registers), and the allocator then spills ACCUMULATORS inside the k-loop to make room
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (KL == 1 && (BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32 || BEPI == EPI_QKV_ROPE_F32)) {
+        // fp32 outputs of the four-wave tile (the fp32 regime's QKV + RoPE and its residual adds), staged through LDS like the
+        // bf16 ones: a token row of this wave is 128 features x 4 B = 512 B, handled as two halves of 64 features (16 rows x 256 B
+        // = one 4 KB buffer, the two buffers alternate); read back 16 bytes per lane, 4 rows x 256 bytes per instruction.
+        // EPI_RESID_F32 adds into x with 16-byte loads and stores of whole lines instead of 16-row x 64-byte fragments.
+        unsigned char* const stg0 = smem + 2 * STAGE_BYTES + wave * 8192;
+        const int hd = g.head_dim, hb = hd / 32;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int mrow = m0 + wm * MB * 16 + j * 16;
+            [[maybe_unused]] int p = 0;
+            if constexpr (BEPI == EPI_QKV_ROPE_F32) p = (mrow + frow) < g.M ? g.pos[mrow + frow] : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned char* stg = stg0 + h * 4096;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * h + ii;
+                    f32x4 y = acc[i][j];
+                    if constexpr (BEPI == EPI_QKV_ROPE_F32) {
+                        // every output block on its own: first half of a head x c - partner s, second half x c + partner s
+                        const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
+                        if (n < g.n_rope) {
+                            const int d = n % hd;
+                            const bool lo = d < hd / 2;
+                            const int dd = lo ? d : d - hd / 2;
+                            const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + dd);
+                            const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + dd);
+                            f32x4 xp;
+                            if (hb == 2) xp = lo ? acc[(i + 2) % NB][j] : acc[(i + NB - 2) % NB][j];
+                            else xp = lo ? acc[(i + 4) % NB][j] : acc[(i + NB - 4) % NB][j];
+                            y = lo ? sr_rope_lo(acc[i][j], xp, c, sn) : sr_rope_hi(xp, acc[i][j], c, sn);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(stg + frow * 256 + (((ii * 4 + fg) ^ frow) << 4)) = y;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int tok = it * 4 + (lane >> 4), pc = lane & 15;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + tok * 256 + ((pc ^ tok) << 4));
+                    const int m = mrow + tok, n = n0 + wn * NB * 16 + h * 64 + pc * 4;
+                    if (m < g.M && n < g.N) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.N + n);
+                        if constexpr (BEPI == EPI_RESID_F32) {
+                            f32x4 x = *dst;
+                            x += v;
+                            v = x;
+                        }
+                        *dst = v;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // see the bf16 version above
+            }
+        }
+    } else if constexpr (KL == 1 && BEPI == EPI_SWIGLU_SPLITH_BASE) {
+        // fp32 regime, SwiGLU output as fp16 plane segments [f1 | f0 | f0] (see the direct-store version below), staged: a token
+        // row of this wave is 64 output features = 128 B per plane; a buffer holds 16 rows x (f1 | f0) = 4 KB
+        unsigned char* const stg0 = smem + 2 * STAGE_BYTES + wave * 8192;
+        const int half_n = g.N >> 1;
+        const int64_t ldc = 3 * (int64_t)half_n;
+        const int nb = (n0 >> 1) + wn * 64;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int mrow = m0 + wm * MB * 16 + j * 16;
+            unsigned char* stg = stg0 + (j & 1) * 4096;
+            const float osc = (mrow + frow) < g.M ? g.out_scale[mrow + frow] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; i += 2) {
+                const f32x4 gt = acc[i][j], up = acc[i + 1][j];
+                bf16x4 p0, p1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = (gt[r] / (1.f + expf(-gt[r]))) * up[r];
+                    unsigned short f0, f1;
+                    split_f16x2(y * osc, f0, f1);
+                    p0[r] = (short)f0; p1[r] = (short)f1;
+                }
+                // 8-byte slot s = (i / 2) * 4 + fg of the row's 16 (f1) + 16 (f0): 16-byte piece s / 2, XOR-swizzled by the row
+                const int sl = (i >> 1) * 4 + fg;
+                *reinterpret_cast<bf16x4*>(stg + frow * 256 + ((((sl >> 1)) ^ (frow & 7)) << 4) + ((sl & 1) << 3)) = p1;
+                *reinterpret_cast<bf16x4*>(stg + frow * 256 + 128 + ((((sl >> 1)) ^ (frow & 7)) << 4) + ((sl & 1) << 3)) = p0;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                // lane -> (row, plane, 16-byte piece): 4 rows x (8 pieces of f1 + 8 of f0) per instruction
+                const int tok = it * 4 + (lane >> 4), pl = (lane >> 3) & 1, pc = lane & 7;
+                const sr_i32x4 v = *reinterpret_cast<const sr_i32x4*>(stg + tok * 256 + pl * 128 + ((pc ^ (tok & 7)) << 4));
+                const int m = mrow + tok, n = nb + pc * 8;
+                if (m < g.M && n < half_n) {
+                    bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n;
+                    if (pl == 0) {
+                        *reinterpret_cast<sr_i32x4*>(crow) = v;                    // f1
+                    } else {
+                        *reinterpret_cast<sr_i32x4*>(crow + half_n) = v;           // f0, twice
+                        *reinterpret_cast<sr_i32x4*>(crow + 2 * half_n) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else if constexpr (BEPI == EPI_STORE_BF16 || BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32) {
 #pragma unroll
@@ -743,14 +857,8 @@ void gemm_bf16_kernel(GemmArgs g) {
                     if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
                     const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
                     const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
-                    f32x4 y1, y2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        y1[r] = x1[r] * c[r] - x2[r] * sn[r];
-                        y2[r] = x2[r] * c[r] + x1[r] * sn[r];
-                    }
-                    put(crow + n, y1);
-                    put(crow + n + hd / 2, y2);
+                    put(crow + n, sr_rope_lo(x1, x2, c, sn));
+                    put(crow + n + hd / 2, sr_rope_hi(x1, x2, c, sn));
                 } else {
                     put(crow + n, acc[i][j]);
                 }
@@ -1022,8 +1130,17 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         // 32-bit byte offsets: 256 rows x 2 K bytes must stay below 2^31
         const char* big = sr_dev_getenv("SR_GEMM_BIG");
         const bool want8 = big && big[0] == '8';
-        if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && !(env && *env == '0'))
-            return launch_cfg<EPI, 2, 2, 8, 8, true, 2, 1>(g, s);
+        // (epilogues without a staged output path - the per-sequence max, plain SwiGLU in fp32, three-bf16-plane outputs - stay on
+        // the 8-wave loop: stored straight from four waves' accumulators their epilogue costs twice the 8-wave one)
+        // The QKV + RoPE epilogues stay on the 8-wave loop too: each output needs an accumulator AND its rotation partner, and with
+        // that epilogue behind the asm-pinned loop the register allocator spills accumulators INSIDE the k-loop (scratch in the
+        // ISA; the fp32-regime query encode went from 300 to 670 ms) - their staged versions are kept for a rotation through LDS.
+        constexpr bool STAGED = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 ||
+                                EPI == EPI_RESID_F32_H || EPI == EPI_SWIGLU_SPLIT_H;
+        if constexpr (STAGED) {
+            if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && !(env && *env == '0'))
+                return launch_cfg<EPI, 2, 2, 8, 8, true, 2, 1>(g, s);
+        }
     }
     if (g.K / G_BK >= 4 && !(env && *env == '0')) return launch_cfg<EPI, 2, 4, 8, 4, true>(g, s);
     return launch_cfg<EPI, 2, 4, 8, 4, false>(g, s);

@@ -56,3 +56,32 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_four_wave_gemm_kernels_use_no_scratch(tmp_path):
+    """The four-wave GEMM loop pins its 256 accumulators to registers with inline-asm constraints; an epilogue that raises the
+    register pressure makes hipcc spill ACCUMULATORS inside the k-loop (the QKV + RoPE epilogues did: fp32-regime query encode
+    300 -> 670 ms, every parity test still green).  The built object's kernel metadata must show no scratch and no spill for
+    every instantiation of that loop (..., KL = 1)."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "scaling_retriever_amd", "csrc", "gemm_bf16.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("needs the built object and the ROCm LLVM tools")
+    fat, dev = str(tmp_path / "g.fatbin"), str(tmp_path / "g_dev.o")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj, str(tmp_path / "unused.o")])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--input={fat}", f"--output={dev}", "--unbundle"])
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", dev], capture_output=True, text=True).stdout
+    # one YAML map per kernel; its keys are sorted, so everything between two `.name:` lines past a kernel's own name up to
+    # `.wavefront_size:` belongs to it (.private_segment_fixed_size, .sgpr_spill_count, .vgpr_spill_count all sort after .name)
+    import re
+    kernels = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size:", notes, flags=re.S):
+        body = m.group(2)
+        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:)\s+(\d+)", body)}
+    four_wave = {k: v for k, v in kernels.items() if k.startswith("_Z16gemm_bf16_kernel") and k.endswith("ELi1EEv8GemmArgs")}
+    assert len(four_wave) >= 4, sorted(kernels)[:5]
+    for name, meta in four_wave.items():
+        assert meta[".private_segment_fixed_size:"] == 0 and meta[".vgpr_spill_count:"] == 0, (name, meta)

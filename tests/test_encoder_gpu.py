@@ -526,3 +526,32 @@ def test_gemm_four_wave_loop_equals_eight_wave_loop(M, N, K, monkeypatch):
     C = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()), "sr_gemm_bf16")
     assert torch.equal(C, ref[0])
+    # QKV + RoPE (bf16 out) for both head sizes, and the fp32 regime's scaled fp16 GEMM (+= into fp32)
+    if N % 128 == 0:
+        pos = torch.randint(0, 300, (M,), device="cuda", generator=g).to(torch.int32)
+        for hd in (64, 128):
+            ang = torch.arange(512, device="cuda")[:, None].float() * (1.0 / 10000 ** (torch.arange(hd // 2, device="cuda").float() / (hd // 2)))[None, :]
+            cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+            n_rope = (N // hd) * hd * 3 // 4 // hd * hd
+
+            def rope():
+                out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+                L.check(lib.sr_gemm_qkv_rope(A.data_ptr(), W.data_ptr(), M, N, K, out.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                             n_rope, hd, L.stream_ptr()), "sr_gemm_qkv_rope")
+                return out
+            monkeypatch.setenv("SR_GEMM_BIG", "8w")
+            want = rope()
+            monkeypatch.delenv("SR_GEMM_BIG")
+            assert torch.equal(rope(), want), hd
+    Ah, Wh = A.float().half(), W.float().half()
+    sa = torch.exp2(torch.randint(-3, 4, (M,), device="cuda", generator=g).float())
+    sw = torch.exp2(torch.randint(-3, 4, (N,), device="cuda", generator=g).float())
+
+    def scaled():
+        X = X0.clone()
+        L.check(lib.sr_gemm_f16_scaled(Ah.data_ptr(), Wh.data_ptr(), M, N, K, sa.data_ptr(), sw.data_ptr(), X.data_ptr(), L.stream_ptr()), "sr_gemm_f16_scaled")
+        return X
+    monkeypatch.setenv("SR_GEMM_BIG", "8w")
+    want = scaled()
+    monkeypatch.delenv("SR_GEMM_BIG")
+    assert torch.equal(scaled(), want)

@@ -86,3 +86,21 @@ def test_encode_is_bitwise_reproducible_under_load(weights):
             assert torch.equal(again, first)
         del model
         torch.cuda.empty_cache()
+
+
+def test_four_wave_gemm_loop_gives_the_eight_wave_bits_through_the_whole_encoder(weights, monkeypatch):
+    """Every GEMM epilogue the encoder uses has a staged-output version for the four-wave 256 x 256 loop (QKV + RoPE, bf16 / fp32
+    residual, SwiGLU, SwiGLU -> fp16 planes).  Both regimes, dense head: SR_GEMM_BIG=8w (the 8-wave loop, direct stores) and the
+    default give identical bits - every output element is the same k-ordered MFMA chain and the same epilogue arithmetic."""
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    ids, mask = _batch(128, 8, 160, 9)
+    t_ids, t_mask = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    for prec in ("bf16", "fp32"):
+        model = LlamaBiDense.from_weights(CFG, weights, precision=prec).to("cuda").eval()
+        monkeypatch.setenv("SR_GEMM_BIG", "8w")
+        want = model.doc_encode(input_ids=t_ids, attention_mask=t_mask).clone()
+        monkeypatch.delenv("SR_GEMM_BIG")
+        got = model.doc_encode(input_ids=t_ids, attention_mask=t_mask)
+        assert torch.equal(got, want), prec
+        del model
+        torch.cuda.empty_cache()
