@@ -187,6 +187,43 @@ def encode_leg(args, cfg, model, device, rank, world, share_gpu, flop_per_token=
         assert written == len(lens), (written, len(lens))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    # ---- the reference's own loader shape (scripts/eval_dense.sh:11-16, eval_dense.py:171-179): 128 consecutive passages per
+    #      doc_encode call, padded to the batch's longest (pads are not computed here either) - through store_embs as well
+    padded = None
+    if world == 1 and not getattr(args, "no_padded_mode", False):
+        n_p = min(len(lens), 32768)
+        flat_all = np.concatenate([c[1] for c in chunks])
+        offs = np.concatenate([[0], np.cumsum(lens)])
+
+        class _Padded128:
+            batch_size = 128
+
+            def __len__(self):
+                return (n_p + 127) // 128
+
+            def __iter__(self):
+                for b0 in range(0, n_p, 128):
+                    ls = lens[b0:b0 + 128]
+                    L_ = int(ls.max())
+                    ids_ = np.full((len(ls), L_), cfg["vocab_size"] - 1, dtype=np.int64)
+                    mask_ = np.zeros((len(ls), L_), dtype=np.int64)
+                    for r_, l_ in enumerate(ls):
+                        ids_[r_, L_ - l_:] = flat_all[offs[b0 + r_]:offs[b0 + r_ + 1]]
+                        mask_[r_, L_ - l_:] = 1
+                    yield {"input_ids": torch.from_numpy(ids_), "attention_mask": torch.from_numpy(mask_), "ids": list(range(rows[0] + b0, rows[0] + b0 + len(ls)))}
+        tmp2 = tempfile.mkdtemp(prefix="sr_bench_embs128_")
+        try:
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            with contextlib.redirect_stdout(sys.stderr):
+                store_embs(model, _Padded128(), rank, tmp2, device, chunk_size=65536)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+        finally:
+            shutil.rmtree(tmp2, ignore_errors=True)
+        padded = {"passages_per_s": round(n_p / tp, 1), "sample_passages": int(n_p), "wall_s": round(tp, 3),
+                  "note": "the reference's loader shape: 128 consecutive passages per doc_encode call, padded to the batch's longest (host-side "
+                          "collation in this process, one call = ~9 600 real tokens); the token-budget loader above is the drivers' default"}
     # whole-job figures: every rank encoded 1/W of the sample, times are the max over ranks
     all_lens = np.clip(np.round(np.random.default_rng(3).lognormal(4.25, 0.35, size=args.encode_passages)), 8, 192)
     tokens = float(all_lens.sum())
@@ -194,6 +231,7 @@ def encode_leg(args, cfg, model, device, rank, world, share_gpu, flop_per_token=
     ach, ach_gpu = flop / te / 1e12 / world, flop / gpu_s / 1e12 / world
     return {"value": round(args.encode_passages / te, 1), "unit": "passages/s (whole job, through store_embs: encode + D2H + .npy files)",
             "passages_per_s_per_gpu": round(args.encode_passages / te / world, 1), "sample_passages": int(args.encode_passages),
+            "padded_batch_128_mode": padded,
             "mean_tokens_per_passage": round(float(all_lens.mean()), 1), "token_budget": args.token_budget, "batches_per_rank": n_batches,
             "dtype": "bf16 GEMM inputs / fp32 accumulate (autocast regime, indexer.py:46-52)",
             "wall_s": round(te, 3), "gpu_encode_s": round(gpu_s, 3),
@@ -325,7 +363,61 @@ def sparse_leg(args, device):
     torch.cuda.empty_cache()
     if not args.no_drop_in:
         out["drop_in"] = drop_in_sparse_leg(args, dict(LION_1B), (indptr, doc_ids, vals, N), (q_indptr, q_cols, q_vals, nq), device)
+    del indptr, doc_ids, vals
+    torch.cuda.empty_cache()
+    if not args.no_sparse_sweep:
+        out["sparse_sweep"] = sparse_sweep_leg(args, device)
     return out
+
+
+def sparse_sweep_leg(args, device):
+    """SURVEY.md 8(d) config 3 "as a function of L0": L0_d in {64, 128, 256} x L0_q in {16, 32, 64} on the Zipf(1.0) index, and one
+    flatter index (df ~ r^-0.7 capped at N / 5: no term in a quarter of the documents, so no dense column and the per-query
+    kernel serves every block) - queries/s, which kernel ran, and ids + fp32 scores of the first queries compared bit for bit with the
+    oracle's C port of numba_score_float + select_topk (indexer.py:315-344) at full collection size."""
+    import synth
+    from oracle import scoring as SC
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    V, N, k, nq = 128256, 8_841_823, 1000, 2048
+    rows = []
+    for name, alpha, cap, l0ds in (("zipf1.0", 1.0, None, (64, 128, 256)), ("flat0.7", 0.7, N // 5, (128,))):
+        for L0_d in l0ds:
+            indptr, doc_ids, vals, df = synth.build_index(V, N, L0_d, device, 3, alpha=alpha, cap=cap)
+            idx = SparseIndexHIP(indptr, doc_ids, vals, N, device=device)
+            host = None
+            for L0_q in (16, 32, 64):
+                q_indptr, q_cols, q_vals = synth.build_queries(V, nq, L0_q, device, 4, alpha=alpha)
+                s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
+                torch.cuda.synchronize()
+                st0 = idx.block_stats()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 2
+                st1 = idx.block_stats()
+                n_check = 64 if (L0_d, L0_q) in ((64, 16), (128, 32), (256, 64)) else 16
+                if host is None:
+                    host = (indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy())
+                hq = (q_indptr[:n_check + 1].cpu().numpy(), q_cols[:n_check * L0_q].cpu().numpy(), q_vals[:n_check * L0_q].cpu().numpy())
+                oi, os_, oc = SC.sparse_retrieve_c(*host, *hq, k, 0.0, N, q_threads=4, inner_threads=max(1, (os.cpu_count() or 8) // 4))
+                gi, gs, gc = i[:n_check].cpu().numpy(), s[:n_check].cpu().numpy(), c[:n_check].cpu().numpy()
+                for q in range(n_check):
+                    assert gc[q] == oc[q], (name, L0_d, L0_q, q)
+                    assert np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), (name, L0_d, L0_q, q)
+                touched = float((indptr[1:] - indptr[:-1])[q_cols.long()].reshape(nq, L0_q).sum(1).double().mean().item())
+                rows.append({"index": name, "L0_d": L0_d, "L0_q": L0_q, "queries_per_s": round(nq / dt, 1), "ms_per_1k_queries": round(dt / nq * 1e6, 1),
+                             "kernel": ("sparse_block_kernel" if st1["block_calls"] > st0["block_calls"] and st1["fallback_calls"] == st0["fallback_calls"]
+                                        else ("sparse_score_kernel" if st1["block_calls"] == st0["block_calls"] else "both")),
+                             "dense_column_terms": st1["dense_terms"], "postings": int(doc_ids.numel()),
+                             "mean_postings_touched_per_query": touched, "queries_bit_exact_vs_oracle": n_check})
+                log("[sparse_sweep]", rows[-1])
+            idx.close()
+            del idx, indptr, doc_ids, vals, host
+            torch.cuda.empty_cache()
+    return {"nq": nq, "k": k, "N": N, "V": V, "rows": rows,
+            "note": "batches of 2 048 queries; Zipf(1.0): document frequencies ~ 1 / rank capped at N, query terms drawn from the same law; "
+                    "flat0.7: ~ rank^-0.7 capped at N / 5 (no dense columns)"}
 
 
 def _loader_batches(q_batches_dev, qids, batch):
@@ -606,6 +698,7 @@ def main():
     ap.add_argument("--no-shard-leg", action="store_true", help="skip the shard_1of8 leg (one of 8 doc shards with the threshold exchange)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in legs (the reference's own call path: loader batches of 128 -> "
                     "get_top_docs / SparseRetrieval.retrieve -> run.json)")
+    ap.add_argument("--no-sparse-sweep", action="store_true", help="skip the L0_d x L0_q / flat-distribution sweep of the sparse scorer")
     ap.add_argument("--no-robustness", action="store_true", help="skip the filter_robustness legs (anisotropic / near-duplicate corpora at full shape)")
     args = ap.parse_args()
 
@@ -1037,6 +1130,16 @@ def main():
         torch.cuda.empty_cache()
         config5 = config5_leg(args, device)
 
+    # self-check of a multi-GPU run: what torch.distributed really set up, and what every rank holds
+    ranks_info = {"world_size": world, "backend": dist.get_backend() if world > 1 else None, "shard_docs": [n_local],
+                  "queries_encoded_per_rank": [q_rows[1] - q_rows[0]]}
+    if world > 1:
+        t = torch.tensor([n_local, q_rows[1] - q_rows[0], torch.cuda.current_device()], dtype=torch.int64, device="cpu" if share_gpu else device)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks_info.update({"shard_docs": [int(x[0]) for x in got], "queries_encoded_per_rank": [int(x[1]) for x in got],
+                           "cuda_device_of_rank": [int(x[2]) for x in got]})
+        assert sum(ranks_info["shard_docs"]) == args.n_docs and sum(ranks_info["queries_encoded_per_rank"]) == args.n_queries
     if rank == 0:
         res = {
             "metric": "MSMARCO-Dev queries/sec end-to-end (query encode + dense brute-force top-1000)",
@@ -1053,6 +1156,7 @@ def main():
                                                  "the error of an fp32 GEMM)",
                        "doc_encode_precision": "bf16 autocast regime", "score_precision": "exact fp32 (k-ordered fmaf chain)" + ("" if args.exact_kernel else ": certified fp16 upper-bound filter + exact re-score of 1-2k candidates per query, "
                                                                                "bit-identical to the exact kernel (parity field)"),
+                       "ranks": ranks_info,
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "exact_kernel_mode": exact_mode, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,

@@ -6,20 +6,23 @@ import numpy as np
 import torch
 
 
-def zipf_df(V, N, total):
-    """df_r = min(N, C / r) with sum = total (water-filling on the cap)."""
-    r = np.arange(1, V + 1, dtype=np.float64)
-    lo, hi = 0.0, float(total) * V
-    for _ in range(100):
+def zipf_df(V, N, total, alpha=1.0, cap=None):
+    """df_r = min(cap, C / r^alpha) with sum = total (water-filling on the cap; cap = N unless given)."""
+    cap = N if cap is None else cap
+    r = np.arange(1, V + 1, dtype=np.float64) ** alpha
+    lo, hi = 0.0, float(total) * V ** max(1.0, alpha)
+    for _ in range(200):
         C = 0.5 * (lo + hi)
-        s = np.minimum(N, C / r).sum()
+        s = np.minimum(cap, C / r).sum()
         lo, hi = (C, hi) if s < total else (lo, C)
-    return np.maximum(1, np.floor(np.minimum(N, C / r))).astype(np.int64)
+    return np.maximum(1, np.floor(np.minimum(cap, C / r))).astype(np.int64)
 
 
-def build_index(V, N, L0_d, device, seed):
+def build_index(V, N, L0_d, device, seed, alpha=1.0, cap=None):
+    """alpha / cap: document-frequency law df_r ~ r^-alpha capped at `cap` docs (default: Zipf(1.0) capped at N, the headline's index;
+    alpha = 0.7 with cap = N / 5 is the `flat` workload of bench.py's sparse_sweep: no term reaches a quarter of the collection)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    df = zipf_df(V, N, N * L0_d)
+    df = zipf_df(V, N, N * L0_d, alpha, cap)
     heavy = int((df > N // 8).sum())          # Bernoulli masks for the heaviest lists, sampling for the rest
     ids_parts, counts = [], np.zeros(V, dtype=np.int64)
     for t in range(heavy):
@@ -43,9 +46,9 @@ def build_index(V, N, L0_d, device, seed):
     return indptr, doc_ids, vals, df
 
 
-def build_queries(V, nq, L0_q, device, seed):
+def build_queries(V, nq, L0_q, device, seed, alpha=1.0):
     g = torch.Generator(device=device).manual_seed(seed)
-    w = 1.0 / torch.arange(1, V + 1, device=device, dtype=torch.float32)
+    w = 1.0 / torch.arange(1, V + 1, device=device, dtype=torch.float32) ** alpha
     cols = torch.multinomial(w.expand(nq, V), L0_q, replacement=False, generator=g)
     cols = torch.sort(cols, dim=1).values.to(torch.int32).reshape(-1).contiguous()
     vals = torch.log1p(torch.rand(nq * L0_q, device=device, generator=g) * 20.0)
