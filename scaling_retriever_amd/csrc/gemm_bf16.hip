@@ -616,14 +616,20 @@ void gemm_bf16_kernel(GemmArgs g) {
 #ifdef KL_NO_STAGING
     constexpr bool KL_STAGED = false;
 #else
-    constexpr bool KL_STAGED = KL == 1 && (BEPI == EPI_STORE_BF16 || BEPI == EPI_SWIGLU || BEPI == EPI_QKV_ROPE);
+    constexpr bool KL_STAGED = KL == 1 && (BEPI == EPI_STORE_BF16 || BEPI == EPI_SWIGLU);
 #endif
+    // The workgroup is persistent: whatever an epilogue computes from the lane index alone (feature offsets, n % head_dim, swizzled
+    // LDS offsets ...) is invariant in the TILE loop, and hipcc hoists it above the k-loop and carries it through - behind the
+    // asm-pinned four-wave loop that meant accumulators spilled to scratch INSIDE the k-loop (QKV + RoPE epilogues: query encode 300
+    // -> 670 ms).  The staged epilogues therefore see the lane coordinates through an opaque asm: nothing of them can be hoisted.
+    [[maybe_unused]] int frow_e = frow, fg_e = fg, lane_e = lane;
+    if constexpr (KL == 1) asm volatile("" : "+v"(frow_e), "+v"(fg_e), "+v"(lane_e));
     if constexpr (KL_STAGED) {
-        // The bf16 outputs of the four-wave tile leave through LDS.  Stored straight from the accumulator layout a lane writes
+        // The bf16 outputs of the four-wave tile leave through LDS.  Stored straight from the accumulator layout a lane_e writes
         // 8 bytes and an instruction 16 rows x 32 bytes: 4 096 32-byte fragments per tile and CU, 256 CUs finishing their tiles
         // together - in-kernel stamps put that epilogue at 8 us of a 57 us tile (K = 2048), 0.2 us without the stores.  Here a
         // wave lays the 16 token rows of one block column into LDS behind the two stages and reads them back as whole rows - 16
-        // bytes per lane, 4 rows x 256 bytes (SwiGLU: 8 rows x 128 bytes) per store instruction: full cache lines, a quarter of
+        // bytes per lane_e, 4 rows x 256 bytes (SwiGLU: 8 rows x 128 bytes) per store instruction: full cache lines, a quarter of
         // the store instructions (8 -> 4.2 us, +6 % on the layer's GEMMs).  LDS operations of one wave execute in order: no barrier.
         constexpr int OUT_F = BEPI == EPI_SWIGLU ? 64 : 128;           // output features per token row of this wave
         constexpr int ROWB = OUT_F * 2, NP = ROWB / 16;                // bytes and 16-byte pieces per staged row
@@ -634,20 +640,19 @@ void gemm_bf16_kernel(GemmArgs g) {
         const int ldc = BEPI == EPI_SWIGLU ? (g.N >> 1) : g.N;
         const int nb = (BEPI == EPI_SWIGLU ? (n0 >> 1) : n0) + wn * OUT_F;      // first output feature of this wave
         unsigned char* stg = stg0;
-        auto put = [&](int f_local, const f32x4& v) {                          // 4 consecutive output features of token row frow
+        auto put = [&](int f_local, const f32x4& v) {                          // 4 consecutive output features of token row frow_e
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(v[r]);
-            *reinterpret_cast<bf16x4*>(stg + frow * ROWB + (((f_local >> 3) ^ (frow & (NP - 1))) << 4) + ((f_local & 4) << 1)) = o;
+            *reinterpret_cast<bf16x4*>(stg + frow_e * ROWB + (((f_local >> 3) ^ (frow_e & (NP - 1))) << 4) + ((f_local & 4) << 1)) = o;
         };
-        const int hd = g.head_dim, hb = hd / 32;
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int mrow = m0 + wm * MB * 16 + j * 16;
             stg = stg0 + (j & 1) * 4096;
             if constexpr (BEPI == EPI_STORE_BF16) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) put(i * 16 + fg * 4, acc[i][j]);
+                for (int i = 0; i < NB; ++i) put(i * 16 + fg_e * 4, acc[i][j]);
             } else if constexpr (BEPI == EPI_SWIGLU) {
 #pragma unroll
                 for (int i = 0; i < NB; i += 2) {
@@ -655,55 +660,30 @@ void gemm_bf16_kernel(GemmArgs g) {
                     f32x4 y;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = (gt[r] * __builtin_amdgcn_rcpf(1.f + __expf(-gt[r]))) * up[r];   // as EPI_SWIGLU below
-                    put((i >> 1) * 16 + fg * 4, y);
-                }
-            } else {      // EPI_QKV_ROPE, bf16 output (see the direct-store version below)
-                const int m = mrow + frow;
-                const int p = m < g.M ? g.pos[m] : 0;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
-                    if (n >= g.N) continue;
-                    if (n < g.n_rope) {
-                        const int d = n % hd;
-                        if (d >= hd / 2) continue;
-                        f32x4 x1 = acc[i][j], x2;
-                        if (hb == 2) x2 = acc[(i + 2) % NB][j]; else x2 = acc[(i + 4) % NB][j];
-                        const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + d);
-                        const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + d);
-                        put(i * 16 + fg * 4, sr_rope_lo(x1, x2, c, sn));
-                        put(i * 16 + fg * 4 + hd / 2, sr_rope_hi(x1, x2, c, sn));
-                    } else {
-                        put(i * 16 + fg * 4, acc[i][j]);
-                    }
+                    put((i >> 1) * 16 + fg_e * 4, y);
                 }
             }
-            // rows back out: lane -> (token row, 16-byte piece)
+            // rows back out: lane_e -> (token row, 16-byte piece)
             constexpr int LPR = OUT_F * 2 / 16;          // lanes per row (16 or 8)
             constexpr int RPI = 64 / LPR;                // rows per instruction (4 or 8)
 #pragma unroll
             for (int it = 0; it < 16 / RPI; ++it) {
-                const int tok = it * RPI + lane / LPR, pc = lane % LPR;
+                const int tok = it * RPI + lane_e / LPR, pc = lane_e % LPR;
                 const sr_i32x4 v = *reinterpret_cast<const sr_i32x4*>(stg + tok * ROWB + ((pc ^ (tok & (NP - 1))) << 4));
                 const int m = mrow + tok, n = nb + pc * 8;
                 if (m < g.M && n < ldc) *reinterpret_cast<sr_i32x4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * ldc + n) = v;
             }
-            // one block column at a time: left alone the scheduler hoists the rope-table loads of all 8 columns to the top (256
-            // registers), and the allocator then spills ACCUMULATORS inside the k-loop to make room
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);       // one block column at a time (bounds what the scheduler keeps in flight)
         }
-    } else if constexpr (KL == 1 && (BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32 || BEPI == EPI_QKV_ROPE_F32)) {
-        // fp32 outputs of the four-wave tile (the fp32 regime's QKV + RoPE and its residual adds), staged through LDS like the
+    } else if constexpr (KL == 1 && (BEPI == EPI_STORE_F32 || BEPI == EPI_RESID_F32)) {
+        // fp32 outputs of the four-wave tile (the fp32 regime's residual adds), staged through LDS like the
         // bf16 ones: a token row of this wave is 128 features x 4 B = 512 B, handled as two halves of 64 features (16 rows x 256 B
-        // = one 4 KB buffer, the two buffers alternate); read back 16 bytes per lane, 4 rows x 256 bytes per instruction.
+        // = one 4 KB buffer, the two buffers alternate); read back 16 bytes per lane_e, 4 rows x 256 bytes per instruction.
         // EPI_RESID_F32 adds into x with 16-byte loads and stores of whole lines instead of 16-row x 64-byte fragments.
         unsigned char* const stg0 = smem + 2 * STAGE_BYTES + wave * 8192;
-        const int hd = g.head_dim, hb = hd / 32;
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             const int mrow = m0 + wm * MB * 16 + j * 16;
-            [[maybe_unused]] int p = 0;
-            if constexpr (BEPI == EPI_QKV_ROPE_F32) p = (mrow + frow) < g.M ? g.pos[mrow + frow] : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 unsigned char* stg = stg0 + h * 4096;
@@ -711,26 +691,11 @@ void gemm_bf16_kernel(GemmArgs g) {
                 for (int ii = 0; ii < 4; ++ii) {
                     const int i = 4 * h + ii;
                     f32x4 y = acc[i][j];
-                    if constexpr (BEPI == EPI_QKV_ROPE_F32) {
-                        // every output block on its own: first half of a head x c - partner s, second half x c + partner s
-                        const int n = n0 + wn * NB * 16 + i * 16 + fg * 4;
-                        if (n < g.n_rope) {
-                            const int d = n % hd;
-                            const bool lo = d < hd / 2;
-                            const int dd = lo ? d : d - hd / 2;
-                            const f32x4 c = *reinterpret_cast<const f32x4*>(g.rope_cos + (int64_t)p * (hd / 2) + dd);
-                            const f32x4 sn = *reinterpret_cast<const f32x4*>(g.rope_sin + (int64_t)p * (hd / 2) + dd);
-                            f32x4 xp;
-                            if (hb == 2) xp = lo ? acc[(i + 2) % NB][j] : acc[(i + NB - 2) % NB][j];
-                            else xp = lo ? acc[(i + 4) % NB][j] : acc[(i + NB - 4) % NB][j];
-                            y = lo ? sr_rope_lo(acc[i][j], xp, c, sn) : sr_rope_hi(xp, acc[i][j], c, sn);
-                        }
-                    }
-                    *reinterpret_cast<f32x4*>(stg + frow * 256 + (((ii * 4 + fg) ^ frow) << 4)) = y;
+                    *reinterpret_cast<f32x4*>(stg + frow_e * 256 + (((ii * 4 + fg_e) ^ frow_e) << 4)) = y;
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int tok = it * 4 + (lane >> 4), pc = lane & 15;
+                    const int tok = it * 4 + (lane_e >> 4), pc = lane_e & 15;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + tok * 256 + ((pc ^ tok) << 4));
                     const int m = mrow + tok, n = n0 + wn * NB * 16 + h * 64 + pc * 4;
                     if (m < g.M && n < g.N) {
@@ -757,7 +722,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         for (int j = 0; j < MB; ++j) {
             const int mrow = m0 + wm * MB * 16 + j * 16;
             unsigned char* stg = stg0 + (j & 1) * 4096;
-            const float osc = (mrow + frow) < g.M ? g.out_scale[mrow + frow] : 0.f;
+            const float osc = (mrow + frow_e) < g.M ? g.out_scale[mrow + frow_e] : 0.f;
 #pragma unroll
             for (int i = 0; i < NB; i += 2) {
                 const f32x4 gt = acc[i][j], up = acc[i + 1][j];
@@ -769,15 +734,15 @@ void gemm_bf16_kernel(GemmArgs g) {
                     split_f16x2(y * osc, f0, f1);
                     p0[r] = (short)f0; p1[r] = (short)f1;
                 }
-                // 8-byte slot s = (i / 2) * 4 + fg of the row's 16 (f1) + 16 (f0): 16-byte piece s / 2, XOR-swizzled by the row
-                const int sl = (i >> 1) * 4 + fg;
-                *reinterpret_cast<bf16x4*>(stg + frow * 256 + ((((sl >> 1)) ^ (frow & 7)) << 4) + ((sl & 1) << 3)) = p1;
-                *reinterpret_cast<bf16x4*>(stg + frow * 256 + 128 + ((((sl >> 1)) ^ (frow & 7)) << 4) + ((sl & 1) << 3)) = p0;
+                // 8-byte slot s = (i / 2) * 4 + fg_e of the row's 16 (f1) + 16 (f0): 16-byte piece s / 2, XOR-swizzled by the row
+                const int sl = (i >> 1) * 4 + fg_e;
+                *reinterpret_cast<bf16x4*>(stg + frow_e * 256 + ((((sl >> 1)) ^ (frow_e & 7)) << 4) + ((sl & 1) << 3)) = p1;
+                *reinterpret_cast<bf16x4*>(stg + frow_e * 256 + 128 + ((((sl >> 1)) ^ (frow_e & 7)) << 4) + ((sl & 1) << 3)) = p0;
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                // lane -> (row, plane, 16-byte piece): 4 rows x (8 pieces of f1 + 8 of f0) per instruction
-                const int tok = it * 4 + (lane >> 4), pl = (lane >> 3) & 1, pc = lane & 7;
+                // lane_e -> (row, plane, 16-byte piece): 4 rows x (8 pieces of f1 + 8 of f0) per instruction
+                const int tok = it * 4 + (lane_e >> 4), pl = (lane_e >> 3) & 1, pc = lane_e & 7;
                 const sr_i32x4 v = *reinterpret_cast<const sr_i32x4*>(stg + tok * 256 + pl * 128 + ((pc ^ (tok & 7)) << 4));
                 const int m = mrow + tok, n = nb + pc * 8;
                 if (m < g.M && n < half_n) {
@@ -1132,9 +1097,10 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         const bool want8 = big && big[0] == '8';
         // (epilogues without a staged output path - the per-sequence max, plain SwiGLU in fp32, three-bf16-plane outputs - stay on
         // the 8-wave loop: stored straight from four waves' accumulators their epilogue costs twice the 8-wave one)
-        // The QKV + RoPE epilogues stay on the 8-wave loop too: each output needs an accumulator AND its rotation partner, and with
-        // that epilogue behind the asm-pinned loop the register allocator spills accumulators INSIDE the k-loop (scratch in the
-        // ISA; the fp32-regime query encode went from 300 to 670 ms) - their staged versions are kept for a rotation through LDS.
+        // The QKV + RoPE epilogues stay on the 8-wave loop too (12 % of a layer's GEMM work): every output needs an accumulator AND
+        // its rotation partner plus two table loads, and behind the asm-pinned loop hipcc then spills to scratch - inside the
+        // k-loop before the lane coordinates were made opaque (fp32-regime query encode 300 -> 670 ms), in the epilogue after.
+        // tests/test_abi.py holds every four-wave instantiation to zero scratch.
         constexpr bool STAGED = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 ||
                                 EPI == EPI_RESID_F32_H || EPI == EPI_SWIGLU_SPLIT_H;
         if constexpr (STAGED) {
