@@ -294,6 +294,22 @@ def sparse_leg(args, device):
         lds_src = "profiles/r02_lds_rmw.json (tools/micro/lds_rmw.hip: random ds_read_b32 + ds_write_b32 on a 32 KB tile, no global traffic)"
     except Exception:
         pass
+    # HBM / fabric bytes per pass of the query-block kernel, from the committed PMC passes (rocprofv3 cannot run inside this
+    # process): used only for the same shape and the same kernel source
+    sp_traffic, sp_traffic_src = None, None
+    try:
+        import hashlib
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_sparse_traffic.json")) as f:
+            pm = json.load(f)
+        with open(os.path.join(ROOT, pm["kernel_source"]["file"]), "rb") as f:
+            same = hashlib.sha256(f.read()).hexdigest() == pm["kernel_source"]["sha256"]
+        sh = pm["shape"]
+        if same and (sh["V"], sh["N"], sh["L0_d"], sh["L0_q"], sh["nq"]) == (V, N, L0_d, L0_q, nq):
+            kk_ = [v for kname, v in pm["kernels"].items() if kname.startswith("sparse_block_kernel")][0]
+            sp_traffic = int(kk_["traffic_bytes"] * kk_["dispatches"] / pm["passes_profiled"])
+            sp_traffic_src = "profiles/r04_pmc_sparse_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes; bytes per pass of 6 980 queries, " + pm.get("commit", "?") + ")"
+    except Exception:
+        sp_traffic = None
     hbm_gbps = unique_bytes / kernel_s / 1e9
     valu_rate = valu_ops / kernel_s
     l2_rate = bytes_loaded / kernel_s
@@ -318,7 +334,9 @@ def sparse_leg(args, device):
            "roofline": {"kernel": "sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel",
                         "dense_column_terms": idx.block_stats()["dense_terms"],
                         "bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": round(hbm_gbps / PEAK_HBM_GBPS, 4), "traffic": None, "launches": int(n_l.value),
+                        "frac": round(hbm_gbps / PEAK_HBM_GBPS, 4), "traffic": sp_traffic, "traffic_source": sp_traffic_src,
+                        "traffic_unit": "bytes beyond L2 per pass of the whole query set (the algorithmic figure beside it: unique_index_bytes_per_pass)",
+                        "launches": int(n_l.value),
                         "kernel_ms_per_pass": round(kernel_s * 1e3, 1), "unique_index_bytes_per_pass": unique_bytes,
                         "hbm_floor_ms_per_pass": round(unique_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3, 2),
                         "note": "achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per posting) / "
@@ -362,7 +380,8 @@ def sparse_leg(args, device):
     del idx, h_indptr, h_ids, h_vals
     torch.cuda.empty_cache()
     if not args.no_drop_in:
-        out["drop_in"] = drop_in_sparse_leg(args, dict(LION_1B), (indptr, doc_ids, vals, N), (q_indptr, q_cols, q_vals, nq), device)
+        with contextlib.redirect_stdout(sys.stderr):          # the reference-shaped classes print like the reference does
+            out["drop_in"] = drop_in_sparse_leg(args, dict(LION_1B), (indptr, doc_ids, vals, N), (q_indptr, q_cols, q_vals, nq), device)
     del indptr, doc_ids, vals
     torch.cuda.empty_cache()
     if not args.no_sparse_sweep:
@@ -563,8 +582,9 @@ def drop_in_sparse_leg(args, cfg_model, idx_parts, q_parts, device):
     stub = _SyntheticSparseQueries(model, q_indptr, q_cols, q_vals, V, rows_of)
     container = IndexDictOfArray(dim_voc=V)
     container.set_device_csr(indptr, doc_ids, vals, N)
-    index_d = {"index": container, "ids_mapping": {i: str(i) for i in range(N)}, "device_csr": (indptr, doc_ids, vals, N)}
+    index_d = {"index": container, "ids_mapping": {i: str(i) for i in range(N)}, "device_csr": (indptr, doc_ids, vals, N), "stats": {}}
     tmp = tempfile.mkdtemp(prefix="sr_bench_sprun_")
+    retr = None
     try:
         retr = SparseRetrieval(stub, {"out_dir": tmp}, V, device, index_d=index_d, compute_stats=True)
         retr.doc_id_table()                                                  # per index, like doc_ids.pkl itself
@@ -590,7 +610,8 @@ def drop_in_sparse_leg(args, cfg_model, idx_parts, q_parts, device):
         l0 = json.load(open(os.path.join(tmp, "q_stats.json")))["L0_q"]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-        retr.hip_index.close()
+        if retr is not None:
+            retr.hip_index.close()
     del model
     out = {"workload": f"SparseRetrieval.retrieve: {nq} queries in {len(dev_loader)} loader batches of {B}, real HIP LlamaBiSparse encode at 1B dims per "
                        f"group + the synthetic Zipf query vectors (random weights give no realistic L0), top-{args.topk}, q_stats.json + run.json",
@@ -806,7 +827,7 @@ def main():
     # run inside this process), used only when measured on the same problem shape; the file names the commit it was taken at
     split_traffic, split_traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             pmc2 = json.load(f)
         shape2 = pmc2["dense_split_launch"]
         import hashlib
@@ -815,7 +836,7 @@ def main():
         if (same_kernel and shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
                 and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
             split_traffic = pmc2["kernels"]["dense_split_kernel"]["traffic_bytes"]
-            split_traffic_src = "profiles/r03_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
+            split_traffic_src = "profiles/r04_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
     except Exception:
         split_traffic = None
     if filtered:
@@ -855,7 +876,8 @@ def main():
     # ---- the reference's own call path at the same shape: loader batches of 128 -> get_top_docs -> run.json ----
     drop_in = None
     if world == 1 and filtered and not args.no_drop_in:
-        drop_in = drop_in_dense_leg(args, cfg, model, index, device, n_local)
+        with contextlib.redirect_stdout(sys.stderr):
+            drop_in = drop_in_dense_leg(args, cfg, model, index, device, n_local)
 
     # ---- the same step with the score kernel in split-bf16 arithmetic (opt-in precision modes of sr_dense_search;
     #      fp32 operands split into bf16 planes, 3 / 6 plane products on the bf16 MFMA pipe, fp32 accumulate) ----
