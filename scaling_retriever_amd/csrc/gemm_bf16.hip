@@ -1091,20 +1091,22 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
     }
     const char* env = sr_dev_getenv("SR_GEMM_PIPE");   // A/B switch: 0 = plain double-buffered loop
     {
-        // SR_GEMM_BIG=8w: the 8-wave loop (A/B); default: the four-wave loop.  Its buffer descriptors address a tile's rows with
-        // 32-bit byte offsets: 256 rows x 2 K bytes must stay below 2^31
+        // The four-wave loop is the default for the bf16 regime's plain-store / residual / SwiGLU GEMMs (o_proj, down_proj, gate-up:
+        // 88 % of a layer's GEMM work; +7-10 % on those, corpus encode 7 590 -> 8 390 passages/s).  SR_GEMM_BIG=8w: the 8-wave loop
+        // everywhere (A/B); SR_GEMM_BIG=4w: the four-wave loop also for the fp32 regime's fp16-plane GEMMs, which have staged
+        // epilogues too but measure 2 % SLOWER on it (query encode 300 -> 307 ms: K' = 3 K k-steps per tile, the epilogue does
+        // not matter there and the 8-wave loop's second wave per SIMD does) - tests force it to keep that path covered.
+        // The QKV + RoPE epilogues stay on the 8-wave loop (12 % of a layer's GEMM work): every output needs an accumulator AND its
+        // rotation partner plus two table loads, and behind the asm-pinned loop hipcc then spills to scratch - inside the k-loop
+        // before the lane coordinates were made opaque (fp32-regime query encode 300 -> 670 ms), in the epilogue after.
+        // tests/test_abi.py holds every four-wave instantiation to zero scratch.  The loop's buffer descriptors address a tile's
+        // rows with 32-bit byte offsets: 256 rows x 2 K bytes must stay below 2^31.
         const char* big = sr_dev_getenv("SR_GEMM_BIG");
-        const bool want8 = big && big[0] == '8';
-        // (epilogues without a staged output path - the per-sequence max, plain SwiGLU in fp32, three-bf16-plane outputs - stay on
-        // the 8-wave loop: stored straight from four waves' accumulators their epilogue costs twice the 8-wave one)
-        // The QKV + RoPE epilogues stay on the 8-wave loop too (12 % of a layer's GEMM work): every output needs an accumulator AND
-        // its rotation partner plus two table loads, and behind the asm-pinned loop hipcc then spills to scratch - inside the
-        // k-loop before the lane coordinates were made opaque (fp32-regime query encode 300 -> 670 ms), in the epilogue after.
-        // tests/test_abi.py holds every four-wave instantiation to zero scratch.
-        constexpr bool STAGED = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 ||
-                                EPI == EPI_RESID_F32_H || EPI == EPI_SWIGLU_SPLIT_H;
-        if constexpr (STAGED) {
-            if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && !(env && *env == '0'))
+        const bool want8 = big && big[0] == '8', want4 = big && big[0] == '4';
+        constexpr bool STAGED_BF16 = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32;
+        constexpr bool STAGED_F16 = EPI == EPI_RESID_F32_H || EPI == EPI_SWIGLU_SPLIT_H;
+        if constexpr (STAGED_BF16 || STAGED_F16) {
+            if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && (STAGED_BF16 || want4) && !(env && *env == '0'))
                 return launch_cfg<EPI, 2, 2, 8, 8, true, 2, 1>(g, s);
         }
     }
