@@ -233,15 +233,43 @@ class DenseFlatIndexer(DenseIndexer):
         assert self.index.ntotal == n_total, (self.index.ntotal, n_total)
         return n
 
+    KNN_CHUNKS = 4          # search_knn pipelines the query set in this many pieces when it is large (>= 1 024 queries)
+
     def search_knn(self, query_reps, top_docs: int):
-        scores, indexes = self.search_arrays(query_reps, top_docs)
-        # db ids through a numpy take per ROW of the result (the reference maps them hit by hit, indexer.py:212-213): the 7 M random
-        # reference-count touches of a Dev-sized result are what this costs, and a row at a time the list conversion finds the
-        # objects still in cache (2.5x faster than one take over the whole matrix); label -1 (fewer than k vectors) -> the
-        # trailing None of the table
+        """indexer.py:210-214: (list of db-id lists, fp32 scores [nq, k]).  The db ids come through a numpy take per ROW of the
+        result (the reference maps them hit by hit, :212-213): 7 M reference-count touches of a Dev-sized result are what the
+        mapping costs, and a row at a time the list conversion finds the objects still in cache; label -1 (fewer than k vectors)
+        -> the trailing None of the table.  A large query set is searched in KNN_CHUNKS pieces, the GPU working on piece c + 1 (in a
+        worker thread: the C call releases the GIL) while this thread maps piece c - the exact results do not depend on how
+        the queries are batched (pieces stay above 64 queries: one kernel family, one k order)."""
         table = self.id_table()
-        top_doc_ids = [table.take(row).tolist() for row in indexes]
-        return top_doc_ids, scores
+        if isinstance(query_reps, torch.Tensor):
+            q = query_reps.to(device=self.index.device, dtype=torch.float32)
+        else:
+            q = torch.from_numpy(np.ascontiguousarray(query_reps, dtype=np.float32)).to(self.index.device)
+        nq = q.shape[0]
+        n_chunks = self.KNN_CHUNKS if nq >= 1024 else 1
+        if n_chunks == 1:
+            scores, indexes = self.search_arrays(q, top_docs)
+            return [table.take(row).tolist() for row in indexes], scores
+        from concurrent.futures import ThreadPoolExecutor
+        per = (nq + n_chunks - 1) // n_chunks
+        bounds = [(c0, min(nq, c0 + per)) for c0 in range(0, nq, per)]
+        dev = self.index.device
+
+        def gpu(c):
+            with torch.cuda.device(dev):
+                return self.search_arrays(q[bounds[c][0]:bounds[c][1]], top_docs)
+        top_doc_ids, score_parts = [], []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(gpu, 0)
+            for c in range(len(bounds)):
+                scores, indexes = fut.result()
+                if c + 1 < len(bounds):
+                    fut = pool.submit(gpu, c + 1)
+                top_doc_ids.extend(table.take(row).tolist() for row in indexes)
+                score_parts.append(scores)
+        return top_doc_ids, np.concatenate(score_parts)
 
     def search_arrays(self, query_reps, top_docs: int):
         """(scores fp32 [nq, k], index positions int64 [nq, k]; -1 = fewer than k vectors) as host arrays: what search_knn maps

@@ -152,6 +152,25 @@ def test_search_knn_and_write_run_match_the_reference_loop(tiny, tmp_path):
     assert all(row[7:] == [None] * 3 and None not in row[:7] for row in ids7)
 
 
+def test_search_knn_in_pipelined_pieces_equals_one_search():
+    """>= 1 024 queries: search_knn searches in KNN_CHUNKS pieces (GPU on piece c + 1 while the host maps piece c); the lists and
+    scores are those of one search over the whole set."""
+    from scaling_retriever_amd.indexer import DenseFlatIndexer
+    rng = np.random.default_rng(12)
+    H, n_docs, nq, k = 64, 30_000, 1101, 40
+    embs = rng.standard_normal((n_docs, H)).astype(np.float32)
+    doc_ids = [f"D{3 * i}" for i in range(n_docs)]
+    index = DenseFlatIndexer()
+    index.init_index(H)
+    index.index_data(embs, doc_ids)
+    q = rng.standard_normal((nq, H)).astype(np.float32)
+    ids, scores = index.search_knn(q, k)
+    whole_s, whole_i = index.search_arrays(q, k)
+    assert DenseFlatIndexer.KNN_CHUNKS > 1 and np.array_equal(scores, whole_s) and scores.dtype == np.float32
+    assert ids == [[doc_ids[j] for j in row] for row in whole_i]
+    assert ids[0][0] is doc_ids[int(whole_i[0, 0])]          # the index's own objects, as the reference's id list gives
+
+
 def test_search_begin_lower_bound_is_an_exact_score_j_documents_reach():
     from scaling_retriever_amd.scoring import DenseIndexHIP
     dev = torch.device("cuda", 0)
