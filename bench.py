@@ -484,6 +484,9 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
     t_gq, (reps, _) = wall(lambda: eval_dense.generate_query_vecs(model, loader, device))
     same_bits = bool(torch.equal(reps, reps_pb))
     t_knn, (top_ids, top_scores) = wall(lambda: fi.search_knn(reps, args.topk))
+    t_arr, (_, arr_idx) = wall(lambda: fi.search_arrays(reps, args.topk))
+    table = fi.id_table()
+    t_map, _ = wall(lambda: [table.take(row).tolist() for row in arr_idx])
     assert isinstance(top_ids[0], list) and len(top_ids) == args.n_queries
     t_top, _ = wall(lambda: retriever.get_top_docs(loader, args.topk))
     tmp = tempfile.mkdtemp(prefix="sr_bench_run_")
@@ -508,7 +511,10 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
                                    "bit_identical_to_one_call_per_batch": same_bits,
                                    "one_query_encode_call_per_loader_batch_ms": round(t_pb * 1e3, 1)},
            "search_knn": {"ms": round(t_knn * 1e3, 1), "queries_per_s": round(nq / t_knn, 1),
-                          "note": "sr_dense_search + D2H + ONE numpy take for the db ids + .tolist() (returns the reference's list of lists)"},
+                          "search_arrays_ms": round(t_arr * 1e3, 1), "id_mapping_alone_ms": round(t_map * 1e3, 1),
+                          "note": "returns the reference's list of lists of db ids: the query set is searched in pieces (sr_dense_search + D2H "
+                                  "through pinned memory), the host maps piece c (numpy take per row + .tolist()) while the GPU searches piece c + 1; "
+                                  "search_arrays_ms = the whole set in one search + D2H, id_mapping_alone_ms = the 7 M-object mapping by itself"},
            "get_top_docs": {"ms": round(t_top * 1e3, 1), "queries_per_s": round(nq / t_top, 1)},
            "retrieval_task_with_run_json": {"ms": round(t_run * 1e3, 1), "queries_per_s": round(nq / t_run, 1), "run_json_bytes": int(nbytes),
                                             "note": "generate_query_vecs + search + sr_write_run_json (the bytes json.dump of the reference's nested "

@@ -219,9 +219,9 @@ def retrieval(args):
             scores, idx = topk_merge(gs, gi)
     if rank == 0:
         # run.json (eval_dense.py:225-241) straight from the result arrays: the bytes json.dump of the reference's nested dict gives
-        from scaling_retriever_amd.utils.run_file import write_run_json
+        from scaling_retriever_amd.utils.run_file import to_host, write_run_json
         doc_ids = np.concatenate([np.load(f) for f in id_files])
-        write_run_json(os.path.join(args.out_dir, "run.json"), qids, scores.cpu().numpy(), idx.cpu().numpy(), doc_ids)
+        write_run_json(os.path.join(args.out_dir, "run.json"), qids, to_host(scores), to_host(idx), doc_ids)
     if world > 1:
         dist.barrier()
 

@@ -27,7 +27,7 @@ from tqdm import tqdm
 from . import _lib
 from .scoring import DenseIndexHIP, SparseIndexHIP
 from .utils.inverted_index import IndexDictOfArray
-from .utils.run_file import IdTable, RunResult
+from .utils.run_file import IdTable, RunResult, to_host
 from .utils.utils import get_rank, get_world_size, is_first_worker, to_list
 
 logger = logging.getLogger()
@@ -279,7 +279,7 @@ class DenseFlatIndexer(DenseIndexer):
         else:
             q = torch.from_numpy(np.ascontiguousarray(query_reps, dtype=np.float32)).to(self.index.device)
         scores, indexes = self.index.search(q, top_docs)
-        return scores.cpu().numpy(), indexes.cpu().numpy()
+        return to_host(scores), to_host(indexes)
 
     def get_index_name(self):
         return "flat_index"
@@ -639,7 +639,7 @@ class SparseRetrieval:
         over the result arrays: the same mapping, without 7 M dict insertions."""
         q = _as_query_csr(sparse_query_vecs, self._dev)
         scores, ids, counts = self.hip_index.search(q.row_ptr, q.cols, q.vals, topk, threshold=threshold)
-        res = RunResult(qids, scores.cpu().numpy(), ids.cpu().numpy(), self.doc_id_table(), counts.cpu().numpy())
+        res = RunResult(qids, to_host(scores), to_host(ids), self.doc_id_table(), to_host(counts))
         stats = defaultdict(float)
         stats["L0_q"] = q.mean_l0()
         return res, stats
@@ -714,7 +714,7 @@ class ShardedSparseRetrieval(SparseRetrieval):
             return None
         doc_ids = self._all_doc_ids()
         n_docs = (max(doc_ids) + 1) if len(doc_ids) else 0
-        res = RunResult(qids, scores.cpu().numpy(), ids.cpu().numpy(), IdTable(_doc_id_table(doc_ids, n_docs)), counts_t.cpu().numpy())
+        res = RunResult(qids, to_host(scores), to_host(ids), IdTable(_doc_id_table(doc_ids, n_docs)), to_host(counts_t))
         nnz = (row_ptr[1:] - row_ptr[:-1])
         stats = {"L0_q": float(nnz.float().mean().item()) if nnz.numel() else 0.0}
         self._write_outputs(res, stats)
