@@ -841,7 +841,7 @@ def main():
             same_kernel = hashlib.sha256(f.read()).hexdigest() == pmc2["kernel_source"]["sha256"]       # stale once the kernel changes
         if (same_kernel and shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
                 and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
-            split_traffic = pmc2["kernels"]["dense_split_kernel"]["traffic_bytes"]
+            split_traffic = [v for kname, v in pmc2["kernels"].items() if kname.startswith("dense_split_kernel") and "<false>" not in kname][0]["traffic_bytes"]
             split_traffic_src = "profiles/r04_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
     except Exception:
         split_traffic = None
