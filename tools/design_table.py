@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Regenerates the measurement table of DESIGN.md section 6 from a bench line, so that the document cannot drift from the numbers:
-python tools/design_table.py profiles/r03_bench_line.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
+python tools/design_table.py profiles/r04_bench_line.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_line.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_bench_line.json")
 r = json.load(open(src))
 rf, bd = r["roofline"], r["breakdown"]
 rows = []
@@ -22,13 +22,22 @@ row("queries/s end to end at the reference's precision: fp32-regime query encode
 row("dominant kernel `dense_split_kernel<true>` (the certified filter's upper-bound pass, fp16 MFMA)",
     f"{rf['achieved']:.0f} TFLOP/s = **{rf['frac']:.3f} of the 16-bit MFMA peak**; {rf['avg_launch_ms']:.4f} ms per launch by HIP events, {rf['launches'] // r['steps']} launches per search = "
     f"{100 * rf['kernel_share_of_step']:.0f} % of the step; {rf['queries_certified']} queries certified, {rf['queries_redone_by_exact_kernel']} re-done; "
-    f"traffic beyond L2 per launch: {rf['traffic']} B ({rf.get('traffic_source')})")
+    f"traffic beyond L2 per launch: {(rf['traffic'] or 0) / 1e9:.2f} GB (`profiles/r04_pmc_traffic.json`)")
 em = r.get("exact_kernel_mode") or {}
 if em:
     row("the same step through the exact fp32 MFMA kernel (`exact_kernel_mode`: the data-independent floor)",
         f"{em['value']:.0f} queries/s; {em['roofline']['achieved']:.1f} TFLOP/s = **{em['roofline']['frac']:.3f} of the fp32 MFMA peak** ({em['roofline']['avg_launch_ms']:.3f} ms per launch)")
 row("query encode, fp32 regime", f"{bd['query_encode_ms']:.0f} ms for {bd['query_tokens']} tokens = {bd['query_encode_mfma_TFLOPs']:.0f} TFLOP/s of fp16 MFMA work (3 plane products per fp32 product); "
     f"bf16 regime: {bd['query_encode_ms_bf16_regime']:.0f} ms")
+di = r.get("drop_in")
+if di:
+    g, kn, td, rt = di["generate_query_vecs"], di["search_knn"], di["get_top_docs"], di["retrieval_task_with_run_json"]
+    row("drop-in: `generate_query_vecs` over 55 loader batches of 128 (`eval_dense.py:94-106`)",
+        f"{g['ms']} ms coalesced ({g['one_query_encode_call_per_loader_batch_ms']} ms with one call per batch); same bits: {g['bit_identical_to_one_call_per_batch']}")
+    row("drop-in: `DenseFlatIndexer.search_knn` → list of lists of db ids (`indexer.py:210-214`)",
+        f"**{kn['queries_per_s']:.0f} queries/s** ({kn['ms']} ms; one search + D2H {kn.get('search_arrays_ms')} ms, the 7 M-object id mapping alone {kn.get('id_mapping_alone_ms')} ms)")
+    row("drop-in: `get_top_docs` (encode + `search_knn`)", f"{td['queries_per_s']:.0f} queries/s ({td['ms']} ms)")
+    row("drop-in: retrieval task incl. `run.json` (`eval_dense.py:225-241`)", f"**{rt['queries_per_s']:.0f} queries/s** ({rt['ms']} ms, {rt['run_json_bytes'] / 1e6:.0f} MB file)")
 for m, name in (("fp32_class_mode", "bf16x6"), ("fast_mode", "bf16x3")):
     if r.get(m) and "value" in r[m]:
         row(f"{name} score MODE (fp32-class scores, not bit-identical; same query encode)", f"{r[m]['value']:.0f} queries/s, kernel at {r[m]['roofline']['frac']:.3f} of bf16 MFMA peak")
@@ -43,7 +52,8 @@ if sh:
 e = r.get("encode")
 if e:
     row("corpus encode through `store_embs`, Lion-DS-1B dims", f"**{e['value']:.0f} passages/s** ({e['sample_passages']} passages, budget {e['token_budget']} tokens, {e['wall_s']} s wall) = "
-        f"{e['roofline']['achieved']:.0f} TFLOP/s = **{e['roofline']['frac']:.3f} of bf16 MFMA peak** ({e['roofline']['frac_gpu_time_only']:.3f} over GPU time only)")
+        f"{e['roofline']['achieved']:.0f} TFLOP/s = **{e['roofline']['frac']:.3f} of bf16 MFMA peak** ({e['roofline']['frac_gpu_time_only']:.3f} over GPU time only)"
+        + (f"; the reference's padded-batch-128 loader: {e['padded_batch_128_mode']['passages_per_s']:.0f} passages/s" if e.get("padded_batch_128_mode") else ""))
 c5 = r.get("config5_8b")
 if c5:
     row("corpus encode, 8B dims (configs[4], one GPU)", f"{c5['encode']['value']:.0f} passages/s = {c5['encode']['roofline']['frac']:.3f} of peak; score stage over the GPU's 1/8 shard at H 4096 through the exact "
@@ -61,16 +71,27 @@ if sp:
     row("... what the kernel does, counted on the device", f"dense-column multiply-adds {b['valu_dense_columns']['ops_per_pass']:.3g} lane-ops: VALU floor {b['valu_dense_columns']['floor_ms_per_pass']} ms; "
         f"bytes loaded {b['l2_bytes_loaded']['bytes_per_pass']:.3g} (columns {b['l2_bytes_loaded']['of_which_dense_columns']:.3g}): L2 floor {b['l2_bytes_loaded']['floor_ms_per_pass']} ms; "
         f"scattered postings {b['lds_scatter']['rmw_per_pass']:.3g}: LDS floor {b['lds_scatter']['floor_ms_per_pass']} ms; sum of floors {b['sum_of_floors_ms']} ms, kernel / floors = {b['kernel_over_sum_of_floors']}")
+    if sp["roofline"].get("traffic"):
+        row("... HBM / fabric traffic of the sparse scorer", f"{sp['roofline']['traffic'] / 1e9:.0f} GB beyond L2 per pass against {sp['roofline']['unique_index_bytes_per_pass'] / 1e9:.1f} GB of unique posting bytes "
+            f"(`profiles/r04_pmc_sparse_traffic.json`)")
+    if sp.get("drop_in"):
+        d2 = sp["drop_in"]
+        row("drop-in: `SparseRetrieval.retrieve` incl. `run.json` + `q_stats.json` (`indexer.py:530-540`)",
+            f"**{d2['retrieve']['queries_per_s']:.0f} queries/s** ({d2['retrieve']['ms']} ms: query encode {d2['generate_query_vecs_ms']} ms, search → RunResult {d2['search_to_RunResult_ms']} ms)")
+    sw = sp.get("sparse_sweep")
+    if sw:
+        cells = "; ".join(f"{x['index']} {x['L0_d']}/{x['L0_q']}: {x['queries_per_s'] / 1e3:.1f} k" for x in sw["rows"])
+        row("sparse sweep (index L0_d/L0_q: queries/s; 64 queries per cell bit-exact vs the C oracle)", cells)
     cb = sp["cpu_baseline"]
     row("sparse CPU baseline", f"{cb['value']} queries/s with the reference's 32 threads (4 × 8); best shape on the host: {cb['best_shape_on_this_host']['value']} with {cb['best_shape_on_this_host']['threads']} threads")
 cb = r.get("cpu_baseline")
 if cb:
     row("dense CPU baseline (faiss's algorithm: BLAS sgemm blocks + a heap per query)", f"{cb['value']} queries/s on {cb.get('host_cpu')} ({cb['cores']} hardware threads, {cb.get('threads')} used: the best sgemm rate measured, "
         f"{cb.get('sgemm_gflops')} GFLOP/s; sgemm {cb.get('sgemm_s')} s + heaps {cb.get('heap_s')} s on the sample)")
-table = "\n".join([f"| r03, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
+table = "\n".join([f"| r04, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-B, E = "<!-- BEGIN r03 table (tools/design_table.py) -->", "<!-- END r03 table -->"
+B, E = "<!-- BEGIN r04 table (tools/design_table.py) -->", "<!-- END r04 table -->"
 if B in s:
     s = s[:s.index(B) + len(B)] + "\n" + table + "\n" + s[s.index(E):]
     open(p, "w").write(s)
