@@ -1000,7 +1000,9 @@ def main():
                "sample": f"scoring stage only (oracle.scoring.flat_ip_search_blas_heap = faiss IndexFlatIP.search as faiss-cpu runs it: "
                          f"host BLAS (OpenBLAS behind numpy) sgemm over (query block, database block) pairs, with the thread count that measured "
                          f"the best sgemm rate on this host ({st['threads']} of {os.cpu_count()} hardware threads), + one heap per query in C / OpenMP, oracle/score_cpu.c): {nqs} queries x {ns} docs x {H}, top-{args.topk}, took {tc:.2f}s; "
-                         f"extrapolated linearly to {args.n_docs} docs; query encoding not included"}
+                         f"extrapolated linearly to {args.n_docs} docs; query encoding not included",
+               "note": f"the host BLAS is the limiter: sgemm ran at {st['sgemm_gflops']:.0f} GFLOP/s, a few per cent of this host's fp32 peak "
+                       f"({100 * st['sgemm_s'] / max(tc, 1e-9):.0f} % of the sample's time; the heaps take the rest) - a reported baseline, not a target"}
         del Dh, cs, ci
 
 

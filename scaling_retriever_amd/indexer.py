@@ -256,9 +256,12 @@ class DenseFlatIndexer(DenseIndexer):
         per = (nq + n_chunks - 1) // n_chunks
         bounds = [(c0, min(nq, c0 + per)) for c0 in range(0, nq, per)]
         dev = self.index.device
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))          # q may come from a side stream of the caller
 
         def gpu(c):
             with torch.cuda.device(dev):
+                torch.cuda.current_stream(dev).wait_event(ready)          # the worker thread's current stream is the default one
                 return self.search_arrays(q[bounds[c][0]:bounds[c][1]], top_docs)
         top_doc_ids, score_parts = [], []
         with ThreadPoolExecutor(max_workers=1) as pool:
