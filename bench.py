@@ -486,7 +486,8 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
     t_knn, (top_ids, top_scores) = wall(lambda: fi.search_knn(reps, args.topk))
     t_arr, (_, arr_idx) = wall(lambda: fi.search_arrays(reps, args.topk))
     table = fi.id_table()
-    t_map, _ = wall(lambda: [table.take(row).tolist() for row in arr_idx])
+    t_map, _ = wall(lambda: fi.id_lists(arr_idx))
+    t_map_np, _ = wall(lambda: [table.take(row).tolist() for row in arr_idx], 1)
     assert isinstance(top_ids[0], list) and len(top_ids) == args.n_queries
     t_top, _ = wall(lambda: retriever.get_top_docs(loader, args.topk))
     tmp = tempfile.mkdtemp(prefix="sr_bench_run_")
@@ -512,9 +513,11 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
                                    "one_query_encode_call_per_loader_batch_ms": round(t_pb * 1e3, 1)},
            "search_knn": {"ms": round(t_knn * 1e3, 1), "queries_per_s": round(nq / t_knn, 1),
                           "search_arrays_ms": round(t_arr * 1e3, 1), "id_mapping_alone_ms": round(t_map * 1e3, 1),
+                          "id_mapping_by_numpy_take_per_row_ms": round(t_map_np * 1e3, 1),
                           "note": "returns the reference's list of lists of db ids: the query set is searched in pieces (sr_dense_search + D2H "
-                                  "through pinned memory), the host maps piece c (numpy take per row + .tolist()) while the GPU searches piece c + 1; "
-                                  "search_arrays_ms = the whole set in one search + D2H, id_mapping_alone_ms = the 7 M-object mapping by itself"},
+                                  "through pinned memory), the host builds the lists of piece c (csrc/host_lists.c: hits radix-sorted by index position, id objects "
+                                  "visited in index order) while the GPU searches piece c + 1; search_arrays_ms = the whole set in one search + D2H, "
+                                  "id_mapping_alone_ms = the 7 M references by themselves (the numpy take + tolist per row it replaces beside it)"},
            "get_top_docs": {"ms": round(t_top * 1e3, 1), "queries_per_s": round(nq / t_top, 1)},
            "retrieval_task_with_run_json": {"ms": round(t_run * 1e3, 1), "queries_per_s": round(nq / t_run, 1), "run_json_bytes": int(nbytes),
                                             "note": "generate_query_vecs + search + sr_write_run_json (the bytes json.dump of the reference's nested "

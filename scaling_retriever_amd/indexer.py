@@ -233,16 +233,22 @@ class DenseFlatIndexer(DenseIndexer):
         assert self.index.ntotal == n_total, (self.index.ntotal, n_total)
         return n
 
+    def id_lists(self, positions):
+        """[[db id of p for p in row] for row in positions] (indexer.py:212-213) for a C-contiguous int64 [nq, k] array of index
+        positions; -1 -> None.  csrc/host_lists.c visits the id objects in index order instead of hit order (7 M references over a
+        500 MB object heap: a TLB miss each in hit order); the lists hold the index's own id objects, as the reference's do."""
+        from . import _host_lists
+        table = self.id_table()
+        positions = np.ascontiguousarray(positions, dtype=np.int64)
+        return _host_lists.take_rows(table.ctypes.data, len(table) - 1, positions.ctypes.data, positions.shape[0], positions.shape[1])
+
     KNN_CHUNKS = 4          # search_knn pipelines the query set in this many pieces when it is large (>= 1 024 queries)
 
     def search_knn(self, query_reps, top_docs: int):
-        """indexer.py:210-214: (list of db-id lists, fp32 scores [nq, k]).  The db ids come through a numpy take per ROW of the
-        result (the reference maps them hit by hit, :212-213): 7 M reference-count touches of a Dev-sized result are what the
-        mapping costs, and a row at a time the list conversion finds the objects still in cache; label -1 (fewer than k vectors)
-        -> the trailing None of the table.  A large query set is searched in KNN_CHUNKS pieces, the GPU working on piece c + 1 (in a
-        worker thread: the C call releases the GIL) while this thread maps piece c - the exact results do not depend on how
-        the queries are batched (pieces stay above 64 queries: one kernel family, one k order)."""
-        table = self.id_table()
+        """indexer.py:210-214: (list of db-id lists, fp32 scores [nq, k]); label -1 (fewer than k vectors) -> None.  The lists come
+        from id_lists (csrc/host_lists.c).  A large query set is searched in KNN_CHUNKS pieces, the GPU working on piece c + 1 (in a
+        worker thread: the C call releases the GIL) while this thread builds the lists of piece c - the exact results do not depend
+        on how the queries are batched (pieces stay above 64 queries: one kernel family, one k order)."""
         if isinstance(query_reps, torch.Tensor):
             q = query_reps.to(device=self.index.device, dtype=torch.float32)
         else:
@@ -251,7 +257,7 @@ class DenseFlatIndexer(DenseIndexer):
         n_chunks = self.KNN_CHUNKS if nq >= 1024 else 1
         if n_chunks == 1:
             scores, indexes = self.search_arrays(q, top_docs)
-            return [table.take(row).tolist() for row in indexes], scores
+            return self.id_lists(indexes), scores
         from concurrent.futures import ThreadPoolExecutor
         per = (nq + n_chunks - 1) // n_chunks
         bounds = [(c0, min(nq, c0 + per)) for c0 in range(0, nq, per)]
@@ -270,7 +276,7 @@ class DenseFlatIndexer(DenseIndexer):
                 scores, indexes = fut.result()
                 if c + 1 < len(bounds):
                     fut = pool.submit(gpu, c + 1)
-                top_doc_ids.extend(table.take(row).tolist() for row in indexes)
+                top_doc_ids.extend(self.id_lists(indexes))
                 score_parts.append(scores)
         return top_doc_ids, np.concatenate(score_parts)
 
