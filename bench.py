@@ -469,13 +469,18 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
     retriever = eval_dense.LocalFaissDenseRetriever(model, device=device, index=fi)
 
     def wall(fn, n=2):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        """Mean wall time of fn() over n calls after one warm-up call.  The previous call's result is dropped OUTSIDE the timed
+        region: freeing 7 M references of a list-of-lists result is the caller's business, not the call's."""
+        r = fn()
+        total = 0.0
         for _ in range(n):
+            r = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             r = fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, r
+            torch.cuda.synchronize()
+            total += time.perf_counter() - t0
+        return total / n, r
 
     def per_batch_encode():                     # the reference's loop, one query_encode call per loader batch
         with torch.no_grad():

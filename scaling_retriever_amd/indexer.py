@@ -242,7 +242,7 @@ class DenseFlatIndexer(DenseIndexer):
         positions = np.ascontiguousarray(positions, dtype=np.int64)
         return _host_lists.take_rows(table.ctypes.data, len(table) - 1, positions.ctypes.data, positions.shape[0], positions.shape[1])
 
-    KNN_CHUNKS = 4          # search_knn pipelines the query set in this many pieces when it is large (>= 1 024 queries)
+    KNN_CHUNKS = 2          # search_knn pipelines the query set in this many pieces when it is large (>= 1 024 queries)
 
     def search_knn(self, query_reps, top_docs: int):
         """indexer.py:210-214: (list of db-id lists, fp32 scores [nq, k]); label -1 (fewer than k vectors) -> None.  The lists come
