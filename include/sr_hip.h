@@ -102,6 +102,12 @@ int sr_dense_index_filter_stats(sr_dense_index* idx, int64_t* n_filtered, int64_
 int sr_dense_index_filter_query_stats(sr_dense_index* idx, int64_t* n_certified, int64_t* n_redone);
 /* Workspace ceiling in bytes for candidate buffers (default 4 GiB). */
 int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t bytes);
+/* on != 0: batches of <= 64 queries run the tiled kernels instead of the streaming one, so that EVERY batch size accumulates in
+ * one k order: a query's ids and fp32 scores are then the same bits alone, in a batch of 8 and in a batch of 6 980 (cost: a pass
+ * of <= 32 queries reads D at ~4.4 TB/s instead of ~5.9).  Off (default): batches <= 64 and larger ones are each exact fp32 chains
+ * but differ in the last bit - as faiss's IndexFlatIP.search does between its small-batch loop and its sgemm path (the switch at
+ * 20 queries that /root/reference/scaling_retriever/indexer.py:211 inherits).                                                     */
+int sr_dense_index_set_batch_invariant(sr_dense_index* idx, int on);
 int sr_dense_index_destroy(sr_dense_index* idx);
 /* Measurement hook: while enabled, every launch of the score kernel is bracketed by HIP
  * events on the search stream.  _read synchronises those events and returns the number

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sr_dense_index_ntotal": (c_int64, [c_void_p]),
     "sr_dense_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "sr_dense_index_set_workspace_limit": (c_int, [c_void_p, c_int64]),
+    "sr_dense_index_set_batch_invariant": (c_int, [c_void_p, c_int]),
     "sr_dense_index_set_precision": (c_int, [c_void_p, c_int]),
     "sr_dense_search_begin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sr_dense_search_finish": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -392,6 +392,7 @@ struct sr_dense_index {
     int64_t ntotal = 0;
     int64_t ws_limit = 4ll << 30;
     int precision = SR_PRECISION_FP32;
+    bool batch_invariant = false;          // sr_dense_index_set_batch_invariant: batches <= 64 run the tiled kernels (one k order)
     unsigned short* qpl[3] = {nullptr, nullptr, nullptr};   // query planes for the split precisions
     int64_t q_cap = 0;
     TopkWS ws;
@@ -528,6 +529,13 @@ extern "C" int sr_dense_index_set_workspace_limit(sr_dense_index* idx, int64_t b
     return SR_OK;
 }
 
+extern "C" int sr_dense_index_set_batch_invariant(sr_dense_index* idx, int on) {
+    SR_REQUIRE(idx, "sr_dense_index_set_batch_invariant: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->batch_invariant = on != 0;
+    return SR_OK;
+}
+
 extern "C" int sr_dense_index_destroy(sr_dense_index* idx) {
     if (!idx) return SR_OK;
     idx->ws.release();
@@ -661,7 +669,7 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
         SR_TRY(topk_finalize(ws, nq, k, -3.402823466e38f, d_out_scores, d_out_ids, nullptr, s));
         return SR_OK;
     }
-    const bool use_stream = variant != 9 && !force_tiled && dense_stream_supports((int)nq, idx->dim);
+    const bool use_stream = variant != 9 && !force_tiled && !idx->batch_invariant && dense_stream_supports((int)nq, idx->dim);
     if (use_stream) {
         // HBM-bound regime: D straight to registers, chunks grow geometrically (64 Ki docs, x2 per launch)
         int64_t cap = idx->ws_limit / (8 * nq);

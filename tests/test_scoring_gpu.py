@@ -353,3 +353,38 @@ def test_topk_ties_straddling_rank_k_resolve_by_ascending_doc_index():
         for g0 in np.flatnonzero(np.diff(sc, prepend=np.inf) != 0):            # inside every tie group: ascending ids
             g1 = g0 + np.argmax(np.append(sc[g0:] != sc[g0], True))
             assert np.all(np.diff(row[g0:g1]) > 0)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32_filtered"])
+def test_batch_invariant_mode_gives_a_query_the_same_bits_alone_and_in_any_batch(precision):
+    """sr_dense_index_set_batch_invariant: one k order for every batch size.  A query alone, among 8, among 40
+    (the streaming kernel's range when the mode is off) and inside a batch of 300 (the tiled kernels / the certified filter) returns
+    identical ids and fp32 scores through sr_dense_search; with the mode off the small batches are exact chains in another k order
+    (equal to 1 ulp, the documented default - as faiss between its small-batch loop and its sgemm path)."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    dev = torch.device("cuda", 0)
+    N, H, k = 200_000, 512, 100
+    g = torch.Generator(device=dev).manual_seed(77)
+    D = torch.randn((N, H), device=dev, generator=g) * (0.5 / H ** 0.5)
+    Q = torch.randn((300, H), device=dev, generator=g) * (0.5 / H ** 0.5)
+    idx = DenseIndexHIP(H, device=dev)
+    idx.set_precision(precision)
+    idx.add_device_rows(D)
+    idx.set_batch_invariant(True)
+    s300, i300 = idx.search(Q, k)
+    for n in (1, 8, 40, 64, 65):
+        s, i = idx.search(Q[:n].contiguous(), k)
+        assert torch.equal(s, s300[:n]) and torch.equal(i, i300[:n]), n
+    s1, i1 = idx.search(Q[7:8].contiguous(), k)
+    assert torch.equal(s1, s300[7:8]) and torch.equal(i1, i300[7:8])
+    # the mode changes the kernel family of small batches, not the large-batch result
+    idx.set_batch_invariant(False)
+    s300b, i300b = idx.search(Q, k)
+    assert torch.equal(s300b, s300) and torch.equal(i300b, i300)
+    s8, i8 = idx.search(Q[:8].contiguous(), k)
+    assert torch.allclose(s8, s300[:8], rtol=1e-6, atol=1e-7)
+    # and the results are the oracle's (k-ordered fmaf chain of the tiled kernels)
+    Qh, Dh = Q[:4].cpu().numpy(), D.cpu().numpy()
+    F = O.dense_scores_fma(Qh, Dh, O.dense_korder(300, H))
+    es, ei = O.topk_rows(F, k)
+    assert np.array_equal(i300[:4].cpu().numpy(), ei) and np.array_equal(s300[:4].cpu().numpy(), es)
