@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <fcntl.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -126,8 +128,8 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
     SR_REQUIRE(n_docs >= 0 && (n_docs == 0 || h_doc_i64 || (h_doc_bytes && (h_doc_off || doc_width > 0))),
                "sr_write_run_json: no document ids");
     const Keys qk{h_qid_i64, h_qid_bytes, h_qid_off, qid_width}, dk{h_doc_i64, h_doc_bytes, h_doc_off, doc_width};
-    FILE* f = fopen(path, "wb");
-    if (!f) {
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) {
         sr_set_error("sr_write_run_json: cannot open %s: %s", path, strerror(errno));
         return SR_ERR_INVALID;
     }
@@ -135,14 +137,19 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
     if ((int64_t)nt > nq) nt = nq > 0 ? (int)nq : 1;
-    // queries are formatted in blocks of `nt` slabs at a time: thread t formats a contiguous run of queries into its own buffer,
-    // the buffers are written in order.  A slab = 256 queries per thread keeps the buffers (~8 MB each at k = 1000) cache-friendly.
-    const int64_t slab = 256;
+    // Thread t formats a contiguous run of queries (a slab) into its own buffer; once a round of `nt` slabs is formatted the
+    // buffers' file offsets are known and every thread writes its own buffer with pwrite (the copy into the page cache is most of
+    // the time of a 200 MB file and parallelises like the formatting).  Slabs are sized so that a Dev-sized result is one round.
+    int64_t slab = (nq + nt - 1) / (nt > 0 ? nt : 1);
+    if (slab < 32) slab = 32;
+    if (slab > 1024) slab = 1024;
     std::vector<std::string> bufs((size_t)nt);
-    std::vector<int> bad((size_t)nt, 0);
-    int64_t total = 0;
-    bool ok = fputc('{', f) != EOF;
-    total += 1;
+    std::vector<int> bad((size_t)nt, 0), io_bad((size_t)nt, 0);
+    std::vector<int64_t> off((size_t)nt, 0);
+    std::vector<size_t> skip((size_t)nt, 0);
+    int64_t total = 1;                                        // the opening brace
+    bool ok = pwrite(fd, "{", 1, 0) == 1;
+    bool any_entry = false;
     for (int64_t q0 = 0; q0 < nq && ok; q0 += slab * nt) {
         auto work = [&](int t) {
             const int64_t a = q0 + (int64_t)t * slab, b = a + slab < nq ? a + slab : nq;
@@ -182,21 +189,40 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
             }
             s.resize(used);
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-        for (int t = 0; t < nt && ok; ++t) {
+        auto put = [&](int t) {
             const std::string& s = bufs[(size_t)t];
-            if (s.empty()) continue;
-            const size_t skip = total == 1 ? 2 : 0;
-            ok = fwrite(s.data() + skip, 1, s.size() - skip, f) == s.size() - skip;
-            total += (int64_t)(s.size() - skip);
+            size_t done = skip[(size_t)t];
+            while (done < s.size()) {
+                const ssize_t w = pwrite(fd, s.data() + done, s.size() - done, (off_t)(off[(size_t)t] + (int64_t)(done - skip[(size_t)t])));
+                if (w <= 0) { io_bad[(size_t)t] = 1; return; }
+                done += (size_t)w;
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto& x : th) x.join();
         }
+        for (int t = 0; t < nt; ++t) {
+            const std::string& s = bufs[(size_t)t];
+            skip[(size_t)t] = (!s.empty() && !any_entry) ? 2 : 0;          // the file's first entry has no separator in front
+            if (!s.empty()) any_entry = true;
+            off[(size_t)t] = total;
+            total += (int64_t)(s.size() - skip[(size_t)t]);
+        }
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t)
+                if (!bufs[(size_t)t].empty()) th.emplace_back(put, t);
+            put(0);
+            for (auto& x : th) x.join();
+        }
+        for (int t = 0; t < nt; ++t) ok = ok && !io_bad[(size_t)t];
     }
-    ok = ok && fputc('}', f) != EOF;
+    ok = ok && pwrite(fd, "}", 1, (off_t)total) == 1;
     total += 1;
-    ok = (fclose(f) == 0) && ok;
+    ok = (close(fd) == 0) && ok;
     for (int t = 0; t < nt; ++t)
         if (bad[(size_t)t]) {
             sr_set_error("sr_write_run_json: a result index lies outside the document id table of %lld entries", (long long)n_docs);

@@ -52,6 +52,27 @@ def test_int_keys_byte_identical_to_json_dump(tmp_path, threads):
     assert "1009" not in json.loads(want)
 
 
+@pytest.mark.parametrize("threads", [1, 2, 64])
+def test_several_rounds_of_slabs_and_empty_leading_queries(tmp_path, threads):
+    """More queries than one round of slabs holds (a thread's slab is capped at 1 024 queries), the first queries - a whole first
+    slab with 64 threads - without any hit: the file's first entry must come without a separator wherever it is."""
+    rng = np.random.default_rng(4)
+    nq, k, N = 2300, 4, 900
+    scores, positions = _case(rng, nq, k, N)
+    positions[:40, :] = -1
+    positions[1500:1510, :] = -1
+    qids = [str(10 * i) for i in range(nq)]
+    docs = np.arange(N, dtype=np.int64) * 3
+    p = tmp_path / "r.json"
+    n = write_run_json(p, qids, scores, positions, docs, n_threads=threads)
+    want = json.dumps(_reference_dict(qids, scores, positions, docs))
+    assert p.read_text() == want and n == len(want)
+    # an existing longer file is replaced, not overwritten in place
+    p.write_text("x" * (2 * len(want)))
+    write_run_json(p, qids, scores, positions, docs, n_threads=threads)
+    assert p.read_text() == want
+
+
 def test_counts_string_keys_and_escapes(tmp_path):
     rng = np.random.default_rng(1)
     nq, k, N = 64, 30, 400
