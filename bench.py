@@ -222,8 +222,9 @@ def encode_leg(args, cfg, model, device, rank, world, share_gpu, flop_per_token=
         finally:
             shutil.rmtree(tmp2, ignore_errors=True)
         padded = {"passages_per_s": round(n_p / tp, 1), "sample_passages": int(n_p), "wall_s": round(tp, 3),
-                  "note": "the reference's loader shape: 128 consecutive passages per doc_encode call, padded to the batch's longest (host-side "
-                          "collation in this process, one call = ~9 600 real tokens); the token-budget loader above is the drivers' default"}
+                  "note": "the reference's loader shape: batches of 128 consecutive passages padded to the batch's longest (host-side collation in "
+                          "this process, ~9 600 real tokens per batch); store_embs encodes four such batches per engine pass (rows bit-identical to "
+                          "batch-by-batch doc_encode calls); the token-budget loader above is the drivers' default"}
     # whole-job figures: every rank encoded 1/W of the sample, times are the max over ranks
     all_lens = np.clip(np.round(np.random.default_rng(3).lognormal(4.25, 0.35, size=args.encode_passages)), 8, 192)
     tokens = float(all_lens.sum())

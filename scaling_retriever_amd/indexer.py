@@ -65,6 +65,9 @@ def encode_group(model, group, device, which="encode"):
     return torch.cat(outs) if len(outs) > 1 else outs[0]
 
 
+STORE_GROUP_ROWS = 512          # store_embs: fixed-size loader batches encoded per engine pass (4 batches of 128)
+
+
 # =============================================================== dense: corpus encode
 def store_embs(model, collection_loader, local_rank, index_dir, device, chunk_size=2_000_000, use_fp16=False,
                is_query=False, idx_to_id=None):
@@ -126,17 +129,32 @@ def store_embs(model, collection_loader, local_rank, index_dir, device, chunk_si
         total = len(collection_loader)
     except TypeError:
         total = None              # token-budget loaders do not know their batch count up front
-    for idx, batch in tqdm(enumerate(collection_loader), disable=not is_first_worker(),
-                           desc="encode # {} seqs".format(total if total is not None else "?"), total=total):
-        inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "ids"}
+    # The reference's loader yields fixed batches of per_device_eval_batch_size passages (128: ~9 600 real tokens), less than the
+    # engine wants per pass.  Fixed-size batches are therefore encoded a few at a time in ONE engine pass (encode_batches: every row
+    # keeps the positions of its own batch, so the vectors are those of batch-by-batch doc_encode calls, bit for bit); a
+    # token-budget loader's batches are already sized for the engine and go one by one.  Chunk files keep the reference's row
+    # counts: a group's rows are appended batch by batch, with the flush check in between.
+    group_rows = STORE_GROUP_ROWS if (batch_size and hasattr(enc, "encode_batches")) else 0
+    progress = tqdm(disable=not is_first_worker(), desc="encode # {} seqs".format(total if total is not None else "?"), total=total)
+    for group in (batch_groups(collection_loader, group_rows) if group_rows else ([b] for b in collection_loader)):
         with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):      # indexer.py:46-52
-            reps = enc.doc_encode(**inputs)
-        text_ids = batch["ids"]
-        assert isinstance(text_ids, list)
-        embeddings.append(reps)
-        embeddings_ids.extend(text_ids)
-        if len(embeddings_ids) >= chunk_docs:
-            flush()
+            if len(group) > 1:
+                reps_g = encode_group(enc, group, device, which="doc_encode")
+            else:
+                inputs = {k: v.to(device, non_blocking=True) for k, v in group[0].items() if k != "ids"}
+                reps_g = enc.doc_encode(**inputs)
+        r0 = 0
+        for batch in group:
+            text_ids = batch["ids"]
+            assert isinstance(text_ids, list)
+            embeddings.append(reps_g[r0:r0 + len(text_ids)])
+            r0 += len(text_ids)
+            embeddings_ids.extend(text_ids)
+            progress.update(1)
+            if len(embeddings_ids) >= chunk_docs:
+                flush()
+        assert r0 == len(reps_g), (r0, len(reps_g))
+    progress.close()
     if len(embeddings) != 0:
         print("last embedddings shape = {}".format((sum(len(e) for e in embeddings), embeddings[0].shape[1])))
         flush()

@@ -78,6 +78,11 @@ def test_store_embs_then_dense_retrieval(tiny, tmp_path):
     assert embs.dtype == np.float32 and embs.shape == (70, cfg["hidden_size"]) and ids == pids
     ref_d = _oracle_encode(LB.dense_encode, w, cfg, docs, V - 1)
     assert np.linalg.norm(embs - ref_d) / np.linalg.norm(ref_d) < 1.5e-2
+    # store_embs encodes the loader's fixed-size batches a few at a time in one engine pass: the rows are those of the reference's
+    # batch-by-batch doc_encode calls under autocast (indexer.py:46-52), bit for bit
+    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+        per_batch = torch.cat([model.doc_encode(input_ids=b["input_ids"].cuda(), attention_mask=b["attention_mask"].cuda()) for b in loader])
+    assert np.array_equal(embs, per_batch.float().cpu().numpy())
     # retrieval task (eval_dense.py:190-241)
     index = DenseFlatIndexer()
     index.init_index(cfg["hidden_size"])
