@@ -284,17 +284,18 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(SparseArgs a) {
 #define SPB_U 4       // postings per lane and group
 #endif
 #ifndef SPB_RING
-#define SPB_RING 6    // register sets of a wave's group walk: SPB_RING - 1 groups of loads in flight per wave
-#endif
+#define SPB_RING 5    // register sets of a wave's group walk: SPB_RING - 1 groups of loads in flight per wave.  Round 4: the kernel is
+#endif                // indifferent to the ring depths (3 .. 6 sets: 222-230 ms per pass) - it is not the loads it waits for; the
+                      // shallower rings leave the kernel without scratch (245 VGPRs, no VGPR spill) and are 3 % faster
 #define SPB_GROUP (SPB_U * 64)                       // postings per wave and group of the longer runs
 #define SPB_TSTRIDE (SPB_TILE + 64)
 #define SPB_DESC 256
 #define SPB_LIGHT 64      // runs up to this many postings take the one-step path
 #ifndef SPB_DRING
-#define SPB_DRING 3     // register sets of the dense-column walk
+#define SPB_DRING 2     // register sets of the dense-column walk
 #endif
 #ifndef SPB_LRING
-#define SPB_LRING 8
+#define SPB_LRING 4
 #endif
 #ifndef SPB_SUBS
 #define SPB_SUBS 1     // consecutive sub-tiles per workgroup: the plan fetch and the launch cost amortise, the next sub-tile's
