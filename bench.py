@@ -21,11 +21,17 @@ sample, rank 0 at N = 1 only), and the other stages / configs of the headline me
   `filter_robustness`  the search stage on anisotropic / near-duplicate corpora and queries drawn near documents (full shape),
                        each compared with the exact kernel on all queries, with the certified / re-done query counts;
   `shard_1of8`         BASELINE.json configs[3] on one GPU: one of 8 doc shards with and without the threshold exchange;
+  `drop_in`            the reference's own entry points at the full shape, inputs as its DataLoader yields them (55 batches of 128
+                       queries, string ids): generate_query_vecs, DenseFlatIndexer.search_knn (list of lists of db ids),
+                       get_top_docs, and the retrieval task including run.json (eval_dense.py:94-135,225-241);
   `encode`             passages/s of the corpus-encode task: >= 100 000 synthetic passages through store_embs (token-budget
                        batches -> doc_encode under autocast -> D2H -> embs_*.npy / ids_*.npy / plan.json), MFMA roofline;
+                       `padded_batch_128_mode`: the same through the reference's loader shape (batches of 128 padded passages);
   `sparse`             BASELINE.json configs[2] (N = 1 only): queries/s of sr_sparse_search on the MSMARCO-shaped synthetic
                        inverted index, all CPU-scored queries compared bit for bit with the oracle, the 32-thread CPU baseline,
-                       and `bounds`: the kernel's VALU / L2 / LDS floors from work counted on the device;
+                       `bounds` (the kernel's VALU / L2 / LDS floors from work counted on the device), `roofline.traffic` (PMC),
+                       `drop_in` (SparseRetrieval.retrieve incl. run.json) and `sparse_sweep` (L0_d x L0_q x two distributions);
+  `small_batch`        1 and 16 queries (the HBM-bound regime), each also in the batch-invariant mode;
   `config5_8b`         BASELINE.json configs[4]: one GPU's share at Lion-DS-8B dims.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
