@@ -389,6 +389,8 @@ class SparseIndexer:
         self.world_size = get_world_size()
         print("world_size: {}, local_rank: {}".format(self.world_size, self.local_rank))
 
+    GROUP_ROWS = 256          # index(): fixed-size loader batches encoded per engine pass (4 batches of 64)
+
     def _encode_batch(self, inputs, batch_ids):
         return self.model.encode(**inputs)
 
@@ -405,15 +407,36 @@ class SparseIndexer:
         # posting by posting in Python, inverted_index.py:74-76).  12 B per posting: 13.5 GB for MS MARCO at L0_d = 128.
         dev_rows, dev_cols, dev_vals = [], [], []
         n_batches = 0
-        for t, batch in enumerate(tqdm(collection_loader, disable=not is_first_worker())):
+        # The reference's loader yields fixed batches (64 passages: ~4 800 real tokens, a fraction of what the engine wants per
+        # pass): fixed-size batches are encoded a few at a time in ONE engine pass (encode_batches: rows bit-identical to
+        # batch-by-batch encode calls), then handled batch by batch exactly as before - statistics, postings and doc ids do not
+        # change.  Token-budget loaders and subclasses with their own _encode_batch (HybridIndexer) go batch by batch.
+        group_rows = (self.GROUP_ROWS if getattr(collection_loader, "batch_size", None) and hasattr(self.model, "encode_batches")
+                      and type(self)._encode_batch is SparseIndexer._encode_batch else 0)
+
+        def encoded_batches():
+            for group in (batch_groups(collection_loader, group_rows) if group_rows else ([b] for b in collection_loader)):
+                if len(group) > 1:
+                    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:255-256
+                        reps_g = encode_group(self.model, group, self.device)
+                    r0 = 0
+                    for b in group:
+                        n = len(b["ids"])
+                        yield b, reps_g[r0:r0 + n]
+                        r0 += n
+                else:
+                    yield group[0], None
+
+        for t, (batch, batch_documents) in enumerate(tqdm(encoded_batches(), disable=not is_first_worker())):
             n_batches += 1
-            inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
             batch_ids = to_list(batch["ids"]) if isinstance(batch["ids"], torch.Tensor) else batch["ids"]
             assert isinstance(batch_ids, list)
             if id_dict:
                 batch_ids = [id_dict[x] for x in batch_ids]
-            with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:255-256
-                batch_documents = self._encode_batch(inputs, batch_ids)      # [bz, vocab_size] fp32 on device
+            if batch_documents is None:
+                inputs = {k: v.to(self.device) for k, v in batch.items() if k not in {"ids"}}
+                with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:255-256
+                    batch_documents = self._encode_batch(inputs, batch_ids)      # [bz, vocab_size] fp32 on device
             if self.compute_stats:
                 stats["L0_d"] += self.l0(batch_documents).item()
             row_ptr, col, data = sparse_reps_to_csr(batch_documents)
