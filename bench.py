@@ -422,7 +422,7 @@ def sparse_sweep_leg(args, device):
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / 2
                 st1 = idx.block_stats()
-                n_check = 64 if (L0_d, L0_q) in ((64, 16), (128, 32), (256, 64)) else 16
+                n_check = 64
                 if host is None:
                     host = (indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy())
                 hq = (q_indptr[:n_check + 1].cpu().numpy(), q_cols[:n_check * L0_q].cpu().numpy(), q_vals[:n_check * L0_q].cpu().numpy())
