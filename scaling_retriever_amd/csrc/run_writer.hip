@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <thread>
 #include <vector>
@@ -211,7 +212,30 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
             off[(size_t)t] = total;
             total += (int64_t)(s.size() - skip[(size_t)t]);
         }
-        {
+        // Large rounds go through a shared mapping of the file: buffered writes to one file serialise on its inode (the copy of a
+        // 200 MB run into the page cache was most of the call), page faults of a mapping do not.  The blocks are reserved first
+        // (posix_fallocate: a full disk is an error code here, not a SIGBUS in a thread); any failure falls back to pwrite.
+        const int64_t round_begin = off[0], round_bytes = total - off[0];
+        bool mapped = false;
+        if (round_bytes >= (8 << 20) && nt > 1 && posix_fallocate(fd, 0, (off_t)total) == 0) {
+            const int64_t page = (int64_t)sysconf(_SC_PAGESIZE);
+            const int64_t map_begin = round_begin / page * page;
+            void* m = mmap(nullptr, (size_t)(total - map_begin), PROT_WRITE, MAP_SHARED, fd, (off_t)map_begin);
+            if (m != MAP_FAILED) {
+                char* base = static_cast<char*>(m) - map_begin;          // base + file offset
+                auto copy = [&](int t) {
+                    const std::string& s = bufs[(size_t)t];
+                    if (s.size() > skip[(size_t)t]) memcpy(base + off[(size_t)t], s.data() + skip[(size_t)t], s.size() - skip[(size_t)t]);
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; ++t)
+                    if (!bufs[(size_t)t].empty()) th.emplace_back(copy, t);
+                copy(0);
+                for (auto& x : th) x.join();
+                mapped = munmap(m, (size_t)(total - map_begin)) == 0;
+            }
+        }
+        if (!mapped) {
             std::vector<std::thread> th;
             for (int t = 1; t < nt; ++t)
                 if (!bufs[(size_t)t].empty()) th.emplace_back(put, t);

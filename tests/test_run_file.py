@@ -2,6 +2,7 @@
 reference's per-hit loops + json.dump write (/root/reference/eval_dense.py:225-241; scaling_retriever/indexer.py:431-432,536-537),
 and RunResult behaves like the nested dict those loops build."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -70,6 +71,25 @@ def test_several_rounds_of_slabs_and_empty_leading_queries(tmp_path, threads):
     # an existing longer file is replaced, not overwritten in place
     p.write_text("x" * (2 * len(want)))
     write_run_json(p, qids, scores, positions, docs, n_threads=threads)
+    assert p.read_text() == want
+
+
+def test_large_result_written_through_the_mapped_path(tmp_path):
+    """Rounds of 8 MB and more are copied into a shared mapping of the file by the formatting threads (buffered writes to one file
+    serialise on its inode): same bytes, and the file ends where the text ends."""
+    rng = np.random.default_rng(5)
+    nq, k, N = 2500, 200, 200_000
+    scores = rng.standard_normal((nq, k)).astype(np.float32)
+    positions = rng.integers(0, N, size=(nq, k)).astype(np.int64)
+    for r in range(nq):                                        # the reference's dict keeps the LAST score of a repeated docid
+        positions[r] = rng.permutation(N)[:k]
+    positions[17, 150:] = -1
+    qids = [str(3 * i) for i in range(nq)]
+    docs = np.arange(N).astype("U7")
+    p = tmp_path / "big.json"
+    n = write_run_json(p, qids, scores, positions, docs, n_threads=8)
+    want = json.dumps(_reference_dict(qids, scores, positions, docs))
+    assert n == len(want) >= (8 << 20) and os.path.getsize(p) == n
     assert p.read_text() == want
 
 
