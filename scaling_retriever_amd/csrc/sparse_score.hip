@@ -403,7 +403,12 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
 #pragma unroll
         for (int i = 0; i < SPB_DV; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool in_regs = true;
-    const float* dcol = b.dense + doc0 + 4 * tid;
+    // dense columns are addressed as (wave-uniform column base in SGPRs) + (32-bit byte offset of the thread, the same for every
+    // column): no per-column 64-bit vector address arithmetic
+    const char* const dense_tile = reinterpret_cast<const char*>(b.dense + doc0);
+    unsigned dvoff[SPB_DV];
+#pragma unroll
+    for (int i = 0; i < SPB_DV; ++i) dvoff[i] = 16u * (unsigned)tid + 16u * SPB_THREADS * (unsigned)i;
     auto to_lds = [&]() {
 #pragma unroll
         for (int q = 0; q < SPB_Q; ++q)
@@ -433,6 +438,9 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
         float my_w = seg_w[0];
 #pragma unroll
         for (int q = 1; q < SPB_Q; ++q) my_w = wave == q ? seg_w[q] : my_w;
+        int wmask = 0;
+#pragma unroll
+        for (int q = 0; q < SPB_Q; ++q) wmask |= seg_w[q] != 0.f ? (1 << q) : 0;
         const uint64_t dmask = __ballot(slot >= 0 && seg_n > 0);
         const uint64_t bmask = __ballot(slot < 0 && seg_n > SPB_LIGHT);                    // scatter runs walked in groups
         const uint64_t lmask = __ballot(slot < 0 && seg_n > 0 && seg_n <= SPB_LIGHT);      // one wave step per run
@@ -472,15 +480,16 @@ __global__ __launch_bounds__(SPB_THREADS, SPB_WAVES_PER_SIMD) void sparse_block_
             if (dense_run) {
                 if (!in_regs) { to_regs(); in_regs = true; }
                 auto dload = [&](int j, f32x4 (&v)[SPB_DV]) {
-                    const float* p = dcol + (int64_t)__builtin_amdgcn_readlane(slot, j) * b.dense_stride;
+                    const char* p = dense_tile + (int64_t)__builtin_amdgcn_readlane(slot, j) * b.dense_stride * 4;
 #pragma unroll
-                    for (int i = 0; i < SPB_DV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * SPB_THREADS * i);
+                    for (int i = 0; i < SPB_DV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + dvoff[i]);
                 };
                 auto dapply = [&](int j, const f32x4 (&v)[SPB_DV]) {
+                    const int qm = __builtin_amdgcn_readlane(wmask, j);          // which of the block's queries carry the term
 #pragma unroll
                     for (int q = 0; q < SPB_Q; ++q) {
-                        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(seg_w[q]), j));
-                        if (w != 0.f) {              // wave-uniform
+                        if (qm & (1 << q)) {         // wave-uniform: one scalar bit test per (column, query)
+                            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(seg_w[q]), j));
 #pragma unroll
                             for (int i = 0; i < SPB_DV; ++i) {
                                 const f32x4 prod = v[i] * w;
