@@ -164,6 +164,37 @@ int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_launches, doub
 int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, int64_t* n_block_calls,
                                 int64_t* n_fallback_calls);
 
+/* The certified two-stage scorer (csrc/sparse_cert.hip).  For an index without negative values sr_sparse_index_create also
+ * builds: fp16 MFMA tiles of the heaviest terms, 4-byte packed postings, a per-term table of doc-tile boundaries and a
+ * doc-major forward index.  sr_sparse_search then scores every (query, doc) approximately with a proven error bound (matrix
+ * pipe for the heavy terms, 16-bit fixed-point LDS atomics for the others), keeps the k + 1024 best keys, certifies that the
+ * true top-k lies among them, re-scores those candidates with the reference's exact fp32 chain
+ * (scaling_retriever/indexer.py:324-340) from the forward index and returns their exact top-k: the same bits as the exact
+ * kernels.  Queries it cannot certify (a negative or unordered query, more than 64 rare terms, a band of undecided keys
+ * wider than 1024, fewer than k docs with a non-zero key) are re-done by the exact kernels inside the same call.
+ * out8: [0] 1 if this index has the scorer, [1] heavy terms on the matrix pipe, [2] searches it ran, [3] queries it was
+ * given, [4] queries re-done by the exact kernels, [5] doc tiles of 1024, [6..7] 0.                                        */
+int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8);
+/* Test hook for the error bound: enable = 1 / 0 switches the recording of the stage-1 keys of every (query, doc) pair on /
+ * off; enable = 2 copies the last search's keys to h_keys uint16 [nq_pad][n_tiles * 1024] (nq_pad = nq rounded up to 32)
+ * and the per-query constants to h_consts fp32 [nq_pad][4] = {c_q (0: query outside the fast path), s_q, rare terms, query
+ * terms}; *vscale, *T = the index-side constants.  With true_fix = 65535 * s_q * (real-arithmetic score) every key obeys
+ * true_fix (1 - dd) - 1.2 <= key <= true_fix (1 + dd) + 1.2 + 1.01 * rare terms.                                          */
+int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_keys, int64_t keys_capacity,
+                               float* h_consts, int64_t nq_pad, float* vscale, int32_t* T);
+
+/* On-device index build: doc-major postings -> CSR by term.  Replaces the per-posting Python append of
+ * IndexDictOfArray.add_batch_document (scaling_retriever/utils/inverted_index.py:67-76) and the per-term concatenation of
+ * merge_indexes (:108-170) behind SparseIndexer.index (scaling_retriever/indexer.py:239-308).
+ * d_rows int32 [nnz] = global doc row of every posting, d_cols int32 [nnz] = term in [0, n_terms), d_vals fp32 [nnz], in
+ * insertion order.  A stable radix sort by term (this library's kernels) keeps the insertion order inside a term - the
+ * reference's posting order; sort_docs = 1 additionally orders every posting list by ascending doc row (needs n_docs >
+ * every row), which is what sr_sparse_index_create requires of a merged multi-rank index.  Outputs: d_indptr int64
+ * [n_terms + 1], d_out_rows int32 [nnz], d_out_vals fp32 [nnz] (must not alias the inputs).  Synchronises the stream.       */
+int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols, const float* d_vals, int64_t nnz,
+                        int64_t n_terms, int64_t n_docs, int sort_docs, int64_t* d_indptr,
+                        int32_t* d_out_rows, float* d_out_vals, sr_stream stream);
+
 /* ------------------------------------------------------------ top-k merge ---
  * The one exchange step of doc-sharded retrieval: merge `n_lists` per-shard
  * top-k lists (after the RCCL gather) into the global top-k per query.

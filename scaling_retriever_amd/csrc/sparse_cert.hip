@@ -1,0 +1,913 @@
+// Certified two-stage inverted-index scoring (gfx950): the sparse twin of the dense filter (dense_split / dense_filter).
+//
+// Reference semantics: SparseRetrieval.numba_score_float + select_topk (scaling_retriever/indexer.py:315-344): per query a
+// term-serial fp32 chain  score[doc] += q_t * v  (unfused, ascending query-term order), docs with score > threshold, k best.
+// The exact kernels (sparse_score.hip) evaluate that chain for EVERY (query, doc, matching term): 1.1e12 lane operations on the
+// columns of the heavy terms per MSMARCO-Dev pass.  For a non-negative index and non-negative queries (always the case behind
+// the encoder's relu + log1p head, llm_encoder.py:186-196) this file does the bulk of that work on the matrix pipe instead and
+// keeps the results identical:
+//
+//  stage 1, cert_score_kernel (approximate, with a proven error bound).  Workgroup = (32 queries, persistent over doc tiles of
+//    1 024 docs), 16 waves in two roles:
+//      matrix waves (8): scores of the T heaviest terms as an fp16 MFMA product (v_mfma_f32_32x32x16_f16, fp32 accumulate) of
+//        the tile's [1 024 docs x T] operand - stored in HBM in MFMA fragment order, read once per 32 queries with coalesced
+//        16-byte loads, no LDS staging - and the query block's [T x 32] operand held in registers;
+//      scatter waves (8): the postings of the other ("rare") query terms inside the tile - lane j = rare term j of the query,
+//        runs found through a per-term table of tile boundaries, postings packed to 4 bytes (doc in tile | fp16 value) - are
+//        added as 16-bit FIXED-POINT numbers into a [32 queries x 1 024 docs] tile of LDS with integer atomics (ds_add_u32 on
+//        one half of a word: exact, order-independent, deterministic);
+//    then the matrix waves convert their accumulators to the same fixed point (v_cvt_pknorm_u16_f32), add the LDS tile and compare
+//    with the query's running threshold; survivors go to the fused top-k machinery (topk.hip) under the 16-bit key.
+//    Per query the scale maps [0, sum_t q_t * max_t(v)] onto [0, 0.98 * 65 535], so a key cannot overflow its half word.
+//  stage 2, certificate + exact re-score.  With true_fix = 65 535 * s_q * (real-arithmetic score) the key obeys
+//        true_fix (1 - dd) - 1.2  <=  key  <=  true_fix (1 + dd) + 1.2 + 1.01 n_rare          (dd: fp16 rounding of both operands)
+//    and the reference's fp32 chain is within (n_terms + 2) 2^-24 of the real-arithmetic score (all terms >= 0).  The k-th largest
+//    key therefore gives a LOWER bound on the k-th largest reference score, and every doc whose UPPER bound stays below it is
+//    out.  The top (k + 1 024) keys are kept; if the band of keys that cannot be excluded lies inside them the query is
+//    certified, its candidates (k + a few hundred) are re-scored by cert_rescore_kernel with the reference's exact chain from
+//    a doc-major forward index, and the exact top-k of those is the result - bit for bit what the exact kernels return.
+//    Anything else - a query outside the preconditions (negative / unordered / too many terms), a band that does not fit,
+//    fewer than k docs with a non-zero key, an overflowing candidate buffer - is flagged and served by the exact kernels.
+#include "sparse_index.h"
+#include <algorithm>
+#include <math.h>
+#include <vector>
+
+#define SC_DT 1024                    // docs per tile
+#define SC_QB 32                      // queries per workgroup (one MFMA N block)
+#define SC_MB (SC_DT / 32)            // 32-doc M blocks per tile
+#define SC_PITCH_W (SC_DT / 2 + 2)    // 32-bit words per query row of the LDS tile (two 16-bit slots per word; + 2: bank spread)
+#define SC_MAXR 64                    // rare terms per query (one lane each)
+#define SC_LIGHT 8                    // runs shorter than this are walked lane-per-term, longer ones wave-wide
+#define SC_BAND 1024                  // keys kept beyond k
+#define SC_CAND_CAP 16384             // candidate slots per query and launch
+#define SC_MAXQT 256                  // terms of a fast-path query
+#define SC_TMAX 256                   // dense terms (MFMA K), at most
+#define SC_FWD_MAX 1024               // postings per doc the forward-index sort handles
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct SparseCert {
+    int T = 0, KS = 0;                // dense terms (multiple of 16) and MFMA k-steps
+    int n_tiles = 0;
+    float vscale = 1.f;               // power of two applied to the values before the fp16 rounding
+    int32_t* dslot = nullptr;         // [V] dense slot of a term, -1 = rare
+    float* vmax = nullptr;            // [V] largest value of a posting list
+    _Float16* d16 = nullptr;          // [n_tiles][KS][SC_MB][64][8]: MFMA A fragments (row = doc, k = dense slot)
+    uint32_t* P = nullptr;            // [nnz] packed postings: doc % SC_DT | fp16(v * vscale) << 16
+    uint32_t* S = nullptr;            // [V][n_tiles + 1]: first posting (absolute index) of term t with doc >= tile * SC_DT
+    int64_t* fwd_indptr = nullptr;    // doc-major forward index, terms ascending inside a doc
+    int32_t* fwd_term = nullptr;
+    float* fwd_val = nullptr;
+    // per-call plan (grown on demand)
+    int64_t nq_cap = 0;
+    _Float16* bfrag = nullptr;        // [nq_pad / 32][KS][64][8]: MFMA B fragments (k = dense slot, col = query)
+    int32_t* rare_term = nullptr;     // [nq_pad][SC_MAXR], -1 = none
+    float* rare_w = nullptr;          // [nq_pad][SC_MAXR]: q_t * s_q * 65535 / vscale
+    float* cq = nullptr;              // [nq_pad]: MFMA sum -> [0, 1]
+    float* sq = nullptr;              // [nq_pad]: score -> [0, 0.98]
+    int32_t* n_rare = nullptr;        // [nq_pad]
+    int32_t* n_qt = nullptr;          // [nq_pad]
+    uint8_t* elig = nullptr;          // [nq_pad]
+    uint8_t* overflow = nullptr;      // [nq_pad]
+    int32_t* m_count = nullptr;       // [nq_pad] candidates to re-score
+    int* d_n_uncert = nullptr;
+    int64_t ap_cap = 0;               // approximate top lists [nq][k_eff]
+    float* ap_scores = nullptr;
+    int64_t* ap_ids = nullptr;
+    int32_t* ap_counts = nullptr;
+    TopkWS ws;
+    // statistics (sr_sparse_index_cert_stats)
+    int64_t n_calls = 0, n_queries = 0, n_uncert = 0, n_rescored = 0;
+    uint16_t* dump = nullptr;         // debug: [nq_pad][n_tiles * SC_DT] keys of the last search (sr_sparse_index_cert_debug)
+    int64_t dump_nq = 0;
+    bool want_dump = false;
+};
+
+// ------------------------------------------------------------------------------------------------------- build ---
+// per term: largest value; flags |= 1 for a negative or non-finite value
+__global__ __launch_bounds__(256) void cert_term_stats_kernel(const int64_t* __restrict__ indptr, const float* __restrict__ vals,
+                                                              float* __restrict__ vmax, int* __restrict__ flags) {
+    __shared__ float red[4];
+    const int64_t t = blockIdx.x;
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    float mx = 0.f;
+    int bad = 0;
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) {
+        const float v = vals[p];
+        if (!(v >= 0.f) || !(v < 3.0e38f)) bad = 1;
+        mx = fmaxf(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    if (bad) atomicOr(flags, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) vmax[t] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ void cert_fill_d16_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
+                                     const float* __restrict__ vals, const int32_t* __restrict__ slot_term, int KS, float vscale,
+                                     _Float16* __restrict__ d16) {
+    const int sl = blockIdx.y;
+    const int64_t t = slot_term[sl];
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    const int s = sl >> 4, kk = sl & 15;
+    for (int64_t p = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t doc = doc_ids[p];
+        const int64_t tile = doc / SC_DT;
+        const int dl = (int)(doc - tile * SC_DT);
+        const int mb = dl >> 5, r = dl & 31;
+        const int lane = r + 32 * (kk >> 3);
+        d16[((((tile * KS + s) * SC_MB + mb) * 64 + lane) << 3) + (kk & 7)] = (_Float16)(vals[p] * vscale);
+    }
+}
+
+__global__ void cert_pack_postings_kernel(const int32_t* __restrict__ doc_ids, const float* __restrict__ vals, int64_t nnz, float vscale,
+                                          uint32_t* __restrict__ P) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const _Float16 h = (_Float16)(vals[p] * vscale);
+    P[p] = ((uint32_t)doc_ids[p] & (SC_DT - 1)) | ((uint32_t)__builtin_bit_cast(unsigned short, h) << 16);
+}
+
+// S[t][i] = indptr[t] + #{postings of t with doc < i * SC_DT}, i = 0 .. n_tiles.  The thread of posting p (doc d, predecessor d')
+// fills the tiles in (tile(d'), tile(d)]; the thread "behind the last posting" fills the rest.
+__global__ __launch_bounds__(256) void cert_s_table_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids, int n_tiles,
+                                                           uint32_t* __restrict__ S) {
+    const int64_t t = blockIdx.x;
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    uint32_t* row = S + t * (int64_t)(n_tiles + 1);
+    for (int64_t p = b + threadIdx.x; p <= e; p += 256) {
+        const int prev = p > b ? (int)(doc_ids[p - 1] / SC_DT) : -1;
+        const int cur = p < e ? (int)(doc_ids[p] / SC_DT) : n_tiles;
+        for (int i = prev + 1; i <= cur; ++i) row[i] = (uint32_t)p;
+    }
+}
+
+__global__ void cert_fwd_count_kernel(const int32_t* __restrict__ doc_ids, int64_t nnz, int32_t* __restrict__ cnt) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) atomicAdd(&cnt[doc_ids[p]], 1);
+}
+__global__ void cert_i32_to_i64_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void cert_fwd_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
+                                                            const float* __restrict__ vals, const int64_t* __restrict__ fwd_indptr,
+                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ fwd_term,
+                                                            float* __restrict__ fwd_val) {
+    const int64_t t = blockIdx.y;
+    const int64_t b = indptr[t], e = indptr[t + 1];
+    for (int64_t p = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = doc_ids[p];
+        const int64_t pos = fwd_indptr[d] + atomicAdd(&cursor[d], 1);
+        fwd_term[pos] = (int32_t)t;
+        fwd_val[pos] = vals[p];
+    }
+}
+// one wave per doc: bitonic sort of its (term, value) pairs by term in LDS; flags |= 2 for a doc with more than SC_FWD_MAX postings
+__global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __restrict__ fwd_indptr, int64_t n_docs, int32_t* __restrict__ fwd_term,
+                                                            float* __restrict__ fwd_val, int* __restrict__ flags) {
+    __shared__ uint64_t keys_all[4][SC_FWD_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t d = (int64_t)blockIdx.x * 4 + wave;
+    if (d >= n_docs) return;
+    const int64_t b = fwd_indptr[d];
+    const int n = (int)(fwd_indptr[d + 1] - b);
+    if (n <= 1) return;
+    if (n > SC_FWD_MAX) {
+        if (lane == 0) atomicOr(flags, 2);
+        return;
+    }
+    uint64_t* keys = keys_all[wave];
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = lane; i < P; i += 64)
+        keys[i] = i < n ? (((uint64_t)(uint32_t)fwd_term[b + i] << 32) | (uint64_t)__float_as_uint(fwd_val[b + i])) : ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int size = 2; size <= P; size <<= 1)
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = (i & size) == 0;
+                    const uint64_t x = keys[i], y = keys[ixj];
+                    if (up ? (x > y) : (x < y)) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    for (int i = lane; i < n; i += 64) {
+        fwd_term[b + i] = (int32_t)(keys[i] >> 32);
+        fwd_val[b + i] = __uint_as_float((uint32_t)(keys[i] & 0xffffffffu));
+    }
+}
+
+void sparse_cert_destroy(SparseCert* c) {
+    if (!c) return;
+    void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
+                    c->cq, c->sq, c->n_rare, c->n_qt, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->ws.release();
+    delete c;
+}
+
+int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
+    // dev switch SR_SPARSE_CERT: 0 = never, 1 = whenever the index qualifies structurally (tests on small indexes);
+    // default: collections of at least 64 tiles
+    int mode = -1;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT")) mode = atoi(e);
+    if (mode == 0) return SR_OK;
+    if (mode < 0 && idx->n_docs < 64 * SC_DT) return SR_OK;
+    std::vector<int64_t> h_indptr((size_t)idx->n_terms + 1);
+    SR_CHECK_HIP(hipMemcpyAsync(h_indptr.data(), idx->indptr, sizeof(int64_t) * h_indptr.size(), hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    const int64_t nnz = h_indptr.back() - h_indptr.front();
+    if (nnz <= 0 || nnz >= 0xffffffffll || h_indptr.front() != 0) return SR_OK;
+    const int64_t V = idx->n_terms, N = idx->n_docs;
+    SparseCert* c = new SparseCert();
+    c->n_tiles = (int)ceil_div64(N, SC_DT);
+    int* d_flags = nullptr;
+    int32_t *d_terms = nullptr, *d_cnt = nullptr;
+    int64_t* d_cnt64 = nullptr;
+    bool ok = false;        // false: the index does not qualify (or no memory): not an error
+    int rc = SR_OK;
+    do {
+        if (hipMalloc((void**)&c->vmax, sizeof(float) * (size_t)V) != hipSuccess || hipMalloc((void**)&d_flags, sizeof(int)) != hipSuccess) break;
+        if (hipMemsetAsync(d_flags, 0, sizeof(int), s) != hipSuccess) { rc = SR_ERR_HIP; break; }
+        hipLaunchKernelGGL(cert_term_stats_kernel, dim3((unsigned)V), dim3(256), 0, s, idx->indptr, idx->vals, c->vmax, d_flags);
+        std::vector<float> h_vmax((size_t)V);
+        int h_flags = 0;
+        if (hipMemcpyAsync(h_vmax.data(), c->vmax, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = SR_ERR_HIP;
+            break;
+        }
+        if (h_flags & 1) break;                   // a negative / non-finite value: exact kernels only
+        float vmax_all = 0.f;
+        for (float v : h_vmax) vmax_all = std::max(vmax_all, v);
+        if (!(vmax_all > 0.f)) break;
+        {   // largest value lands in [2^13, 2^14): far from fp16's subnormals and from its maximum
+            int ex;
+            (void)frexpf(vmax_all, &ex);          // vmax_all = m * 2^ex, m in [0.5, 1)
+            c->vscale = ldexpf(1.0f, 14 - ex);
+        }
+        // dense terms: the longest lists, those present in at least 1 / 1024 of the docs, at most T_max, a multiple of 16
+        int t_max = 128;
+        if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_T")) t_max = atoi(e);
+        t_max = std::max(16, std::min(SC_TMAX, t_max / 16 * 16));
+        std::vector<std::pair<int64_t, int32_t>> heavy;
+        for (int64_t t = 0; t < V; ++t) {
+            const int64_t len = h_indptr[(size_t)t + 1] - h_indptr[(size_t)t];
+            if (len > 0 && len * 1024 >= N) heavy.emplace_back(-len, (int32_t)t);
+        }
+        std::sort(heavy.begin(), heavy.end());
+        int n_heavy = (int)std::min<size_t>(heavy.size(), (size_t)t_max);
+        c->T = std::max(16, (n_heavy + 15) / 16 * 16);
+        c->KS = c->T / 16;
+        if (c->KS != 1 && c->KS != 2 && c->KS != 4 && c->KS != 8 && c->KS != 16) {     // instantiated k-step counts
+            c->KS = c->KS < 4 ? 4 : (c->KS < 8 ? 8 : 16);
+            c->T = c->KS * 16;
+        }
+        std::vector<int32_t> h_slot((size_t)V, -1), h_terms((size_t)std::max(1, n_heavy));
+        for (int i = 0; i < n_heavy; ++i) {
+            h_slot[(size_t)heavy[(size_t)i].second] = i;
+            h_terms[(size_t)i] = heavy[(size_t)i].second;
+        }
+        const size_t d16_halves = (size_t)c->n_tiles * (size_t)c->T * SC_DT;
+        const size_t s_words = (size_t)V * (size_t)(c->n_tiles + 1);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { rc = SR_ERR_HIP; break; }
+        const size_t need = d16_halves * 2 + (size_t)nnz * 12 + s_words * 4 + (size_t)N * 16 + (64u << 20);
+        if (need > free_b / 2) break;             // side structures may take at most half of what is free
+        if (hipMalloc((void**)&c->dslot, sizeof(int32_t) * (size_t)V) != hipSuccess || hipMalloc((void**)&c->d16, d16_halves * 2) != hipSuccess ||
+            hipMalloc((void**)&c->P, sizeof(uint32_t) * (size_t)nnz) != hipSuccess || hipMalloc((void**)&c->S, s_words * 4) != hipSuccess ||
+            hipMalloc((void**)&c->fwd_indptr, sizeof(int64_t) * (size_t)(N + 1)) != hipSuccess ||
+            hipMalloc((void**)&c->fwd_term, sizeof(int32_t) * (size_t)nnz) != hipSuccess ||
+            hipMalloc((void**)&c->fwd_val, sizeof(float) * (size_t)nnz) != hipSuccess ||
+            hipMalloc((void**)&d_terms, sizeof(int32_t) * h_terms.size()) != hipSuccess ||
+            hipMalloc((void**)&d_cnt, sizeof(int32_t) * (size_t)N) != hipSuccess || hipMalloc((void**)&d_cnt64, sizeof(int64_t) * (size_t)N) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        rc = SR_ERR_HIP;
+        if (hipMemcpyAsync(c->dslot, h_slot.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemcpyAsync(d_terms, h_terms.data(), sizeof(int32_t) * h_terms.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemsetAsync(c->d16, 0, d16_halves * 2, s) != hipSuccess) break;
+        if (hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)N, s) != hipSuccess) break;
+        if (n_heavy > 0)
+            hipLaunchKernelGGL(cert_fill_d16_kernel, dim3(256, (unsigned)n_heavy), dim3(256), 0, s, idx->indptr, idx->doc_ids, idx->vals, d_terms,
+                               c->KS, c->vscale, c->d16);
+        hipLaunchKernelGGL(cert_pack_postings_kernel, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, s, idx->doc_ids, idx->vals, nnz,
+                           c->vscale, c->P);
+        hipLaunchKernelGGL(cert_s_table_kernel, dim3((unsigned)V), dim3(256), 0, s, idx->indptr, idx->doc_ids, c->n_tiles, c->S);
+        hipLaunchKernelGGL(cert_fwd_count_kernel, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, s, idx->doc_ids, nnz, d_cnt);
+        hipLaunchKernelGGL(cert_i32_to_i64_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, s, d_cnt, N, d_cnt64);
+        if (hipGetLastError() != hipSuccess) break;
+        if (sr_device_exclusive_scan_i64(d_cnt64, c->fwd_indptr, N, s) != SR_OK) break;
+        if (hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)N, s) != hipSuccess) break;
+        hipLaunchKernelGGL(cert_fwd_fill_kernel, dim3(64, (unsigned)V), dim3(256), 0, s, idx->indptr, idx->doc_ids, idx->vals, c->fwd_indptr, d_cnt,
+                           c->fwd_term, c->fwd_val);
+        hipLaunchKernelGGL(cert_fwd_sort_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, s, c->fwd_indptr, N, c->fwd_term, c->fwd_val, d_flags);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+        rc = SR_OK;
+        if (h_flags & 2) break;                   // a doc with more postings than the forward sort handles
+        ok = true;
+    } while (0);
+    if (d_flags) (void)hipFree(d_flags);
+    if (d_terms) (void)hipFree(d_terms);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_cnt64) (void)hipFree(d_cnt64);
+    if (rc != SR_OK) {
+        sr_set_error("sr_sparse_index_create: building the certified scorer's structures failed: %s", hipGetErrorString(hipGetLastError()));
+        sparse_cert_destroy(c);
+        return rc;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        sparse_cert_destroy(c);
+        return SR_OK;
+    }
+    idx->cert = c;
+    return SR_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------- plan ---
+// One wave per query: preconditions, scale, MFMA B fragment entries of its dense terms, rare term list.
+struct CertPlanArgs {
+    const int64_t* q_indptr;
+    const int32_t* q_cols;
+    const float* q_vals;
+    int64_t nq, n_terms;
+    const int64_t* indptr;
+    const int32_t* dslot;
+    const float* vmax;
+    int KS;
+    float vscale;
+    _Float16* bfrag;
+    int32_t* rare_term;
+    float* rare_w;
+    float* cq;
+    float* sq;
+    int32_t* n_rare;
+    int32_t* n_qt;
+    uint8_t* elig;
+    uint8_t* overflow;
+};
+
+__global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nq_pad = (a.nq + SC_QB - 1) / SC_QB * SC_QB;
+    if (q >= nq_pad) return;
+    // defaults: a query outside the fast path contributes nothing to stage 1
+    a.rare_term[q * SC_MAXR + lane] = -1;
+    a.rare_w[q * SC_MAXR + lane] = 0.f;
+    if (lane == 0) { a.cq[q] = 0.f; a.sq[q] = 0.f; a.n_rare[q] = 0; a.n_qt[q] = 0; a.elig[q] = 0; a.overflow[q] = 0; }
+    if (q >= a.nq) return;
+    const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
+    const int n = (int)(te - tb);
+    if (n <= 0 || n > SC_MAXQT) return;
+    bool ok = true;
+    int term[SC_MAXQT / 64], slot[SC_MAXQT / 64];
+    float val[SC_MAXQT / 64], vmx[SC_MAXQT / 64];
+    float tot = 0.f, dmax = 0.f, dmin = 3.0e38f;
+    int nr = 0, nd = 0;
+#pragma unroll
+    for (int c = 0; c < SC_MAXQT / 64; ++c) {
+        const int i = c * 64 + lane;
+        term[c] = -1; slot[c] = -1; val[c] = 0.f; vmx[c] = 0.f;
+        if (i < n) {
+            const int t = a.q_cols[tb + i];
+            const float v = a.q_vals[tb + i];
+            if (i > 0 && a.q_cols[tb + i - 1] >= t) ok = false;          // the union order must be the query's own (strictly ascending)
+            if (!(v >= 0.f) || !(v < 3.0e38f)) ok = false;
+            if (t >= 0 && (int64_t)t < a.n_terms && v > 0.f && a.indptr[t + 1] > a.indptr[t]) {
+                term[c] = t; val[c] = v; vmx[c] = a.vmax[t]; slot[c] = a.dslot[t];
+                tot += v * vmx[c];
+                if (slot[c] >= 0) { dmax = fmaxf(dmax, v); dmin = fminf(dmin, v); ++nd; } else ++nr;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        tot += __shfl_xor(tot, off);
+        dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        dmin = fminf(dmin, __shfl_xor(dmin, off));
+        nr += __shfl_xor(nr, off);
+        nd += __shfl_xor(nd, off);
+    }
+    ok = __ballot(!ok) == 0;
+    if (!ok || nr > SC_MAXR || !(tot > 0.f) || !(tot < 1.0e30f)) return;
+    const float sq = 0.98f / (tot * 1.0001f);               // every real-arithmetic score * sq <= 0.98
+    // dense operand: q_t * sq * 2^e with the largest one in [2^13, 2^14); all of them normal fp16 numbers
+    float two_e = 1.f;
+    if (nd > 0) {
+        int ex;
+        (void)frexpf(dmax * sq, &ex);
+        two_e = ldexpf(1.0f, 14 - ex);
+        if (!(dmin * sq * two_e >= 6.2e-5f)) return;       // a term 2^27 below the largest: exact kernels
+    }
+    const float cqv = 1.0f / (two_e * a.vscale);
+    // flushed / subnormal fp16 values of the doc side cost at most 65535 * cq * nd * 2^14 * 2^-14 key units: must stay below 0.1
+    if (!(65535.0f * cqv * (float)nd <= 0.1f)) return;
+    const int64_t qb = q / SC_QB;
+    const int qn = (int)(q % SC_QB);
+    int rbase = 0;
+#pragma unroll
+    for (int c = 0; c < SC_MAXQT / 64; ++c) {
+        const bool is_r = term[c] >= 0 && slot[c] < 0;
+        const uint64_t m = __ballot(is_r);
+        if (term[c] >= 0 && slot[c] >= 0) {
+            const int s = slot[c] >> 4, kk = slot[c] & 15;
+            a.bfrag[(((qb * a.KS + s) * 64 + qn + 32 * (kk >> 3)) << 3) + (kk & 7)] = (_Float16)(val[c] * sq * two_e);
+        }
+        if (is_r) {
+            const int j = rbase + __popcll(m & ((1ull << lane) - 1ull));
+            a.rare_term[q * SC_MAXR + j] = term[c];
+            a.rare_w[q * SC_MAXR + j] = val[c] * sq * 65535.0f / a.vscale;
+        }
+        rbase += __popcll(m);
+    }
+    if (lane == 0) { a.cq[q] = cqv; a.sq[q] = sq; a.n_rare[q] = nr; a.n_qt[q] = n; a.elig[q] = 1; }
+}
+
+// ------------------------------------------------------------------------------------------------- score kernel ---
+struct CertArgs {
+    const f16x8* d16;
+    const uint32_t* P;
+    const uint32_t* S;
+    int s_stride;            // n_tiles + 1
+    const f16x8* bfrag;
+    const int32_t* rare_term;
+    const float* rare_w;
+    const float* cq;
+    const float* tau;        // (k + band)-th best key so far, -inf until that many are held
+    int64_t nq;
+    uint64_t* cand_keys;
+    int* cand_count;
+    int64_t cand_cap;
+    uint8_t* overflow;
+    int tile_begin, n_tiles_launch, tiles_per_wg, n_qblocks;
+    uint16_t* dump;          // debug: [nq_pad][dump_stride] keys
+    int64_t dump_stride;
+};
+
+__device__ __forceinline__ void cert_add_posting(uint32_t* row, uint32_t p, float w) {
+    const uint32_t d = p & 0xffffu;
+    const float v = (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
+    const uint32_t c = (uint32_t)(v * w + 1.0f);                 // in (x, x + 1]: rounded up, never below the real contribution
+    atomicAdd(&row[d >> 1], c << ((d & 1u) * 16u));
+}
+
+template <int KS>
+__global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
+    extern __shared__ uint32_t slots[];                          // [SC_QB][SC_PITCH_W]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroups of one doc chunk share blockIdx.x % 8, i.e. one XCD under round-robin placement: the chunk's tiles, postings
+    // and table rows are pulled into ONE L2 (speed only, never correctness)
+    const int L = (int)blockIdx.x;
+    const int xcd = L & 7, r = L >> 3;
+    const int qb = r % a.n_qblocks, cg = r / a.n_qblocks;
+    const int chunk = cg * 8 + xcd;
+    const int n_chunks = (a.n_tiles_launch + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    if (chunk >= n_chunks) return;
+    const int tile0 = a.tile_begin + chunk * a.tiles_per_wg;
+    const int tile_end = a.tile_begin + a.n_tiles_launch;
+    const int tile1 = tile0 + a.tiles_per_wg < tile_end ? tile0 + a.tiles_per_wg : tile_end;
+    for (int i = tid; i < SC_QB * SC_PITCH_W; i += 1024) slots[i] = 0u;
+    // the query block's MFMA B fragments (k-step s: 64 lanes x 8 halves), read back per k-step: they would cost 4 KS VGPRs
+    f16x8* const bl = reinterpret_cast<f16x8*>(slots + SC_QB * SC_PITCH_W);
+    if (tid < KS * 64) bl[tid] = a.bfrag[(int64_t)qb * KS * 64 + tid];
+    __syncthreads();
+
+    if (wave < 8) {
+        // ---------------- matrix waves: M blocks 4 wave .. 4 wave + 3 of every tile ----------------
+        const int qn = lane & 31, h = lane >> 5;
+        const int64_t q = (int64_t)qb * SC_QB + qn;
+        const float cq = a.cq[q];
+        const float tq = q < a.nq ? a.tau[q] : INFINITY;
+        int cut = 1;                                             // keys of 0 are never candidates
+        if (tq > 1.f) cut = tq >= 65536.f ? 65536 : (int)ceilf(tq);
+        const uint32_t cutm1 = (uint32_t)(cut - 1);
+        const uint32_t cutm1x2 = cutm1 | (cutm1 << 16);
+        for (int tile = tile0; tile < tile1; ++tile) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+            const f16x8* A = a.d16 + ((int64_t)tile * KS * SC_MB + wave * 4) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                f16x8 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = A[((int64_t)s * SC_MB + j) * 64];
+                const f16x8 bq = bl[s * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], bq, acc[j], 0, 0, 0);
+            }
+            // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1}
+            uint32_t key[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    key[j][g] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(acc[j][2 * g] * cq, acc[j][2 * g + 1] * cq));
+            __syncthreads();                                     // A: the scatter waves' adds are in the LDS tile
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    const int dl = (wave * 4 + j) * 32 + 8 * G + 4 * h;         // 4 consecutive docs: one 8-byte read
+                    uint32_t* sp = slots + qn * SC_PITCH_W + (dl >> 1);
+                    const uint2 sv = *reinterpret_cast<const uint2*>(sp);
+                    *reinterpret_cast<uint2*>(sp) = make_uint2(0u, 0u);
+                    const u16x2 k0 = __builtin_bit_cast(u16x2, key[j][2 * G]) + __builtin_bit_cast(u16x2, sv.x);
+                    const u16x2 k1 = __builtin_bit_cast(u16x2, key[j][2 * G + 1]) + __builtin_bit_cast(u16x2, sv.y);
+                    key[j][2 * G] = __builtin_bit_cast(uint32_t, k0);
+                    key[j][2 * G + 1] = __builtin_bit_cast(uint32_t, k1);
+                    any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k0, __builtin_bit_cast(u16x2, cutm1x2)));
+                    any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k1, __builtin_bit_cast(u16x2, cutm1x2)));
+                }
+            if (a.dump) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int64_t doc = (int64_t)tile * SC_DT + (wave * 4 + j) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1);
+                        *reinterpret_cast<uint32_t*>(a.dump + q * a.dump_stride + doc) = key[j][g];
+                    }
+            }
+            if (any != 0) {                                      // rare once the threshold has risen: a few lanes per tile
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        cnt += ((key[j][g] & 0xffffu) > cutm1 ? 1 : 0) + ((key[j][g] >> 16) > cutm1 ? 1 : 0);
+                int pos = atomicAdd(&a.cand_count[q], cnt);
+                if ((int64_t)pos + cnt > a.cand_cap) a.overflow[q] = 1;
+                uint64_t* dst = a.cand_keys + q * a.cand_cap;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const uint32_t doc = (uint32_t)tile * SC_DT + (uint32_t)((wave * 4 + j) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1));
+                        const uint32_t lo = key[j][g] & 0xffffu, hi = key[j][g] >> 16;
+                        if (lo > cutm1) { if (pos < a.cand_cap) dst[pos] = sr_make_key((float)lo, doc); ++pos; }
+                        if (hi > cutm1) { if (pos < a.cand_cap) dst[pos] = sr_make_key((float)hi, doc + 1u); ++pos; }
+                    }
+            }
+            __syncthreads();                                     // B: the LDS tile is zero again
+        }
+    } else {
+        // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
+        const int sw = wave - 8;
+        int32_t term[4];
+        float w[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const int64_t q = (int64_t)qb * SC_QB + sw * 4 + qi;
+            term[qi] = a.rare_term[q * SC_MAXR + lane];
+            w[qi] = a.rare_w[q * SC_MAXR + lane];
+        }
+        for (int tile = tile0; tile < tile1; ++tile) {
+            uint32_t start[4];
+            int len[4];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                u32x2_u se = {0u, 0u};
+                if (term[qi] >= 0) se = *reinterpret_cast<const u32x2_u*>(a.S + (int64_t)term[qi] * a.s_stride + tile);
+                start[qi] = se.x;
+                len[qi] = (int)(se.y - se.x);
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                uint32_t* row = slots + (sw * 4 + qi) * SC_PITCH_W;
+                const bool light = len[qi] > 0 && len[qi] < SC_LIGHT;
+                // short runs: lane j walks run j
+                uint32_t pv[SC_LIGHT - 1];
+#pragma unroll
+                for (int rr = 0; rr < SC_LIGHT - 1; ++rr) pv[rr] = (light && len[qi] > rr) ? a.P[start[qi] + rr] : 0u;
+#pragma unroll
+                for (int rr = 0; rr < SC_LIGHT - 1; ++rr)
+                    if (light && len[qi] > rr) cert_add_posting(row, pv[rr], w[qi]);
+                // longer runs: the wave walks one run, 64 postings per step
+                uint64_t mm = __ballot(len[qi] >= SC_LIGHT);
+                while (mm) {
+                    const int j = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)start[qi], j);
+                    const int nj = __builtin_amdgcn_readlane(len[qi], j);
+                    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[qi]), j));
+                    for (int off = 0; off < nj; off += 64)
+                        if (off + lane < nj) cert_add_posting(row, a.P[base + (uint32_t)(off + lane)], wj);
+                }
+            }
+            __syncthreads();                                     // A
+            __syncthreads();                                     // B
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- certificate kernel ---
+// One thread per query, over the approximate top list (keys descending): the candidates that need the exact chain, or "uncertified".
+struct CertSelectArgs {
+    const float* ap_scores;
+    const int32_t* ap_counts;
+    int64_t nq;
+    int k, k_eff, T;
+    const uint8_t* elig;
+    const uint8_t* overflow;
+    const int32_t* n_rare;
+    const int32_t* n_qt;
+    int32_t* m_count;
+    uint8_t* uncert;
+    int* n_uncert;
+};
+__global__ void cert_select_kernel(CertSelectArgs a) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nq) return;
+    int m = 0;
+    bool good = a.elig[q] && !a.overflow[q];
+    const int cnt = a.ap_counts[q];
+    const float* sc = a.ap_scores + q * a.k_eff;
+    if (good && cnt >= a.k) {
+        // relative error of the MFMA part: two fp16 roundings (2^-11 each, and their product), fp32 accumulation over T terms, the
+        // scaling multiply; gamma: the reference's fp32 chain against real arithmetic
+        const double dd = 2.0 * 4.8828125e-4 + 2.4e-7 + (double)a.T * 2.4e-7 + 1.0e-5;
+        const double gamma = ((double)a.n_qt[q] + 2.0) * 6.0e-8 * 1.01;
+        const double Kk = (double)sc[a.k - 1];
+        const double lb = (Kk - 1.2 - 1.01 * (double)a.n_rare[q]) / (1.0 + dd);           // lower bound of the k-th true_fix
+        const double cutd = floor(lb * (1.0 - gamma) * (1.0 - dd) / (1.0 + gamma) - 1.2) - 1.0;
+        if (cutd >= 1.0) {
+            const float cutf = (float)cutd;
+            // the list is complete down to its last key: certified if it is not truncated, or if the truncation lies below the cut
+            if (cnt < a.k_eff || sc[a.k_eff - 1] < cutf) {
+                int lo = a.k, hi = cnt;                  // first index with key < cut (keys descend)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sc[mid] >= cutf) lo = mid + 1; else hi = mid;
+                }
+                m = lo;
+            } else good = false;
+        } else good = false;
+    } else good = false;
+    a.m_count[q] = good ? m : 0;
+    a.uncert[q] = good ? 0 : 1;
+    if (!good) atomicAdd(a.n_uncert, 1);
+}
+
+// ---------------------------------------------------------------------------------------------- exact re-score ---
+// One workgroup per certified query, one wave per candidate: the doc's forward row (terms ascending) is intersected with the
+// query's terms (ascending) and the products are added in that order, unfused - the reference's chain (indexer.py:324-340).
+struct CertRescoreArgs {
+    const int64_t* q_indptr;
+    const int32_t* q_cols;
+    const float* q_vals;
+    const int64_t* fwd_indptr;
+    const int32_t* fwd_term;
+    const float* fwd_val;
+    const int64_t* ap_ids;
+    const int32_t* m_count;
+    int k_eff;
+    float threshold;
+    uint32_t id_base, id_stride;
+    uint64_t* cand_keys;
+    int* cand_count;
+    int64_t cand_cap;
+};
+__global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
+#pragma clang fp contract(off)
+    __shared__ int32_t qc[SC_MAXQT];
+    __shared__ float qv[SC_MAXQT];
+    __shared__ int n_kept;
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = a.m_count[q];
+    if (m == 0) return;                       // cand_count[q] stays 0 (topk_reset)
+    const int64_t tb = a.q_indptr[q];
+    const int nqt = (int)(a.q_indptr[q + 1] - tb);
+    for (int i = tid; i < SC_MAXQT; i += 256) {
+        qc[i] = i < nqt ? a.q_cols[tb + i] : 0x7fffffff;
+        qv[i] = i < nqt ? a.q_vals[tb + i] : 0.f;
+    }
+    if (tid == 0) n_kept = 0;
+    __syncthreads();
+    uint64_t* dst = a.cand_keys + q * a.cand_cap;
+    for (int c = wave; c < m; c += 4) {
+        const int64_t doc = a.ap_ids[q * a.k_eff + c];
+        const int64_t b = a.fwd_indptr[doc], e = a.fwd_indptr[doc + 1];
+        float s = 0.f;
+        for (int64_t p0 = b; p0 < e; p0 += 64) {
+            const int64_t p = p0 + lane;
+            const bool live = p < e;
+            const int32_t t = live ? a.fwd_term[p] : 0x7fffffff;
+            const float v = live ? a.fwd_val[p] : 0.f;
+            int lo = 0;                       // lower bound of t among the query's terms (padded with INT_MAX to SC_MAXQT)
+#pragma unroll
+            for (int step = SC_MAXQT / 2; step > 0; step >>= 1)
+                if (qc[lo + step - 1] < t) lo += step;
+            const bool match = live && lo < nqt && qc[lo] == t;
+            const float prod = match ? qv[lo] * v : 0.f;
+            uint64_t mm = __ballot(match);
+            while (mm) {
+                const int i = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod), i));
+            }
+        }
+        if (lane == 0 && s > a.threshold) {
+            const int pos = atomicAdd(&n_kept, 1);
+            dst[pos] = sr_make_key(s, a.id_base + (uint32_t)doc * a.id_stride);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) a.cand_count[q] = n_kept;
+}
+
+// ------------------------------------------------------------------------------------------------------ driver ---
+template <typename T>
+static int cert_realloc(T*& p, size_t n) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    SR_CHECK_HIP(hipMalloc((void**)&p, sizeof(T) * n));
+    return SR_OK;
+}
+
+template <int KS>
+static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
+    static DeviceOnce lds_set;
+    const int lds = (int)(sizeof(uint32_t) * SC_QB * SC_PITCH_W + 1024 * KS);
+    if (bool* slot = lds_set.pending()) {
+        SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        *slot = true;
+    }
+    hipLaunchKernelGGL(cert_score_kernel<KS>, dim3(grid), dim3(1024), lds, s, a);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
+                       int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
+                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, hipStream_t s) {
+    SparseCert* c = idx->cert;
+    const int k_eff = k + SC_BAND;
+    const int64_t nq_pad = ceil_div64(nq, SC_QB) * SC_QB;
+    const int n_qblocks = (int)(nq_pad / SC_QB);
+    if (nq_pad > c->nq_cap) {
+        SR_TRY(cert_realloc(c->bfrag, (size_t)nq_pad * (size_t)c->T));
+        SR_TRY(cert_realloc(c->rare_term, (size_t)nq_pad * SC_MAXR));
+        SR_TRY(cert_realloc(c->rare_w, (size_t)nq_pad * SC_MAXR));
+        SR_TRY(cert_realloc(c->cq, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->sq, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->n_rare, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->n_qt, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->elig, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->overflow, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->m_count, (size_t)nq_pad));
+        c->nq_cap = nq_pad;
+    }
+    if (nq_pad * k_eff > c->ap_cap) {
+        SR_TRY(cert_realloc(c->ap_scores, (size_t)nq_pad * (size_t)k_eff));
+        SR_TRY(cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)k_eff));
+        SR_TRY(cert_realloc(c->ap_counts, (size_t)nq_pad));
+        c->ap_cap = nq_pad * k_eff;
+    }
+    if (!c->d_n_uncert) SR_CHECK_HIP(hipMalloc((void**)&c->d_n_uncert, sizeof(int)));
+    const int64_t dump_stride = (int64_t)c->n_tiles * SC_DT;
+    if (c->want_dump && c->dump_nq < nq_pad) {
+        SR_TRY(cert_realloc(c->dump, (size_t)nq_pad * (size_t)dump_stride));
+        c->dump_nq = nq_pad;
+    }
+    SR_TRY(c->ws.ensure(nq_pad, k_eff, SC_CAND_CAP));
+
+    // plan
+    SR_CHECK_HIP(hipMemsetAsync(c->bfrag, 0, sizeof(_Float16) * (size_t)nq_pad * (size_t)c->T, s));
+    SR_CHECK_HIP(hipMemsetAsync(c->d_n_uncert, 0, sizeof(int), s));
+    CertPlanArgs pa;
+    pa.q_indptr = d_q_indptr; pa.q_cols = d_q_cols; pa.q_vals = d_q_vals; pa.nq = nq; pa.n_terms = idx->n_terms;
+    pa.indptr = idx->indptr; pa.dslot = c->dslot; pa.vmax = c->vmax; pa.KS = c->KS; pa.vscale = c->vscale;
+    pa.bfrag = c->bfrag; pa.rare_term = c->rare_term; pa.rare_w = c->rare_w; pa.cq = c->cq; pa.sq = c->sq; pa.n_rare = c->n_rare; pa.n_qt = c->n_qt;
+    pa.elig = c->elig; pa.overflow = c->overflow;
+    hipLaunchKernelGGL(cert_plan_kernel, dim3((unsigned)ceil_div64(nq_pad, 4)), dim3(256), 0, s, pa);
+    SR_CHECK_LAUNCH();
+
+    // stage 1: doc tiles in launches that grow geometrically (the threshold tightens early), at most 512 tiles each
+    SR_TRY(topk_reset(c->ws, nq_pad, s));
+    CertArgs a;
+    a.d16 = reinterpret_cast<const f16x8*>(c->d16);
+    a.P = c->P; a.S = c->S; a.s_stride = c->n_tiles + 1;
+    a.bfrag = reinterpret_cast<const f16x8*>(c->bfrag);
+    a.rare_term = c->rare_term; a.rare_w = c->rare_w; a.cq = c->cq; a.tau = c->ws.tau; a.nq = nq;
+    a.cand_keys = c->ws.cand_keys; a.cand_count = c->ws.cand_count; a.cand_cap = c->ws.cand_cap; a.overflow = c->overflow;
+    a.n_qblocks = n_qblocks;
+    a.dump = c->want_dump ? c->dump : nullptr;
+    a.dump_stride = dump_stride;
+    int64_t step = 1;
+    for (int64_t t0 = 0; t0 < c->n_tiles;) {
+        int64_t nt = step < 512 ? step : 512;
+        if (t0 + nt > c->n_tiles) nt = c->n_tiles - t0;
+        a.tile_begin = (int)t0;
+        a.n_tiles_launch = (int)nt;
+        int64_t tpw = nt * n_qblocks / 1024;           // enough workgroups to fill the chip, then longer walks per workgroup
+        tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+        a.tiles_per_wg = (int)tpw;
+        const int64_t n_chunks = ceil_div64(nt, tpw);
+        const unsigned grid = (unsigned)(ceil_div64(n_chunks, 8) * 8 * n_qblocks);
+        idx->prof.begin(s);
+        int rc;
+        switch (c->KS) {
+            case 1: rc = cert_launch_score<1>(a, grid, s); break;
+            case 2: rc = cert_launch_score<2>(a, grid, s); break;
+            case 4: rc = cert_launch_score<4>(a, grid, s); break;
+            case 8: rc = cert_launch_score<8>(a, grid, s); break;
+            default: rc = cert_launch_score<16>(a, grid, s); break;
+        }
+        idx->prof.end(s, 0, 0);
+        SR_TRY(rc);
+        SR_TRY(topk_compact(c->ws, nq_pad, k_eff, s));
+        t0 += nt;
+        step *= 2;
+    }
+    SR_TRY(topk_finalize(c->ws, nq_pad, k_eff, 0.f, c->ap_scores, c->ap_ids, c->ap_counts, s));
+
+    // stage 2: certificate, exact re-score of the candidates, exact top-k of those
+    CertSelectArgs sa;
+    sa.ap_scores = c->ap_scores; sa.ap_counts = c->ap_counts; sa.nq = nq; sa.k = k; sa.k_eff = k_eff; sa.T = c->T;
+    sa.elig = c->elig; sa.overflow = c->overflow; sa.n_rare = c->n_rare; sa.n_qt = c->n_qt; sa.m_count = c->m_count;
+    sa.uncert = d_uncert; sa.n_uncert = c->d_n_uncert;
+    hipLaunchKernelGGL(cert_select_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, sa);
+    SR_CHECK_LAUNCH();
+    SR_TRY(topk_reset(c->ws, nq_pad, s));
+    CertRescoreArgs ra;
+    ra.q_indptr = d_q_indptr; ra.q_cols = d_q_cols; ra.q_vals = d_q_vals;
+    ra.fwd_indptr = c->fwd_indptr; ra.fwd_term = c->fwd_term; ra.fwd_val = c->fwd_val;
+    ra.ap_ids = c->ap_ids; ra.m_count = c->m_count; ra.k_eff = k_eff; ra.threshold = threshold;
+    ra.id_base = (uint32_t)id_base; ra.id_stride = (uint32_t)id_stride;
+    ra.cand_keys = c->ws.cand_keys; ra.cand_count = c->ws.cand_count; ra.cand_cap = c->ws.cand_cap;
+    hipLaunchKernelGGL(cert_rescore_kernel, dim3((unsigned)nq), dim3(256), 0, s, ra);
+    SR_CHECK_LAUNCH();
+    SR_TRY(topk_compact(c->ws, nq, k, s));
+    SR_TRY(topk_finalize(c->ws, nq, k, 0.f, d_out_scores, d_out_ids, d_out_counts, s));
+    int h_un = 0;
+    SR_CHECK_HIP(hipMemcpyAsync(&h_un, c->d_n_uncert, sizeof(int), hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    *n_uncert = h_un;
+    ++c->n_calls;
+    c->n_queries += nq;
+    c->n_uncert += h_un;
+    return SR_OK;
+}
+
+// Which path served the searches so far.  out[0] = 1 if the certified scorer exists for this index, [1] dense terms (MFMA K),
+// [2] searches it ran, [3] queries it was given, [4] queries it handed to the exact kernels (uncertified), [5] doc tiles, [6] reserved
+extern "C" int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8) {
+    SR_REQUIRE(idx && out8, "sr_sparse_index_cert_stats: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (SparseCert* c = idx->cert) {
+        out8[0] = 1; out8[1] = c->T; out8[2] = c->n_calls; out8[3] = c->n_queries; out8[4] = c->n_uncert; out8[5] = c->n_tiles;
+    }
+    return SR_OK;
+}
+
+// Debug / test hook: after enable = 1 every search keeps the stage-1 keys of all (query, doc) pairs; enable = 2 copies the keys of
+// the last search to h_keys [nq_pad][n_tiles * 1024] (uint16) and returns the per-query constants the bound needs:
+// h_consts [nq_pad][4] = {cq (0: the query is outside the fast path), s_q, n_rare, n_query_terms}.  *vscale / *T: the index-side constants.
+extern "C" int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_keys, int64_t keys_capacity, float* h_consts,
+                                          int64_t nq_pad, float* vscale, int32_t* T) {
+    SR_REQUIRE(idx, "sr_sparse_index_cert_debug: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    SparseCert* c = idx->cert;
+    SR_REQUIRE(c, "sr_sparse_index_cert_debug: this index has no certified scorer");
+    if (enable != 2) {
+        c->want_dump = enable != 0;
+        return SR_OK;
+    }
+    SR_REQUIRE(c->dump && h_keys && h_consts && nq_pad <= c->dump_nq, "sr_sparse_index_cert_debug: nothing recorded");
+    const int64_t stride = (int64_t)c->n_tiles * SC_DT;
+    SR_REQUIRE(keys_capacity >= nq_pad * stride, "sr_sparse_index_cert_debug: key buffer too small");
+    SR_CHECK_HIP(hipDeviceSynchronize());
+    SR_CHECK_HIP(hipMemcpy(h_keys, c->dump, sizeof(uint16_t) * (size_t)(nq_pad * stride), hipMemcpyDeviceToHost));
+    std::vector<float> cqv((size_t)nq_pad), sqv((size_t)nq_pad);
+    std::vector<int32_t> nr((size_t)nq_pad), nt((size_t)nq_pad);
+    SR_CHECK_HIP(hipMemcpy(cqv.data(), c->cq, sizeof(float) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    SR_CHECK_HIP(hipMemcpy(sqv.data(), c->sq, sizeof(float) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    SR_CHECK_HIP(hipMemcpy(nr.data(), c->n_rare, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    SR_CHECK_HIP(hipMemcpy(nt.data(), c->n_qt, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    for (int64_t q = 0; q < nq_pad; ++q) {
+        h_consts[4 * q] = cqv[(size_t)q];
+        h_consts[4 * q + 1] = sqv[(size_t)q];
+        h_consts[4 * q + 2] = (float)nr[(size_t)q];
+        h_consts[4 * q + 3] = (float)nt[(size_t)q];
+    }
+    if (vscale) *vscale = c->vscale;
+    if (T) *T = c->T;
+    return SR_OK;
+}

@@ -978,42 +978,7 @@ __global__ void sparse_validate_kernel(const int64_t* __restrict__ indptr, const
     if (bad) atomicOr(flags, bad);
 }
 
-struct sr_sparse_index {
-    const int64_t* indptr = nullptr;
-    const int32_t* doc_ids = nullptr;
-    const float* vals = nullptr;
-    int64_t n_terms = 0, n_docs = 0;
-    int n_tiles = 0;
-    int32_t* skip = nullptr;
-    // heavy terms as dense columns (query-block kernel)
-    int n_dense = 0;
-    int64_t dense_stride = 0;
-    float* dense = nullptr;
-    int32_t* dense_slot = nullptr;
-    // per-call plan of the query blocks
-    int64_t plan_cap = 0, plan_blocks_cap = 0;
-    int32_t* plan_term = nullptr;
-    float* plan_w = nullptr;
-    int32_t* plan_n = nullptr;
-    uint8_t* plan_ok = nullptr;
-    int64_t* plan_off = nullptr;
-    unsigned long long* d_stamps = nullptr;   // dev switch SR_SPARSE_STAMPS
-    unsigned long long* d_counters = nullptr; // sr_sparse_index_work_counters
-    int* seg_cnt = nullptr;                   // wave-owned candidate regions of the query-block kernel: [q_batch][seg_cap]
-    int64_t seg_q_cap = 0; int seg_cap = 0;
-    bool count_work = false;
-    int32_t* plan_perm = nullptr;     // every batch's queries in block order
-    uint8_t* q_done = nullptr;
-    int64_t plan_q_cap = 0;
-    int* plan_bad = nullptr;
-    int64_t n_block_calls = 0, n_fallback_calls = 0;
-    int64_t ws_limit = 4ll << 30;
-    TopkWS ws;
-    StreamOrder order;
-    LaunchProfile prof;
-    unsigned long long* d_postings = nullptr;  // device counter of postings touched (profiling only)
-    std::mutex mu;
-};
+#include "sparse_index.h"
 
 // postings of the batch's query terms inside tiles [tile_begin, tile_begin + n_t): one thread per query term
 __global__ void sparse_count_postings_kernel(const int32_t* __restrict__ skip, int n_tiles, int64_t n_terms,
@@ -1160,6 +1125,7 @@ extern "C" int sr_sparse_index_create(sr_sparse_index** out, const int64_t* d_in
     } while (0);
     if (d_flags) (void)hipFree(d_flags);
     if (rc == SR_OK) rc = sparse_build_dense(idx, s);
+    if (rc == SR_OK) rc = sparse_cert_build(idx, s);
     if (rc != SR_OK) {
         sparse_free_device(idx);
         delete idx;
@@ -1187,6 +1153,8 @@ extern "C" int sr_sparse_index_destroy(sr_sparse_index* idx) {
     }
     idx->ws.release();
     idx->order.release();
+    sparse_cert_destroy(idx->cert);
+    idx->cert = nullptr;
     sparse_free_device(idx);
     if (idx->d_postings) (void)hipFree(idx->d_postings);
     if (idx->d_counters) (void)hipFree(idx->d_counters);
@@ -1248,20 +1216,11 @@ extern "C" int sr_sparse_index_profile_read(sr_sparse_index* idx, int64_t* n_lau
     return SR_OK;
 }
 
-extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
-                                const float* d_q_vals, int64_t nq, int k, float threshold, int64_t id_base,
-                                int64_t id_stride, float* d_out_scores, int64_t* d_out_ids, int32_t* d_out_counts,
-                                sr_stream stream) {
-    SR_REQUIRE(idx, "sr_sparse_search: null index");
-    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_sparse_search: bad nq");
-    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_sparse_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
-    SR_REQUIRE(id_stride >= 1 && id_base >= 0 && id_base + (idx->n_docs - 1) * id_stride < 0xffffffffll,
-               "sr_sparse_search: global doc index exceeds 32 bits");
-    if (nq == 0) return SR_OK;
-    SR_REQUIRE(d_q_indptr && d_out_scores && d_out_ids, "sr_sparse_search: null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(idx->mu);
-    StreamOrder::Scope in_order(idx->order, s);
+// The exact kernels over all docs for the queries of one CSR (the caller holds idx->mu and the stream order).
+static int sparse_exact_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
+                               const float* d_q_vals, int64_t nq, int k, float threshold, int64_t id_base,
+                               int64_t id_stride, float* d_out_scores, int64_t* d_out_ids, int32_t* d_out_counts,
+                               hipStream_t s) {
 
     // query batches bound the candidate workspace: cap (slots per query) = docs per launch
     int64_t q_batch_max = 1024;
@@ -1435,4 +1394,115 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                              d_out_counts ? d_out_counts + qb : nullptr, s));
     }
     return SR_OK;
+}
+
+// ---- queries the certified scorer hands back: their rows are gathered into a CSR of their own, scored by the exact kernels and
+// scattered into the result rows
+__global__ void sparse_sub_gather_kernel(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_cols, const float* __restrict__ q_vals,
+                                         const int64_t* __restrict__ sel, const int64_t* __restrict__ sub_indptr, int32_t* __restrict__ sub_cols,
+                                         float* __restrict__ sub_vals) {
+    const int64_t j = blockIdx.x;
+    const int64_t q = sel[j];
+    const int64_t b = q_indptr[q], n = q_indptr[q + 1] - b, o = sub_indptr[j];
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        sub_cols[o + i] = q_cols[b + i];
+        sub_vals[o + i] = q_vals[b + i];
+    }
+}
+__global__ void sparse_sub_scatter_kernel(const int64_t* __restrict__ sel, int k, const float* __restrict__ s_in, const int64_t* __restrict__ i_in,
+                                          const int32_t* __restrict__ c_in, float* __restrict__ s_out, int64_t* __restrict__ i_out,
+                                          int32_t* __restrict__ c_out) {
+    const int64_t j = blockIdx.x;
+    const int64_t q = sel[j];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        s_out[q * k + i] = s_in[j * k + i];
+        i_out[q * k + i] = i_in[j * k + i];
+    }
+    if (c_out && threadIdx.x == 0) c_out[q] = c_in[j];
+}
+
+static int sparse_redo_exact(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
+                             int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
+                             int32_t* d_out_counts, const uint8_t* d_uncert, hipStream_t s) {
+    std::vector<uint8_t> h_un((size_t)nq);
+    std::vector<int64_t> h_ip((size_t)nq + 1);
+    SR_CHECK_HIP(hipMemcpyAsync(h_un.data(), d_uncert, (size_t)nq, hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipMemcpyAsync(h_ip.data(), d_q_indptr, sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<int64_t> sel, sub_ip(1, 0);
+    for (int64_t q = 0; q < nq; ++q)
+        if (h_un[(size_t)q]) {
+            sel.push_back(q);
+            sub_ip.push_back(sub_ip.back() + (h_ip[(size_t)q + 1] - h_ip[(size_t)q]));
+        }
+    const int64_t ns = (int64_t)sel.size();
+    if (ns == 0) return SR_OK;
+    const int64_t nnz = sub_ip.back();
+    int64_t *d_sel = nullptr, *d_sip = nullptr, *d_ids = nullptr;
+    int32_t *d_cols = nullptr, *d_cnt = nullptr;
+    float *d_vals = nullptr, *d_sc = nullptr;
+    int rc = SR_OK;
+    if (hipMalloc((void**)&d_sel, 8 * (size_t)ns) != hipSuccess || hipMalloc((void**)&d_sip, 8 * ((size_t)ns + 1)) != hipSuccess ||
+        hipMalloc((void**)&d_cols, 4 * (size_t)(nnz > 0 ? nnz : 1)) != hipSuccess || hipMalloc((void**)&d_vals, 4 * (size_t)(nnz > 0 ? nnz : 1)) != hipSuccess ||
+        hipMalloc((void**)&d_sc, 4 * (size_t)ns * (size_t)k) != hipSuccess || hipMalloc((void**)&d_ids, 8 * (size_t)ns * (size_t)k) != hipSuccess ||
+        hipMalloc((void**)&d_cnt, 4 * (size_t)ns) != hipSuccess) {
+        sr_set_error("sr_sparse_search: out of device memory for %lld re-done queries", (long long)ns);
+        rc = SR_ERR_NOMEM;
+    }
+    if (rc == SR_OK && (hipMemcpyAsync(d_sel, sel.data(), 8 * (size_t)ns, hipMemcpyHostToDevice, s) != hipSuccess ||
+                        hipMemcpyAsync(d_sip, sub_ip.data(), 8 * ((size_t)ns + 1), hipMemcpyHostToDevice, s) != hipSuccess))
+        rc = SR_ERR_HIP;
+    if (rc == SR_OK) {
+        hipLaunchKernelGGL(sparse_sub_gather_kernel, dim3((unsigned)ns), dim3(64), 0, s, d_q_indptr, d_q_cols, d_q_vals, d_sel, d_sip, d_cols, d_vals);
+        rc = sparse_exact_search(idx, d_sip, d_cols, d_vals, ns, k, threshold, id_base, id_stride, d_sc, d_ids, d_cnt, s);
+    }
+    if (rc == SR_OK) {
+        hipLaunchKernelGGL(sparse_sub_scatter_kernel, dim3((unsigned)ns), dim3(256), 0, s, d_sel, k, d_sc, d_ids, d_cnt, d_out_scores, d_out_ids,
+                           d_out_counts);
+        if (hipGetLastError() != hipSuccess) rc = SR_ERR_HIP;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess && rc == SR_OK) rc = SR_ERR_HIP;      // the temporaries are freed below
+    if (rc == SR_ERR_HIP) sr_set_error("sr_sparse_search: re-doing uncertified queries failed: %s", hipGetErrorString(hipGetLastError()));
+    void* ptrs[] = {d_sel, d_sip, d_cols, d_vals, d_sc, d_ids, d_cnt};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols,
+                                const float* d_q_vals, int64_t nq, int k, float threshold, int64_t id_base,
+                                int64_t id_stride, float* d_out_scores, int64_t* d_out_ids, int32_t* d_out_counts,
+                                sr_stream stream) {
+    SR_REQUIRE(idx, "sr_sparse_search: null index");
+    SR_REQUIRE(nq >= 0 && nq < (1ll << 30), "sr_sparse_search: bad nq");
+    SR_REQUIRE(k >= 1 && k <= SR_MAX_TOPK, "sr_sparse_search: k=%d outside [1, %d]", k, SR_MAX_TOPK);
+    SR_REQUIRE(id_stride >= 1 && id_base >= 0 && id_base + (idx->n_docs - 1) * id_stride < 0xffffffffll,
+               "sr_sparse_search: global doc index exceeds 32 bits");
+    if (nq == 0) return SR_OK;
+    SR_REQUIRE(d_q_indptr && d_out_scores && d_out_ids, "sr_sparse_search: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    StreamOrder::Scope in_order(idx->order, s);
+    // certified two-stage scorer (sparse_cert.hip) where the index has one and k leaves room for its band of extra keys; the
+    // queries it cannot certify are re-done by the exact kernels.  Dev switch SR_SPARSE_CERT_SEARCH=0: exact kernels only (A/B)
+    bool use_cert = idx->cert != nullptr && k + 1024 <= SR_MAX_TOPK;
+    {
+        const char* forced = sr_dev_getenv("SR_SPARSE_CERT");        // 1: also on collections too small for it to pay (tests)
+        if (!(forced && atoi(forced) == 1)) use_cert = use_cert && idx->n_docs >= 8ll * (k + 1024);
+    }
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_SEARCH")) use_cert = use_cert && atoi(e) != 0;
+    if (use_cert) {
+        uint8_t* d_uncert = nullptr;
+        SR_CHECK_HIP(hipMalloc((void**)&d_uncert, (size_t)nq));
+        int64_t n_un = 0;
+        int rc = sparse_cert_search(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
+                                    d_out_counts, d_uncert, &n_un, s);
+        if (rc == SR_OK && n_un > 0)
+            rc = sparse_redo_exact(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
+                                   d_out_counts, d_uncert, s);
+        (void)hipFree(d_uncert);       // sparse_cert_search synchronised the stream after its last use
+        return rc;
+    }
+    return sparse_exact_search(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
+                               d_out_counts, s);
 }

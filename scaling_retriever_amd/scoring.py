@@ -267,6 +267,33 @@ class SparseIndexHIP:
         _lib.check(self.lib.sr_sparse_index_block_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"dense_terms": a.value, "block_calls": b.value, "fallback_calls": c.value}
 
+    def cert_stats(self):
+        """Certified two-stage scorer (csrc/sparse_cert.hip): {"present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles"}."""
+        out = (ctypes.c_int64 * 8)()
+        _lib.check(self.lib.sr_sparse_index_cert_stats(self._h, out), "sr_sparse_index_cert_stats")
+        keys = ("present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles")
+        return {k_: int(v) for k_, v in zip(keys, out)}
+
+    def cert_record_keys(self, enable):
+        """Test hook: keep the stage-1 keys of every (query, doc) pair of the following searches."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_sparse_index_cert_debug(self._h, 1 if enable else 0, None, 0, None, 0, None, None),
+                       "sr_sparse_index_cert_debug")
+
+    def cert_recorded_keys(self, nq):
+        """(keys uint16 [nq_pad, n_tiles * 1024], consts fp32 [nq_pad, 4] = (c_q, s_q, rare terms, query terms), vscale, T) of the
+        last search (after cert_record_keys(True))."""
+        nq_pad = (nq + 31) // 32 * 32
+        stride = self.cert_stats()["doc_tiles"] * 1024
+        keys = np.empty((nq_pad, stride), dtype=np.uint16)
+        consts = np.empty((nq_pad, 4), dtype=np.float32)
+        vs, T = ctypes.c_float(0), ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sr_sparse_index_cert_debug(self._h, 2, keys.ctypes.data_as(ctypes.c_void_p), keys.size,
+                                                           consts.ctypes.data_as(ctypes.c_void_p), nq_pad, ctypes.byref(vs), ctypes.byref(T)),
+                       "sr_sparse_index_cert_debug")
+        return keys, consts, vs.value, T.value
+
     def work_counters(self, enable):
         """Switch the query-block kernel's work counters on / off; returns what was counted since the last call:
         {"dense_columns_loaded", "dense_column_applications", "light_postings", "grouped_postings", "plan_entries", "workgroup_tiles"}."""
@@ -308,6 +335,26 @@ class SparseIndexHIP:
             self.close()
         except Exception:
             pass
+
+
+def sparse_csr_build(rows, cols, vals, n_terms, n_docs=0, sort_docs=False):
+    """Doc-major postings (cuda tensors: rows int32 = global doc row, cols int32 = term, vals fp32; insertion order) -> CSR by term
+    (indptr int64 [n_terms + 1], doc_ids int32, vals fp32) with sr_sparse_csr_build: this library's stable radix sort on the device.
+    Replaces the per-posting append of IndexDictOfArray.add_batch_document (inverted_index.py:67-76)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    rows = rows.to(torch.int32).contiguous()
+    cols = cols.to(torch.int32).contiguous()
+    vals = vals.to(torch.float32).contiguous()
+    nnz = rows.numel()
+    dev = rows.device
+    indptr = torch.empty(int(n_terms) + 1, dtype=torch.int64, device=dev)
+    out_rows = torch.empty(max(1, nnz), dtype=torch.int32, device=dev)
+    out_vals = torch.empty(max(1, nnz), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_sparse_csr_build(_ptr(rows), _ptr(cols), _ptr(vals), nnz, int(n_terms), int(n_docs), 1 if sort_docs else 0,
+                                           _ptr(indptr), _ptr(out_rows), _ptr(out_vals), _lib.stream_ptr()), "sr_sparse_csr_build")
+    return indptr, out_rows[:nnz], out_vals[:nnz]
 
 
 def topk_merge(scores, ids, pad_score=-3.402823466e38):
