@@ -306,6 +306,9 @@ int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_sc
                       const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off, int64_t qid_width,
                       const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off, int64_t doc_width,
                       int64_t n_docs, int32_t n_threads, int64_t* bytes_written);
+/* Test hook: rounds of sr_write_run_json that were copied through the shared file mapping (rounds of >= 8 MB with more than
+ * one thread) since the library was loaded; the other rounds are written with pwrite.                                       */
+int64_t sr_run_writer_mapped_rounds(void);
 
 /* ----------------------------------------------------- building blocks ---
  * The two MFMA kernels of the encoder, exported for per-kernel parity tests and

@@ -79,6 +79,7 @@ SIGNATURES = {
     "sr_model_last_hidden": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     "sr_model_destroy": (c_int, [c_void_p]),
     "sr_lora_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
+    "sr_run_writer_mapped_rounds": (c_int64, []),
     "sr_write_run_json": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_int64)]),
     "sr_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

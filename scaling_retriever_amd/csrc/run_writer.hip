@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -119,6 +120,10 @@ struct Keys {
 
 }  // namespace
 
+static std::atomic<int64_t> g_mapped_rounds{0};
+// rounds of sr_write_run_json that went through the shared file mapping since the library was loaded (test hook)
+extern "C" int64_t sr_run_writer_mapped_rounds(void) { return g_mapped_rounds.load(); }
+
 extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
                                  const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
                                  int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
@@ -129,7 +134,7 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
     SR_REQUIRE(n_docs >= 0 && (n_docs == 0 || h_doc_i64 || (h_doc_bytes && (h_doc_off || doc_width > 0))),
                "sr_write_run_json: no document ids");
     const Keys qk{h_qid_i64, h_qid_bytes, h_qid_off, qid_width}, dk{h_doc_i64, h_doc_bytes, h_doc_off, doc_width};
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);      // O_RDWR: a shared writable mapping needs read access (EACCES with O_WRONLY)
     if (fd < 0) {
         sr_set_error("sr_write_run_json: cannot open %s: %s", path, strerror(errno));
         return SR_ERR_INVALID;
@@ -233,6 +238,7 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
                 copy(0);
                 for (auto& x : th) x.join();
                 mapped = munmap(m, (size_t)(total - map_begin)) == 0;
+                if (mapped) g_mapped_rounds.fetch_add(1);
             }
         }
         if (!mapped) {

@@ -38,12 +38,14 @@
 #define SC_MB (SC_DT / 32)            // 32-doc M blocks per tile
 #define SC_PITCH_W (SC_DT / 2 + 2)    // 32-bit words per query row of the LDS tile (two 16-bit slots per word; + 2: bank spread)
 #define SC_MAXR 64                    // rare terms per query (one lane each)
-#define SC_LIGHT 8                    // runs shorter than this are walked lane-per-term, longer ones wave-wide
 #define SC_BAND 1024                  // keys kept beyond k
 #define SC_CAND_CAP 16384             // candidate slots per query and launch
 #define SC_MAXQT 256                  // terms of a fast-path query
 #define SC_TMAX 256                   // dense terms (MFMA K), at most
 #define SC_FWD_MAX 1024               // postings per doc the forward-index sort handles
+#ifndef SC_DIAG
+#define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -55,8 +57,8 @@ struct SparseCert {
     float vscale = 1.f;               // power of two applied to the values before the fp16 rounding
     int32_t* dslot = nullptr;         // [V] dense slot of a term, -1 = rare
     float* vmax = nullptr;            // [V] largest value of a posting list
-    _Float16* d16 = nullptr;          // [n_tiles][KS][SC_MB][64][8]: MFMA A fragments (row = doc, k = dense slot)
-    uint32_t* P = nullptr;            // [nnz] packed postings: doc % SC_DT | fp16(v * vscale) << 16
+    _Float16* d16 = nullptr;          // [n_tiles][SC_MB][KS][64][8]: MFMA A fragments (row = doc, k = dense slot); a matrix wave streams 4 KS KB per tile
+    uint32_t* P = nullptr;            // [nnz] packed postings: (doc % SC_DT / 2) * 4 | doc % 2  (byte offset of the doc's LDS word | its half) | fp16(v * vscale) << 16
     uint32_t* S = nullptr;            // [V][n_tiles + 1]: first posting (absolute index) of term t with doc >= tile * SC_DT
     int64_t* fwd_indptr = nullptr;    // doc-major forward index, terms ascending inside a doc
     int32_t* fwd_term = nullptr;
@@ -120,7 +122,7 @@ __global__ void cert_fill_d16_kernel(const int64_t* __restrict__ indptr, const i
         const int dl = (int)(doc - tile * SC_DT);
         const int mb = dl >> 5, r = dl & 31;
         const int lane = r + 32 * (kk >> 3);
-        d16[((((tile * KS + s) * SC_MB + mb) * 64 + lane) << 3) + (kk & 7)] = (_Float16)(vals[p] * vscale);
+        d16[((((tile * SC_MB + mb) * KS + s) * 64 + lane) << 3) + (kk & 7)] = (_Float16)(vals[p] * vscale);
     }
 }
 
@@ -129,7 +131,8 @@ __global__ void cert_pack_postings_kernel(const int32_t* __restrict__ doc_ids, c
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nnz) return;
     const _Float16 h = (_Float16)(vals[p] * vscale);
-    P[p] = ((uint32_t)doc_ids[p] & (SC_DT - 1)) | ((uint32_t)__builtin_bit_cast(unsigned short, h) << 16);
+    const uint32_t dl = (uint32_t)doc_ids[p] & (SC_DT - 1);
+    P[p] = ((dl >> 1) << 2) | (dl & 1u) | ((uint32_t)__builtin_bit_cast(unsigned short, h) << 16);
 }
 
 // S[t][i] = indptr[t] + #{postings of t with doc < i * SC_DT}, i = 0 .. n_tiles.  The thread of posting p (doc d, predecessor d')
@@ -456,16 +459,48 @@ struct CertArgs {
     int64_t dump_stride;
 };
 
+// low half of a packed posting: byte offset of the doc's word inside a query row of the LDS tile | doc parity (SC_POST_LO)
 __device__ __forceinline__ void cert_add_posting(uint32_t* row, uint32_t p, float w) {
-    const uint32_t d = p & 0xffffu;
     const float v = (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
     const uint32_t c = (uint32_t)(v * w + 1.0f);                 // in (x, x + 1]: rounded up, never below the real contribution
-    atomicAdd(&row[d >> 1], c << ((d & 1u) * 16u));
+    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(row) + (p & 0xfffcu)), c << ((p & 1u) * 16u));
 }
+
+// wave-wide inclusive scans on the DPP row shifts / row broadcasts of gfx9 (6 VALU instructions, no LDS)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int sc_dpp(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int sc_scan_add(int v) {
+    v += sc_dpp<0x111, 0xf>(v);      // row_shr:1
+    v += sc_dpp<0x112, 0xf>(v);      // row_shr:2
+    v += sc_dpp<0x114, 0xf>(v);      // row_shr:4
+    v += sc_dpp<0x118, 0xf>(v);      // row_shr:8
+    v += sc_dpp<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += sc_dpp<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
+    v = max(v, sc_dpp<0x111, 0xf>(v));
+    v = max(v, sc_dpp<0x112, 0xf>(v));
+    v = max(v, sc_dpp<0x114, 0xf>(v));
+    v = max(v, sc_dpp<0x118, 0xf>(v));
+    v = max(v, sc_dpp<0x142, 0xa>(v));
+    v = max(v, sc_dpp<0x143, 0xc>(v));
+    return v;
+}
+
+#ifndef SC_DP
+#define SC_DP 8                       // A fragments in flight per matrix wave
+#endif
+#ifndef SC_ITERS
+#define SC_ITERS 8
+#endif
+// SC_ITERS:                    // 64-posting steps of a (query, tile) whose loads are issued ahead, in registers
+#define SC_LMAX 1024                  // postings of a (query, tile) the flattened walk handles (beyond: run by run)
+#define SC_MARK (SC_LMAX + 64)        // bytes of one mark buffer
 
 template <int KS>
 __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
-    extern __shared__ uint32_t slots[];                          // [SC_QB][SC_PITCH_W]
+    extern __shared__ uint32_t slots[];                          // [SC_QB][SC_PITCH_W] | B fragments | mark buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroups of one doc chunk share blockIdx.x % 8, i.e. one XCD under round-robin placement: the chunk's tiles, postings
     // and table rows are pulled into ONE L2 (speed only, never correctness)
@@ -485,7 +520,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     __syncthreads();
 
     if (wave < 8) {
-        // ---------------- matrix waves: M blocks 4 wave .. 4 wave + 3 of every tile ----------------
+        // ---------------- matrix waves: M blocks 4 wave .. 4 wave + 3 of every tile, one after the other ----------------
         const int qn = lane & 31, h = lane >> 5;
         const int64_t q = (int64_t)qb * SC_QB + qn;
         const float cq = a.cq[q];
@@ -494,29 +529,44 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         if (tq > 1.f) cut = tq >= 65536.f ? 65536 : (int)ceilf(tq);
         const uint32_t cutm1 = (uint32_t)(cut - 1);
         const uint32_t cutm1x2 = cutm1 | (cutm1 << 16);
+        // The A fragments of a tile are a sequence of NL = 4 KS loads (block, k-step); DP of them are in flight
+        // in a ring of registers at any time, across tile boundaries too - the matrix pipe never waits for a fresh round trip.
+        constexpr int NL = 4 * KS;
+        constexpr int DP = NL < SC_DP ? NL : SC_DP;
+        // fragment i of the wave's tile slice lies i KB behind the slice's start: wave-uniform base (SGPRs) + 16 lane + immediate
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        auto a_ptr = [&](int tile, int i) -> const f16x8* {
+            const char* base = reinterpret_cast<const char*>(a.d16) + (((int64_t)tile * SC_MB + wave_u * 4) * KS) * 1024;
+            return reinterpret_cast<const f16x8*>(base + i * 1024 + lane * 16);
+        };
+        f16x8 af[DP];
+#pragma unroll
+        for (int i = 0; i < DP; ++i) af[i] = (SC_DIAG & 2) ? f16x8{} : *a_ptr(tile0, i);
         for (int tile = tile0; tile < tile1; ++tile) {
-            f32x16 acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-            const f16x8* A = a.d16 + ((int64_t)tile * KS * SC_MB + wave * 4) * 64 + lane;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                f16x8 af[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = A[((int64_t)s * SC_MB + j) * 64];
-                const f16x8 bq = bl[s * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], bq, acc[j], 0, 0, 0);
-            }
-            // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1}
+            const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
+            f32x16 acc;
             uint32_t key[4][8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < NL; ++i) {
+                const int mb = i / KS, ks = i % KS;
+                if (ks == 0) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    key[j][g] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(acc[j][2 * g] * cq, acc[j][2 * g + 1] * cq));
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                }
+                const f16x8 bq = bl[ks * 64 + lane];
+                if (!(SC_DIAG & 2)) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);           // the ring's order is the point: hipcc otherwise re-packs the loads into one register and waits for each
+                    af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == KS - 1) {
+                    // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1}
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        key[mb][g] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(acc[2 * g] * cq, acc[2 * g + 1] * cq));
+                }
+            }
             __syncthreads();                                     // A: the scatter waves' adds are in the LDS tile
             uint32_t any = 0;
 #pragma unroll
@@ -567,7 +617,13 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
+        // The postings a (query, tile) item has to add are the runs of its rare terms inside the tile: len_j postings from
+        // start_j on (table S).  They are walked FLATTENED: posting f of the item belongs to the run r with b_r <= f < b_r + len_r
+        // (b = exclusive prefix of the lengths); r comes from a byte array in LDS holding r + 1 at position b_r (zero elsewhere)
+        // and a wave-wide running maximum, 64 postings per step, every lane busy whatever the run lengths are.  The loads of an
+        // item are issued one item ahead (the next query's, or the next tile's first query's) into a second set of registers.
         const int sw = wave - 8;
+        unsigned char* const mark_base = reinterpret_cast<unsigned char*>(bl + KS * 64) + sw * 2 * SC_MARK;
         int32_t term[4];
         float w[4];
 #pragma unroll
@@ -576,39 +632,98 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             term[qi] = a.rare_term[q * SC_MAXR + lane];
             w[qi] = a.rare_w[q * SC_MAXR + lane];
         }
-        for (int tile = tile0; tile < tile1; ++tile) {
-            uint32_t start[4];
-            int len[4];
+        auto fetch_runs = [&](int tile, uint32_t (&st)[4], int (&ln)[4]) {
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) {
                 u32x2_u se = {0u, 0u};
-                if (term[qi] >= 0) se = *reinterpret_cast<const u32x2_u*>(a.S + (int64_t)term[qi] * a.s_stride + tile);
-                start[qi] = se.x;
-                len[qi] = (int)(se.y - se.x);
+                if (!(SC_DIAG & 4) && term[qi] >= 0 && tile < tile1) se = *reinterpret_cast<const u32x2_u*>(a.S + (int64_t)term[qi] * a.s_stride + tile);
+                st[qi] = se.x;
+                ln[qi] = (SC_DIAG & 1) ? 0 : (int)(se.y - se.x);
             }
+        };
+        // mapping of flat positions [64 it, 64 it + 64) of an item to (posting index, weight); carry = running maximum so far
+        auto map_step = [&](const unsigned char* mark, int it, int Lx, uint32_t delta, float wq, int& carry, uint32_t& pidx, float& wv) -> bool {
+            const int f = it * 64 + lane;
+            int v = max((int)mark[f], carry);
+            v = sc_scan_max(v);
+            carry = __builtin_amdgcn_readlane(v, 63);
+            const int rr = (v - 1) & 63;
+            pidx = (uint32_t)f + (uint32_t)__shfl((int)delta, rr);
+            wv = __shfl(wq, rr);
+            return f < Lx;
+        };
+        struct Staged { uint32_t pp[SC_ITERS]; float ww[SC_ITERS]; int Lx; int carry; };
+        auto stage = [&](unsigned char* mark, uint32_t st, int ln, float wq, Staged& g) {
+            const int e = sc_scan_add(ln);
+            const int Lx = __builtin_amdgcn_readlane(e, 63);
+            g.Lx = Lx;
+            g.carry = 0;
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                uint32_t* row = slots + (sw * 4 + qi) * SC_PITCH_W;
-                const bool light = len[qi] > 0 && len[qi] < SC_LIGHT;
-                // short runs: lane j walks run j
-                uint32_t pv[SC_LIGHT - 1];
+            for (int it = 0; it < SC_ITERS; ++it) { g.pp[it] = 0u; g.ww[it] = 0.f; }
+            if (Lx == 0 || Lx > SC_LMAX) return;                 // wave-uniform
+            const int b = e - ln;
+            const uint32_t delta = st - (uint32_t)b;
+            for (int f0 = 0; f0 < Lx; f0 += 64) mark[f0 + lane] = 0;
+            if (ln > 0) mark[b] = (unsigned char)(lane + 1);
+            int carry = 0;
 #pragma unroll
-                for (int rr = 0; rr < SC_LIGHT - 1; ++rr) pv[rr] = (light && len[qi] > rr) ? a.P[start[qi] + rr] : 0u;
-#pragma unroll
-                for (int rr = 0; rr < SC_LIGHT - 1; ++rr)
-                    if (light && len[qi] > rr) cert_add_posting(row, pv[rr], w[qi]);
-                // longer runs: the wave walks one run, 64 postings per step
-                uint64_t mm = __ballot(len[qi] >= SC_LIGHT);
-                while (mm) {
-                    const int j = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)start[qi], j);
-                    const int nj = __builtin_amdgcn_readlane(len[qi], j);
-                    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[qi]), j));
-                    for (int off = 0; off < nj; off += 64)
-                        if (off + lane < nj) cert_add_posting(row, a.P[base + (uint32_t)(off + lane)], wj);
+            for (int it = 0; it < SC_ITERS; ++it) {
+                if (it * 64 < Lx) {                              // wave-uniform
+                    uint32_t pidx;
+                    float wv;
+                    const bool live = map_step(mark, it, Lx, delta, wq, carry, pidx, wv);
+                    g.ww[it] = wv;
+                    if (live) g.pp[it] = a.P[pidx];
                 }
             }
+            g.carry = carry;
+        };
+        auto consume = [&](const unsigned char* mark, uint32_t* row, uint32_t st, int ln, float wq, const Staged& g) {
+            const int Lx = g.Lx;
+            if (Lx == 0) return;
+            if (Lx <= SC_LMAX) {
+#pragma unroll
+                for (int it = 0; it < SC_ITERS; ++it)
+                    if (it * 64 + lane < Lx) cert_add_posting(row, g.pp[it], g.ww[it]);
+                if (Lx > SC_ITERS * 64) {                        // the steps beyond the registers: load and add one by one
+                    const int e = sc_scan_add(ln);
+                    const uint32_t delta = st - (uint32_t)(e - ln);
+                    int carry = g.carry;
+                    for (int it = SC_ITERS; it * 64 < Lx; ++it) {
+                        uint32_t pidx;
+                        float wv;
+                        if (map_step(mark, it, Lx, delta, wq, carry, pidx, wv)) cert_add_posting(row, a.P[pidx], wv);
+                    }
+                }
+            } else {                                             // more postings than docs in the tile: run by run, 64 per step
+                uint64_t m = __ballot(ln > 0);
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t* pb = a.P + (uint32_t)__builtin_amdgcn_readlane((int)st, j);
+                    const int nj = __builtin_amdgcn_readlane(ln, j);
+                    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq), j));
+                    for (int off = 0; off < nj; off += 64)
+                        if (off + lane < nj) cert_add_posting(row, pb[off + lane], wj);
+                }
+            }
+        };
+        uint32_t start[4], nstart[4];
+        int len[4], nlen[4];
+        fetch_runs(tile0, start, len);
+        Staged sg[2];
+        stage(mark_base, start[0], len[0], w[0], sg[0]);
+        for (int tile = tile0; tile < tile1; ++tile) {
+            fetch_runs(tile + 1, nstart, nlen);                  // the next tile's table entries fly while this tile is scored
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                // item qi of this tile sits in set qi & 1; the next item (the next tile's query 0 after query 3) goes to the other one
+                if (qi < 3) stage(mark_base + ((qi + 1) & 1) * SC_MARK, start[qi + 1], len[qi + 1], w[qi + 1], sg[(qi + 1) & 1]);
+                else stage(mark_base, nstart[0], nlen[0], w[0], sg[0]);
+                consume(mark_base + (qi & 1) * SC_MARK, slots + (sw * 4 + qi) * SC_PITCH_W, start[qi], len[qi], w[qi], sg[qi & 1]);
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) { start[qi] = nstart[qi]; len[qi] = nlen[qi]; }
             __syncthreads();                                     // A
             __syncthreads();                                     // B
         }
@@ -743,7 +858,7 @@ static int cert_realloc(T*& p, size_t n) {
 template <int KS>
 static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
     static DeviceOnce lds_set;
-    const int lds = (int)(sizeof(uint32_t) * SC_QB * SC_PITCH_W + 1024 * KS);
+    const int lds = (int)(sizeof(uint32_t) * SC_QB * SC_PITCH_W + 1024 * KS + 8 * 2 * SC_MARK);
     if (bool* slot = lds_set.pending()) {
         SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         *slot = true;

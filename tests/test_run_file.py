@@ -87,10 +87,17 @@ def test_large_result_written_through_the_mapped_path(tmp_path):
     qids = [str(3 * i) for i in range(nq)]
     docs = np.arange(N).astype("U7")
     p = tmp_path / "big.json"
+    from scaling_retriever_amd import _lib
+    before = _lib.load().sr_run_writer_mapped_rounds()
     n = write_run_json(p, qids, scores, positions, docs, n_threads=8)
+    assert _lib.load().sr_run_writer_mapped_rounds() == before + 1       # the mapping was taken, not the pwrite fallback
     want = json.dumps(_reference_dict(qids, scores, positions, docs))
     assert n == len(want) >= (8 << 20) and os.path.getsize(p) == n
     assert p.read_text() == want
+    # one thread: pwrite, no mapping, same bytes
+    n1 = write_run_json(tmp_path / "big1.json", qids, scores, positions, docs, n_threads=1)
+    assert _lib.load().sr_run_writer_mapped_rounds() == before + 1 and n1 == n
+    assert (tmp_path / "big1.json").read_text() == want
 
 
 def test_counts_string_keys_and_escapes(tmp_path):

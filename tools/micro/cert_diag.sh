@@ -1,0 +1,21 @@
+#!/bin/bash
+# Timing-only variants of cert_score_kernel (never shipped; wrong results): which role sets the tile time?
+#   SC_DIAG bit 1: scatter waves add no postings   bit 2: matrix waves load / multiply nothing   bit 4: no table lookups
+# Build HERE (hipcc cross-compiles): bash tools/micro/cert_diag.sh build "0 1 2 3 5 7" ; run on the GPU box: bash tools/micro/cert_diag.sh run "0 1 2 3 5 7"
+set -e
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
+mkdir -p "$ROOT/build_var"
+cd "$ROOT/scaling_retriever_amd/csrc"
+if [ "$1" = build ]; then
+  OBJS=$(ls *.o | grep -v sparse_cert.o)
+  for d in $2; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSC_DIAG=$d $3 -c sparse_cert.hip -o "$ROOT/build_var/cert_$d.o"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build_var/libsr_cert_$d.so" "$ROOT/build_var/cert_$d.o" $OBJS
+  done
+else
+  cd "$ROOT"
+  for d in $2; do
+    echo "== SC_DIAG=$d"
+    SR_HIP_LIB="$ROOT/build_var/libsr_cert_$d.so" python tools/quick_sparse_cert.py --exact 0 --check 0 --steps 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['certified'])"
+  done
+fi
