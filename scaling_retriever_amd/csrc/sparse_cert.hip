@@ -491,16 +491,14 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
 #ifndef SC_DP
 #define SC_DP 8                       // A fragments in flight per matrix wave
 #endif
-#ifndef SC_ITERS
-#define SC_ITERS 8
-#endif
-// SC_ITERS:                    // 64-posting steps of a (query, tile) whose loads are issued ahead, in registers
-#define SC_LMAX 1024                  // postings of a (query, tile) the flattened walk handles (beyond: run by run)
-#define SC_MARK (SC_LMAX + 64)        // bytes of one mark buffer
+#define SC_ITERS 8                    // 64-posting steps of a (query, tile) item whose loads are issued a tile ahead, in registers
+#define SC_LMAX 1024                  // postings of an item the flattened walk handles (beyond: run by run)
+#define SC_MARK (SC_LMAX + 64)        // bytes of a wave's mark buffer
+#define SC_SLOT_WORDS (SC_QB * SC_PITCH_W)
 
 template <int KS>
 __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
-    extern __shared__ uint32_t slots[];                          // [SC_QB][SC_PITCH_W] | B fragments | mark buffers
+    extern __shared__ uint32_t slots[];                          // 2 x [SC_QB][SC_PITCH_W] | B fragments | mark buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroups of one doc chunk share blockIdx.x % 8, i.e. one XCD under round-robin placement: the chunk's tiles, postings
     // and table rows are pulled into ONE L2 (speed only, never correctness)
@@ -513,11 +511,13 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     const int tile0 = a.tile_begin + chunk * a.tiles_per_wg;
     const int tile_end = a.tile_begin + a.n_tiles_launch;
     const int tile1 = tile0 + a.tiles_per_wg < tile_end ? tile0 + a.tiles_per_wg : tile_end;
-    for (int i = tid; i < SC_QB * SC_PITCH_W; i += 1024) slots[i] = 0u;
+    for (int i = tid; i < 2 * SC_SLOT_WORDS; i += 1024) slots[i] = 0u;
     // the query block's MFMA B fragments (k-step s: 64 lanes x 8 halves), read back per k-step: they would cost 4 KS VGPRs
-    f16x8* const bl = reinterpret_cast<f16x8*>(slots + SC_QB * SC_PITCH_W);
+    f16x8* const bl = reinterpret_cast<f16x8*>(slots + 2 * SC_SLOT_WORDS);
     if (tid < KS * 64) bl[tid] = a.bfrag[(int64_t)qb * KS * 64 + tid];
     __syncthreads();
+    // The two roles work on DIFFERENT tiles: in step t the scatter waves add the rare postings of tile t into LDS tile t & 1 while
+    // the matrix waves multiply tile t - 1, add LDS tile (t - 1) & 1 to it, filter and clear it.  One barrier per step.
 
     if (wave < 8) {
         // ---------------- matrix waves: M blocks 4 wave .. 4 wave + 3 of every tile, one after the other ----------------
@@ -542,88 +542,79 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         f16x8 af[DP];
 #pragma unroll
         for (int i = 0; i < DP; ++i) af[i] = (SC_DIAG & 2) ? f16x8{} : *a_ptr(tile0, i);
+        __syncthreads();                                         // step tile0: the scatter waves fill LDS tile tile0 & 1
         for (int tile = tile0; tile < tile1; ++tile) {
             const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
-            f32x16 acc;
-            uint32_t key[4][8];
+            uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int mb = i / KS, ks = i % KS;
-                if (ks == 0) {
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x16 acc;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int i = mb * KS + ks;
+                    const f16x8 bq = bl[ks * 64 + lane];
+                    if (!(SC_DIAG & 2)) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);       // the ring's order is the point: hipcc otherwise re-packs the loads into one register and waits for each
+                        af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                const f16x8 bq = bl[ks * 64 + lane];
-                if (!(SC_DIAG & 2)) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq, acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);           // the ring's order is the point: hipcc otherwise re-packs the loads into one register and waits for each
-                    af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (ks == KS - 1) {
-                    // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1}
-#pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        key[mb][g] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(acc[2 * g] * cq, acc[2 * g + 1] * cq));
-                }
-            }
-            __syncthreads();                                     // A: the scatter waves' adds are in the LDS tile
-            uint32_t any = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+                // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1};
+                // + the LDS tile's fixed-point sums of the rare terms (4 consecutive docs: one 8-byte read), which are cleared
+                uint32_t key[8];
+                uint32_t any = 0;
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
-                    const int dl = (wave * 4 + j) * 32 + 8 * G + 4 * h;         // 4 consecutive docs: one 8-byte read
-                    uint32_t* sp = slots + qn * SC_PITCH_W + (dl >> 1);
+                    const int dl = (wave * 4 + mb) * 32 + 8 * G + 4 * h;
+                    uint32_t* sp = buf + qn * SC_PITCH_W + (dl >> 1);
                     const uint2 sv = *reinterpret_cast<const uint2*>(sp);
                     *reinterpret_cast<uint2*>(sp) = make_uint2(0u, 0u);
-                    const u16x2 k0 = __builtin_bit_cast(u16x2, key[j][2 * G]) + __builtin_bit_cast(u16x2, sv.x);
-                    const u16x2 k1 = __builtin_bit_cast(u16x2, key[j][2 * G + 1]) + __builtin_bit_cast(u16x2, sv.y);
-                    key[j][2 * G] = __builtin_bit_cast(uint32_t, k0);
-                    key[j][2 * G + 1] = __builtin_bit_cast(uint32_t, k1);
+                    const u16x2 k0 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G] * cq, acc[4 * G + 1] * cq) + __builtin_bit_cast(u16x2, sv.x);
+                    const u16x2 k1 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G + 2] * cq, acc[4 * G + 3] * cq) + __builtin_bit_cast(u16x2, sv.y);
+                    key[2 * G] = __builtin_bit_cast(uint32_t, k0);
+                    key[2 * G + 1] = __builtin_bit_cast(uint32_t, k1);
                     any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k0, __builtin_bit_cast(u16x2, cutm1x2)));
                     any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k1, __builtin_bit_cast(u16x2, cutm1x2)));
                 }
-            if (a.dump) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                if (a.dump) {
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
-                        const int64_t doc = (int64_t)tile * SC_DT + (wave * 4 + j) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1);
-                        *reinterpret_cast<uint32_t*>(a.dump + q * a.dump_stride + doc) = key[j][g];
+                        const int64_t doc = (int64_t)tile * SC_DT + (wave * 4 + mb) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1);
+                        *reinterpret_cast<uint32_t*>(a.dump + q * a.dump_stride + doc) = key[g];
                     }
-            }
-            if (any != 0) {                                      // rare once the threshold has risen: a few lanes per tile
-                int cnt = 0;
+                }
+                if (any != 0) {                                  // rare once the threshold has risen: a few lanes per tile
+                    int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        cnt += ((key[j][g] & 0xffffu) > cutm1 ? 1 : 0) + ((key[j][g] >> 16) > cutm1 ? 1 : 0);
-                int pos = atomicAdd(&a.cand_count[q], cnt);
-                if ((int64_t)pos + cnt > a.cand_cap) a.overflow[q] = 1;
-                uint64_t* dst = a.cand_keys + q * a.cand_cap;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int g = 0; g < 8; ++g) cnt += ((key[g] & 0xffffu) > cutm1 ? 1 : 0) + ((key[g] >> 16) > cutm1 ? 1 : 0);
+                    int pos = atomicAdd(&a.cand_count[q], cnt);
+                    if ((int64_t)pos + cnt > a.cand_cap) a.overflow[q] = 1;
+                    uint64_t* dst = a.cand_keys + q * a.cand_cap;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
-                        const uint32_t doc = (uint32_t)tile * SC_DT + (uint32_t)((wave * 4 + j) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1));
-                        const uint32_t lo = key[j][g] & 0xffffu, hi = key[j][g] >> 16;
+                        const uint32_t doc = (uint32_t)tile * SC_DT + (uint32_t)((wave * 4 + mb) * 32 + 8 * (g >> 1) + 4 * h + 2 * (g & 1));
+                        const uint32_t lo = key[g] & 0xffffu, hi = key[g] >> 16;
                         if (lo > cutm1) { if (pos < a.cand_cap) dst[pos] = sr_make_key((float)lo, doc); ++pos; }
                         if (hi > cutm1) { if (pos < a.cand_cap) dst[pos] = sr_make_key((float)hi, doc + 1u); ++pos; }
                     }
+                }
             }
-            __syncthreads();                                     // B: the LDS tile is zero again
+            __syncthreads();                                     // step tile + 1
         }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
         // The postings a (query, tile) item has to add are the runs of its rare terms inside the tile: len_j postings from
         // start_j on (table S).  They are walked FLATTENED: posting f of the item belongs to the run r with b_r <= f < b_r + len_r
         // (b = exclusive prefix of the lengths); r comes from a byte array in LDS holding r + 1 at position b_r (zero elsewhere)
-        // and a wave-wide running maximum, 64 postings per step, every lane busy whatever the run lengths are.  The loads of an
-        // item are issued one item ahead (the next query's, or the next tile's first query's) into a second set of registers.
+        // and a wave-wide running maximum, 64 postings per step, every lane busy whatever the run lengths are.  An item's loads
+        // are issued ONE TILE AHEAD (a gather over 4.5 GB takes 2-3 us under load): query slot qi of the wave owns a set of
+        // registers (SC_ITERS packed postings + their run ids, 6 bits each); in step t the wave adds what was loaded for tile t and
+        // issues the loads of tile t + 1; the table entries are fetched two tiles ahead.
         const int sw = wave - 8;
-        unsigned char* const mark_base = reinterpret_cast<unsigned char*>(bl + KS * 64) + sw * 2 * SC_MARK;
+        unsigned char* const mark = reinterpret_cast<unsigned char*>(bl + KS * 64) + sw * SC_MARK;
         int32_t term[4];
         float w[4];
 #pragma unroll
@@ -641,58 +632,62 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 ln[qi] = (SC_DIAG & 1) ? 0 : (int)(se.y - se.x);
             }
         };
-        // mapping of flat positions [64 it, 64 it + 64) of an item to (posting index, weight); carry = running maximum so far
-        auto map_step = [&](const unsigned char* mark, int it, int Lx, uint32_t delta, float wq, int& carry, uint32_t& pidx, float& wv) -> bool {
-            const int f = it * 64 + lane;
-            int v = max((int)mark[f], carry);
+        // run id of the flat positions [64 it, 64 it + 64) of an item; carry = running maximum so far
+        auto run_of = [&](int it, int& carry) -> int {
+            int v = max((int)mark[it * 64 + lane], carry);
             v = sc_scan_max(v);
             carry = __builtin_amdgcn_readlane(v, 63);
-            const int rr = (v - 1) & 63;
-            pidx = (uint32_t)f + (uint32_t)__shfl((int)delta, rr);
-            wv = __shfl(wq, rr);
-            return f < Lx;
+            return (v - 1) & 63;
         };
-        struct Staged { uint32_t pp[SC_ITERS]; float ww[SC_ITERS]; int Lx; int carry; };
-        auto stage = [&](unsigned char* mark, uint32_t st, int ln, float wq, Staged& g) {
+        auto write_marks = [&](int Lx, int b, int ln) {
+            for (int f0 = 0; f0 < Lx; f0 += 64) mark[f0 + lane] = 0;
+            if (ln > 0) mark[b] = (unsigned char)(lane + 1);
+        };
+        struct Staged { uint32_t pp[SC_ITERS]; uint32_t rr[SC_ITERS / 4]; int Lx; };
+        auto stage = [&](uint32_t st, int ln, Staged& g) {
             const int e = sc_scan_add(ln);
             const int Lx = __builtin_amdgcn_readlane(e, 63);
             g.Lx = Lx;
-            g.carry = 0;
 #pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) { g.pp[it] = 0u; g.ww[it] = 0.f; }
+            for (int it = 0; it < SC_ITERS; ++it) g.pp[it] = 0u;
+#pragma unroll
+            for (int it = 0; it < SC_ITERS / 4; ++it) g.rr[it] = 0u;
             if (Lx == 0 || Lx > SC_LMAX) return;                 // wave-uniform
             const int b = e - ln;
             const uint32_t delta = st - (uint32_t)b;
-            for (int f0 = 0; f0 < Lx; f0 += 64) mark[f0 + lane] = 0;
-            if (ln > 0) mark[b] = (unsigned char)(lane + 1);
+            write_marks(Lx, b, ln);
             int carry = 0;
 #pragma unroll
             for (int it = 0; it < SC_ITERS; ++it) {
                 if (it * 64 < Lx) {                              // wave-uniform
-                    uint32_t pidx;
-                    float wv;
-                    const bool live = map_step(mark, it, Lx, delta, wq, carry, pidx, wv);
-                    g.ww[it] = wv;
-                    if (live) g.pp[it] = a.P[pidx];
+                    const int rr = run_of(it, carry);
+                    g.rr[it / 4] |= (uint32_t)rr << (8 * (it % 4));
+                    const uint32_t pidx = (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);
+                    if (it * 64 + lane < Lx) g.pp[it] = a.P[pidx];
                 }
             }
-            g.carry = carry;
         };
-        auto consume = [&](const unsigned char* mark, uint32_t* row, uint32_t st, int ln, float wq, const Staged& g) {
+        auto consume = [&](uint32_t* row, uint32_t st, int ln, float wq, const Staged& g) {
             const int Lx = g.Lx;
             if (Lx == 0) return;
             if (Lx <= SC_LMAX) {
 #pragma unroll
                 for (int it = 0; it < SC_ITERS; ++it)
-                    if (it * 64 + lane < Lx) cert_add_posting(row, g.pp[it], g.ww[it]);
-                if (Lx > SC_ITERS * 64) {                        // the steps beyond the registers: load and add one by one
+                    if (it * 64 < Lx) {                          // wave-uniform
+                        const float wv = __shfl(wq, (int)((g.rr[it / 4] >> (8 * (it % 4))) & 63u));
+                        if (it * 64 + lane < Lx) cert_add_posting(row, g.pp[it], wv);
+                    }
+                if (Lx > SC_ITERS * 64) {                        // the steps beyond the registers: marks again, then load and add one by one
                     const int e = sc_scan_add(ln);
-                    const uint32_t delta = st - (uint32_t)(e - ln);
-                    int carry = g.carry;
-                    for (int it = SC_ITERS; it * 64 < Lx; ++it) {
-                        uint32_t pidx;
-                        float wv;
-                        if (map_step(mark, it, Lx, delta, wq, carry, pidx, wv)) cert_add_posting(row, a.P[pidx], wv);
+                    const int b = e - ln;
+                    const uint32_t delta = st - (uint32_t)b;
+                    write_marks(Lx, b, ln);
+                    int carry = 0;
+                    for (int it = 0; it * 64 < Lx; ++it) {
+                        const int rr = run_of(it, carry);
+                        const uint32_t pidx = (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);     // shuffles with every lane active
+                        const float wv = __shfl(wq, rr);
+                        if (it >= SC_ITERS && it * 64 + lane < Lx) cert_add_posting(row, a.P[pidx], wv);
                     }
                 }
             } else {                                             // more postings than docs in the tile: run by run, 64 per step
@@ -708,25 +703,26 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 }
             }
         };
-        uint32_t start[4], nstart[4];
-        int len[4], nlen[4];
+        uint32_t start[4], nstart[4], fstart[4];
+        int len[4], nlen[4], flen[4];
+        Staged sg[4];
         fetch_runs(tile0, start, len);
-        Staged sg[2];
-        stage(mark_base, start[0], len[0], w[0], sg[0]);
+        fetch_runs(tile0 + 1, nstart, nlen);
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) stage(start[qi], len[qi], sg[qi]);
         for (int tile = tile0; tile < tile1; ++tile) {
-            fetch_runs(tile + 1, nstart, nlen);                  // the next tile's table entries fly while this tile is scored
+            uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
+            fetch_runs(tile + 2, fstart, flen);                  // table entries two tiles ahead
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) {
-                // item qi of this tile sits in set qi & 1; the next item (the next tile's query 0 after query 3) goes to the other one
-                if (qi < 3) stage(mark_base + ((qi + 1) & 1) * SC_MARK, start[qi + 1], len[qi + 1], w[qi + 1], sg[(qi + 1) & 1]);
-                else stage(mark_base, nstart[0], nlen[0], w[0], sg[0]);
-                consume(mark_base + (qi & 1) * SC_MARK, slots + (sw * 4 + qi) * SC_PITCH_W, start[qi], len[qi], w[qi], sg[qi & 1]);
+                consume(buf + (sw * 4 + qi) * SC_PITCH_W, start[qi], len[qi], w[qi], sg[qi]);
+                stage(nstart[qi], nlen[qi], sg[qi]);             // tile + 1 (lengths 0 behind the last tile)
             }
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) { start[qi] = nstart[qi]; len[qi] = nlen[qi]; }
-            __syncthreads();                                     // A
-            __syncthreads();                                     // B
+            for (int qi = 0; qi < 4; ++qi) { start[qi] = nstart[qi]; len[qi] = nlen[qi]; nstart[qi] = fstart[qi]; nlen[qi] = flen[qi]; }
+            __syncthreads();                                     // step tile + 1
         }
+        __syncthreads();                                         // the matrix waves' last step
     }
 }
 
@@ -858,7 +854,7 @@ static int cert_realloc(T*& p, size_t n) {
 template <int KS>
 static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
     static DeviceOnce lds_set;
-    const int lds = (int)(sizeof(uint32_t) * SC_QB * SC_PITCH_W + 1024 * KS + 8 * 2 * SC_MARK);
+    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_MARK);
     if (bool* slot = lds_set.pending()) {
         SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         *slot = true;
