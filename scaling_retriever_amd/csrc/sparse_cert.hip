@@ -44,7 +44,7 @@
 #define SC_TMAX 256                   // dense terms (MFMA K), at most
 #define SC_FWD_MAX 1024               // postings per doc the forward-index sort handles
 #ifndef SC_DIAG
-#define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups
+#define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups, 8 no LDS adds, 16 plain LDS read-modify-write
 #endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -60,6 +60,9 @@ struct SparseCert {
     _Float16* d16 = nullptr;          // [n_tiles][SC_MB][KS][64][8]: MFMA A fragments (row = doc, k = dense slot); a matrix wave streams 4 KS KB per tile
     uint32_t* P = nullptr;            // [nnz] packed postings: (doc % SC_DT / 2) * 4 | doc % 2  (byte offset of the doc's LDS word | its half) | fp16(v * vscale) << 16
     uint32_t* S = nullptr;            // [V][n_tiles + 1]: first posting (absolute index) of term t with doc >= tile * SC_DT
+    uint32_t* E = nullptr;            // [V][e_stride]: the run of term t inside tile i in one word: 0 = empty, a packed posting | 2 = its only
+                                      // posting, 0xffff0000 | length = two or more postings (in P from the running start on)
+    int e_stride = 0;                 // n_tiles rounded up to 4, + 4: 16-byte rows, a 16-byte read never leaves its row
     int64_t* fwd_indptr = nullptr;    // doc-major forward index, terms ascending inside a doc
     int32_t* fwd_term = nullptr;
     float* fwd_val = nullptr;
@@ -86,6 +89,7 @@ struct SparseCert {
     uint16_t* dump = nullptr;         // debug: [nq_pad][n_tiles * SC_DT] keys of the last search (sr_sparse_index_cert_debug)
     int64_t dump_nq = 0;
     bool want_dump = false;
+    unsigned long long* d_stamps = nullptr;   // dev switch SR_CERT_STAMPS
 };
 
 // ------------------------------------------------------------------------------------------------------- build ---
@@ -146,6 +150,23 @@ __global__ __launch_bounds__(256) void cert_s_table_kernel(const int64_t* __rest
         const int prev = p > b ? (int)(doc_ids[p - 1] / SC_DT) : -1;
         const int cur = p < e ? (int)(doc_ids[p] / SC_DT) : n_tiles;
         for (int i = prev + 1; i <= cur; ++i) row[i] = (uint32_t)p;
+    }
+}
+
+// E[t][i] from the table of starts and the packed postings (see SparseCert::E)
+__global__ __launch_bounds__(256) void cert_e_table_kernel(const uint32_t* __restrict__ S, const uint32_t* __restrict__ P, int n_tiles, int e_stride,
+                                                           uint32_t* __restrict__ E) {
+    const int64_t t = blockIdx.x;
+    const uint32_t* srow = S + t * (int64_t)(n_tiles + 1);
+    uint32_t* erow = E + t * (int64_t)e_stride;
+    for (int i = threadIdx.x; i < e_stride; i += 256) {
+        uint32_t e = 0u;
+        if (i < n_tiles) {
+            const uint32_t b = srow[i], n = srow[i + 1] - b;
+            if (n == 1u) e = P[b] | 2u;
+            else if (n >= 2u) e = 0xffff0000u | (n < 0xffffu ? n : 0xffffu);
+        }
+        erow[i] = e;
     }
 }
 
@@ -210,7 +231,14 @@ __global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __res
 
 void sparse_cert_destroy(SparseCert* c) {
     if (!c) return;
-    void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
+    if (c->d_stamps) {          // diagnostic: mean cycles per tile step of the sampled waves
+        unsigned long long h[8] = {0};
+        if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] && h[6])
+            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f barrier %.0f (%llu steps)\n",
+                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[5] / h[6], h[6]);
+        (void)hipFree(c->d_stamps);
+    }
+    void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
                     c->cq, c->sq, c->n_rare, c->n_qt, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -282,12 +310,15 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         }
         const size_t d16_halves = (size_t)c->n_tiles * (size_t)c->T * SC_DT;
         const size_t s_words = (size_t)V * (size_t)(c->n_tiles + 1);
+        c->e_stride = (c->n_tiles + 3) / 4 * 4 + 4;
+        const size_t e_words = (size_t)V * (size_t)c->e_stride;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { rc = SR_ERR_HIP; break; }
-        const size_t need = d16_halves * 2 + (size_t)nnz * 12 + s_words * 4 + (size_t)N * 16 + (64u << 20);
+        const size_t need = d16_halves * 2 + (size_t)nnz * 12 + (s_words + e_words) * 4 + (size_t)N * 16 + (64u << 20);
         if (need > free_b / 2) break;             // side structures may take at most half of what is free
         if (hipMalloc((void**)&c->dslot, sizeof(int32_t) * (size_t)V) != hipSuccess || hipMalloc((void**)&c->d16, d16_halves * 2) != hipSuccess ||
-            hipMalloc((void**)&c->P, sizeof(uint32_t) * (size_t)nnz) != hipSuccess || hipMalloc((void**)&c->S, s_words * 4) != hipSuccess ||
+            hipMalloc((void**)&c->P, sizeof(uint32_t) * ((size_t)nnz + 4)) != hipSuccess || hipMalloc((void**)&c->S, s_words * 4) != hipSuccess ||
+            hipMalloc((void**)&c->E, e_words * 4) != hipSuccess ||
             hipMalloc((void**)&c->fwd_indptr, sizeof(int64_t) * (size_t)(N + 1)) != hipSuccess ||
             hipMalloc((void**)&c->fwd_term, sizeof(int32_t) * (size_t)nnz) != hipSuccess ||
             hipMalloc((void**)&c->fwd_val, sizeof(float) * (size_t)nnz) != hipSuccess ||
@@ -307,6 +338,8 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         hipLaunchKernelGGL(cert_pack_postings_kernel, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, s, idx->doc_ids, idx->vals, nnz,
                            c->vscale, c->P);
         hipLaunchKernelGGL(cert_s_table_kernel, dim3((unsigned)V), dim3(256), 0, s, idx->indptr, idx->doc_ids, c->n_tiles, c->S);
+        if (hipMemsetAsync(c->P + nnz, 0, 4 * sizeof(uint32_t), s) != hipSuccess) break;       // an 8-byte read of the last posting stays inside
+        hipLaunchKernelGGL(cert_e_table_kernel, dim3((unsigned)V), dim3(256), 0, s, c->S, c->P, c->n_tiles, c->e_stride, c->E);
         hipLaunchKernelGGL(cert_fwd_count_kernel, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, s, idx->doc_ids, nnz, d_cnt);
         hipLaunchKernelGGL(cert_i32_to_i64_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, s, d_cnt, N, d_cnt64);
         if (hipGetLastError() != hipSuccess) break;
@@ -444,6 +477,8 @@ struct CertArgs {
     const uint32_t* P;
     const uint32_t* S;
     int s_stride;            // n_tiles + 1
+    const uint32_t* E;
+    int e_stride;
     const f16x8* bfrag;
     const int32_t* rare_term;
     const float* rare_w;
@@ -456,6 +491,7 @@ struct CertArgs {
     uint8_t* overflow;
     int tile_begin, n_tiles_launch, tiles_per_wg, n_qblocks;
     uint16_t* dump;          // debug: [nq_pad][dump_stride] keys
+    unsigned long long* stamps;   // dev switch SR_CERT_STAMPS: [8] cycle sums per phase of sampled waves
     int64_t dump_stride;
 };
 
@@ -463,7 +499,10 @@ struct CertArgs {
 __device__ __forceinline__ void cert_add_posting(uint32_t* row, uint32_t p, float w) {
     const float v = (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
     const uint32_t c = (uint32_t)(v * w + 1.0f);                 // in (x, x + 1]: rounded up, never below the real contribution
-    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(row) + (p & 0xfffcu)), c << ((p & 1u) * 16u));
+    uint32_t* const wp = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(row) + (p & 0xfffcu));
+    if (SC_DIAG & 8) { if (c == 0xffffffffu) *wp = c; }          // timing only: no LDS traffic
+    else if (SC_DIAG & 16) *wp = *wp + (c << ((p & 1u) * 16u));  // timing only: plain read-modify-write
+    else atomicAdd(wp, c << ((p & 1u) * 16u));
 }
 
 // wave-wide inclusive scans on the DPP row shifts / row broadcasts of gfx9 (6 VALU instructions, no LDS)
@@ -491,8 +530,8 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
 #ifndef SC_DP
 #define SC_DP 8                       // A fragments in flight per matrix wave
 #endif
-#define SC_ITERS 8                    // 64-posting steps of a (query, tile) item whose loads are issued a tile ahead, in registers
-#define SC_LMAX 1024                  // postings of an item the flattened walk handles (beyond: run by run)
+#define SC_ITERS 4                    // 64-lane steps (two postings per lane) of a (query, tile) item whose loads are issued a tile ahead, in registers
+#define SC_LMAX 1024                  // posting PAIRS of an item the flattened walk handles (beyond: run by run)
 #define SC_MARK (SC_LMAX + 64)        // bytes of a wave's mark buffer
 #define SC_SLOT_WORDS (SC_QB * SC_PITCH_W)
 
@@ -543,6 +582,8 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 #pragma unroll
         for (int i = 0; i < DP; ++i) af[i] = (SC_DIAG & 2) ? f16x8{} : *a_ptr(tile0, i);
         __syncthreads();                                         // step tile0: the scatter waves fill LDS tile tile0 & 1
+        const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
+        unsigned long long st_w = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
             const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
             uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
@@ -602,95 +643,127 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                     }
                 }
             }
+            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_w += now - st_t; st_t = now; }
             __syncthreads();                                     // step tile + 1
+            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
+        if (st_on && lane == 0) { atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
-        // The postings a (query, tile) item has to add are the runs of its rare terms inside the tile: len_j postings from
-        // start_j on (table S).  They are walked FLATTENED: posting f of the item belongs to the run r with b_r <= f < b_r + len_r
-        // (b = exclusive prefix of the lengths); r comes from a byte array in LDS holding r + 1 at position b_r (zero elsewhere)
-        // and a wave-wide running maximum, 64 postings per step, every lane busy whatever the run lengths are.  An item's loads
-        // are issued ONE TILE AHEAD (a gather over 4.5 GB takes 2-3 us under load): query slot qi of the wave owns a set of
-        // registers (SC_ITERS packed postings + their run ids, 6 bits each); in step t the wave adds what was loaded for tile t and
-        // issues the loads of tile t + 1; the table entries are fetched two tiles ahead.
+        // What a (query, tile) item adds: per rare term the run of its postings inside the tile.  Table E gives the run in ONE word per
+        // (term, tile) - 16 bytes = 4 consecutive tiles per load, a cache line = 16 tiles: nothing, the single posting itself, or a
+        // length (postings in P from the term's running start on; the start at the chunk's first tile comes from table S, once).
+        //   single postings: lane j adds its own, one predicated LDS add per item;
+        //   longer runs are walked FLATTENED, two postings per lane: pair f of the item belongs to the run r with b_r <= f < b_r + np_r
+        //   (np = pairs of a run, b = exclusive prefix); r comes from a byte array in LDS holding r + 1 at position b_r (bit 7: the
+        //   pair is the odd tail of its run) and a wave-wide running maximum - every lane busy whatever the run lengths are.
+        // An item's loads are issued ONE TILE AHEAD (gathers over 4.5 GB take 2-3 us under load) and UNCONDITIONALLY (idle lanes read
+        // entry 0): the number of vector-memory instructions per stage is a constant, so the compiler can wait for an item's loads with
+        // a counted vmcnt that leaves everything issued after them in flight.
         const int sw = wave - 8;
         unsigned char* const mark = reinterpret_cast<unsigned char*>(bl + KS * 64) + sw * SC_MARK;
         int32_t term[4];
         float w[4];
+        uint32_t cur[4];            // running start (index into P) of every rare term's next run, at the tile being staged
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const int64_t q = (int64_t)qb * SC_QB + sw * 4 + qi;
             term[qi] = a.rare_term[q * SC_MAXR + lane];
             w[qi] = a.rare_w[q * SC_MAXR + lane];
+            cur[qi] = term[qi] >= 0 ? a.S[(int64_t)term[qi] * a.s_stride + tile0] : 0u;
         }
-        auto fetch_runs = [&](int tile, uint32_t (&st)[4], int (&ln)[4]) {
+        // the E words of tile pair g (tiles 2 g, 2 g + 1); pairs behind the chunk read the row's zero padding or a later chunk's words
+        // (never used: the per-tile guard below)
+        auto load_group = [&](int g, uint2 (&e2)[4]) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                u32x2_u se = {0u, 0u};
-                if (!(SC_DIAG & 4) && term[qi] >= 0 && tile < tile1) se = *reinterpret_cast<const u32x2_u*>(a.S + (int64_t)term[qi] * a.s_stride + tile);
-                st[qi] = se.x;
-                ln[qi] = (SC_DIAG & 1) ? 0 : (int)(se.y - se.x);
-            }
+            for (int qi = 0; qi < 4; ++qi)
+                e2[qi] = *reinterpret_cast<const uint2*>(a.E + (int64_t)(term[qi] >= 0 && !(SC_DIAG & 4) ? term[qi] : 0) * a.e_stride + 2 * g);
         };
-        // run id of the flat positions [64 it, 64 it + 64) of an item; carry = running maximum so far
-        auto run_of = [&](int it, int& carry) -> int {
-            int v = max((int)mark[it * 64 + lane], carry);
-            v = sc_scan_max(v);
+        auto run_of = [&](int it, int& carry, int& odd) -> int {
+            const int m = (int)mark[it * 64 + lane];
+            odd = m >> 7;
+            int v = sc_scan_max(max(m & 0x7f, carry));
             carry = __builtin_amdgcn_readlane(v, 63);
             return (v - 1) & 63;
         };
-        auto write_marks = [&](int Lx, int b, int ln) {
-            for (int f0 = 0; f0 < Lx; f0 += 64) mark[f0 + lane] = 0;
-            if (ln > 0) mark[b] = (unsigned char)(lane + 1);
-        };
-        struct Staged { uint32_t pp[SC_ITERS]; uint32_t rr[SC_ITERS / 4]; int Lx; };
-        auto stage = [&](uint32_t st, int ln, Staged& g) {
-            const int e = sc_scan_add(ln);
-            const int Lx = __builtin_amdgcn_readlane(e, 63);
-            g.Lx = Lx;
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) g.pp[it] = 0u;
-#pragma unroll
-            for (int it = 0; it < SC_ITERS / 4; ++it) g.rr[it] = 0u;
-            if (Lx == 0 || Lx > SC_LMAX) return;                 // wave-uniform
-            const int b = e - ln;
-            const uint32_t delta = st - (uint32_t)b;
-            write_marks(Lx, b, ln);
-            int carry = 0;
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) {
-                if (it * 64 < Lx) {                              // wave-uniform
-                    const int rr = run_of(it, carry);
-                    g.rr[it / 4] |= (uint32_t)rr << (8 * (it % 4));
-                    const uint32_t pidx = (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);
-                    if (it * 64 + lane < Lx) g.pp[it] = a.P[pidx];
-                }
+        auto write_marks = [&](int Lp, int b, int np, int ln) {
+            for (int f0 = 0; f0 < Lp; f0 += 64) mark[f0 + lane] = 0;
+            if (np == 1) mark[b] = (unsigned char)((lane + 1) | ((ln & 1) << 7));
+            else if (np > 1) {
+                mark[b] = (unsigned char)(lane + 1);
+                if (ln & 1) mark[b + np - 1] = 0x80;
             }
         };
-        auto consume = [&](uint32_t* row, uint32_t st, int ln, float wq, const Staged& g) {
-            const int Lx = g.Lx;
-            if (Lx == 0) return;
-            if (Lx <= SC_LMAX) {
+        struct Staged { uint2 pp[SC_ITERS]; uint32_t rr; int Lp; };
+        // ln = postings of the lane's run when it has two or more (else 0), st = its first posting
+        auto stage = [&](uint32_t st, int ln, Staged& g) {
+            const int np = (ln + 1) >> 1;
+            const int e = sc_scan_add(np);
+            const int Lp = __builtin_amdgcn_readlane(e, 63);
+            g.Lp = Lp;
+            const int b = e - np;
+            const uint32_t delta = st - 2u * (uint32_t)b;        // posting index of pair f of run r: 2 f + delta_r
+            const bool flat = Lp > 0 && Lp <= SC_LMAX;           // wave-uniform
+            if (flat) write_marks(Lp, b, np, ln);
+            int rid[SC_ITERS];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) rid[it] = (flat && it * 64 < Lp) ? (int)mark[it * 64 + lane] : 0;
+            int carry = 0;
+            g.rr = 0u;
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) {
+                if (flat && it * 64 < Lp) {                      // wave-uniform
+                    const int odd = rid[it] >> 7;
+                    const int v = sc_scan_max(max(rid[it] & 0x7f, carry));
+                    carry = __builtin_amdgcn_readlane(v, 63);
+                    rid[it] = (v - 1) & 63;
+                    g.rr |= (uint32_t)(rid[it] | (odd << 7)) << (8 * it);
+                }
+            }
+            uint32_t pidx[SC_ITERS];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) pidx[it] = (uint32_t)__shfl((int)delta, rid[it]);
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) {
+                const uint32_t pi = (flat && it * 64 + lane < Lp) ? pidx[it] + 2u * (uint32_t)(it * 64 + lane) : 0u;
+                const u32x2_u v2 = *reinterpret_cast<const u32x2_u*>(a.P + pi);
+                g.pp[it] = make_uint2(v2.x, v2.y);
+            }
+        };
+        // e = the item's E word of the lane's term (its single posting, if any), st / ln as for stage (the paths beyond the registers)
+        auto consume = [&](uint32_t* row, uint32_t e, uint32_t st, int ln, float wq, const Staged& g) {
+            if (e != 0u && (e >> 16) != 0xffffu) cert_add_posting(row, e, wq);
+            const int Lp = g.Lp;
+            if (Lp == 0) return;
+            if (Lp <= SC_LMAX) {
+                float wv[SC_ITERS];
+#pragma unroll
+                for (int it = 0; it < SC_ITERS; ++it) wv[it] = __shfl(wq, (int)((g.rr >> (8 * it)) & 63u));
 #pragma unroll
                 for (int it = 0; it < SC_ITERS; ++it)
-                    if (it * 64 < Lx) {                          // wave-uniform
-                        const float wv = __shfl(wq, (int)((g.rr[it / 4] >> (8 * (it % 4))) & 63u));
-                        if (it * 64 + lane < Lx) cert_add_posting(row, g.pp[it], wv);
+                    if (it * 64 + lane < Lp) {
+                        cert_add_posting(row, g.pp[it].x, wv[it]);
+                        if (!((g.rr >> (8 * it + 7)) & 1u)) cert_add_posting(row, g.pp[it].y, wv[it]);
                     }
-                if (Lx > SC_ITERS * 64) {                        // the steps beyond the registers: marks again, then load and add one by one
-                    const int e = sc_scan_add(ln);
-                    const int b = e - ln;
-                    const uint32_t delta = st - (uint32_t)b;
-                    write_marks(Lx, b, ln);
+                if (Lp > SC_ITERS * 64) {                        // the steps beyond the registers: marks again, then load and add one by one
+                    const int np = (ln + 1) >> 1;
+                    const int e2 = sc_scan_add(np);
+                    const int b = e2 - np;
+                    const uint32_t delta = st - 2u * (uint32_t)b;
+                    write_marks(Lp, b, np, ln);
                     int carry = 0;
-                    for (int it = 0; it * 64 < Lx; ++it) {
-                        const int rr = run_of(it, carry);
-                        const uint32_t pidx = (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);     // shuffles with every lane active
-                        const float wv = __shfl(wq, rr);
-                        if (it >= SC_ITERS && it * 64 + lane < Lx) cert_add_posting(row, a.P[pidx], wv);
+                    for (int it = 0; it * 64 < Lp; ++it) {
+                        int odd;
+                        const int rr = run_of(it, carry, odd);
+                        const uint32_t pi = 2u * (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);     // shuffles with every lane active
+                        const float wv1 = __shfl(wq, rr);
+                        if (it >= SC_ITERS && it * 64 + lane < Lp) {
+                            cert_add_posting(row, a.P[pi], wv1);
+                            if (!odd) cert_add_posting(row, a.P[pi + 1u], wv1);
+                        }
                     }
                 }
-            } else {                                             // more postings than docs in the tile: run by run, 64 per step
+            } else {                                             // more pairs than the mark buffer holds: run by run, 64 postings per step
                 uint64_t m = __ballot(ln > 0);
                 while (m) {
                     const int j = __builtin_ctzll(m);
@@ -703,25 +776,56 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 }
             }
         };
-        uint32_t start[4], nstart[4], fstart[4];
-        int len[4], nlen[4], flen[4];
-        Staged sg[4];
-        fetch_runs(tile0, start, len);
-        fetch_runs(tile0 + 1, nstart, nlen);
+        auto multi_len = [&](uint32_t e) -> int { return (e >> 16) == 0xffffu ? (int)(e & 0xffffu) : 0; };
+        auto run_len = [&](uint32_t e) -> uint32_t { return (e >> 16) == 0xffffu ? (e & 0xffffu) : (e != 0u ? 1u : 0u); };
+        // E words: ecur = the pair holding the tile being STAGED, enext = the pair behind it (loaded a pair ahead)
+        uint2 ecur[4], enext[4];
+        load_group(tile0 >> 1, ecur);
+        load_group((tile0 >> 1) + 1, enext);
+        if (tile0 & 1) {
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi) stage(start[qi], len[qi], sg[qi]);
+            for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
+        }
+        uint32_t e_cons[4];
+        Staged sg[4];
+        // stages query slot qi for `tile` from ecur.x (zero behind the chunk)
+        auto stage_slot = [&](int tile, int qi) {
+            const uint32_t e = (tile < tile1 && term[qi] >= 0 && !(SC_DIAG & 1)) ? ecur[qi].x : 0u;
+            e_cons[qi] = e;
+            stage(cur[qi], multi_len(e), sg[qi]);
+            cur[qi] += run_len(e);
+        };
+        auto advance_queue = [&](int tile) {
+            if (tile & 1) {                                      // wave-uniform: the next pair becomes current, the one behind it is fetched
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) ecur[qi] = enext[qi];
+                load_group((tile >> 1) + 2, enext);
+            } else {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
+            }
+        };
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) stage_slot(tile0, qi);
+        advance_queue(tile0);
+        const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 8;
+        unsigned long long st_c = 0, st_s = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
             uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
-            fetch_runs(tile + 2, fstart, flen);                  // table entries two tiles ahead
+            // per query slot: add the item whose loads were issued a step ago, then stage the slot for the next tile
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) {
-                consume(buf + (sw * 4 + qi) * SC_PITCH_W, start[qi], len[qi], w[qi], sg[qi]);
-                stage(nstart[qi], nlen[qi], sg[qi]);             // tile + 1 (lengths 0 behind the last tile)
+                // cur is the start of the NEXT tile's run until the slot is staged again: this item's run began run_len earlier
+                consume(buf + (sw * 4 + qi) * SC_PITCH_W, e_cons[qi], cur[qi] - run_len(e_cons[qi]), multi_len(e_cons[qi]), w[qi], sg[qi]);
+                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_c += now - st_t; st_t = now; }
+                stage_slot(tile + 1, qi);
+                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_s += now - st_t; st_t = now; }
             }
-#pragma unroll
-            for (int qi = 0; qi < 4; ++qi) { start[qi] = nstart[qi]; len[qi] = nlen[qi]; nstart[qi] = fstart[qi]; nlen[qi] = flen[qi]; }
+            advance_queue(tile + 1);
             __syncthreads();                                     // step tile + 1
+            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
+        if (st_on && lane == 0) { atomicAdd(&a.stamps[0], st_c); atomicAdd(&a.stamps[1], st_s); atomicAdd(&a.stamps[2], st_b); atomicAdd(&a.stamps[3], st_n); }
         __syncthreads();                                         // the matrix waves' last step
     }
 }
@@ -913,12 +1017,17 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     SR_TRY(topk_reset(c->ws, nq_pad, s));
     CertArgs a;
     a.d16 = reinterpret_cast<const f16x8*>(c->d16);
-    a.P = c->P; a.S = c->S; a.s_stride = c->n_tiles + 1;
+    a.P = c->P; a.S = c->S; a.s_stride = c->n_tiles + 1; a.E = c->E; a.e_stride = c->e_stride;
     a.bfrag = reinterpret_cast<const f16x8*>(c->bfrag);
     a.rare_term = c->rare_term; a.rare_w = c->rare_w; a.cq = c->cq; a.tau = c->ws.tau; a.nq = nq;
     a.cand_keys = c->ws.cand_keys; a.cand_count = c->ws.cand_count; a.cand_cap = c->ws.cand_cap; a.overflow = c->overflow;
     a.n_qblocks = n_qblocks;
     a.dump = c->want_dump ? c->dump : nullptr;
+    if (sr_dev_getenv("SR_CERT_STAMPS") && !c->d_stamps) {
+        SR_CHECK_HIP(hipMalloc((void**)&c->d_stamps, 8 * 8));
+        SR_CHECK_HIP(hipMemsetAsync(c->d_stamps, 0, 8 * 8, s));
+    }
+    a.stamps = c->d_stamps;
     a.dump_stride = dump_stride;
     int64_t step = 1;
     for (int64_t t0 = 0; t0 < c->n_tiles;) {

@@ -16,6 +16,10 @@ else
   cd "$ROOT"
   for d in $2; do
     echo "== SC_DIAG=$d"
-    SR_HIP_LIB="$ROOT/build_var/libsr_cert_$d.so" python tools/quick_sparse_cert.py --exact 0 --check 0 --steps 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['certified'])"
+    SR_CERT_STAMPS=1 SR_HIP_LIB="$ROOT/build_var/libsr_cert_$d.so" python tools/quick_sparse_cert.py --exact 0 --check 0 --steps 2 2>&1 | grep -v amdgpu.ids | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'): print(json.loads(l)['certified'])
+    elif 'stamps' in l: print(l.strip())"
   done
 fi
