@@ -50,6 +50,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 struct SparseCert {
     int T = 0, KS = 0;                // dense terms (multiple of 16) and MFMA k-steps
@@ -75,6 +76,7 @@ struct SparseCert {
     float* sq = nullptr;              // [nq_pad]: score -> [0, 0.98]
     int32_t* n_rare = nullptr;        // [nq_pad]
     int32_t* n_qt = nullptr;          // [nq_pad]
+    int32_t* n_drop = nullptr;        // [nq_pad] rare terms left out of stage 1 (weight below fp16's normal range)
     uint8_t* elig = nullptr;          // [nq_pad]
     uint8_t* overflow = nullptr;      // [nq_pad]
     int32_t* m_count = nullptr;       // [nq_pad] candidates to re-score
@@ -234,12 +236,12 @@ void sparse_cert_destroy(SparseCert* c) {
     if (c->d_stamps) {          // diagnostic: mean cycles per tile step of the sampled waves
         unsigned long long h[8] = {0};
         if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] && h[6])
-            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f barrier %.0f (%llu steps)\n",
-                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[5] / h[6], h[6]);
+            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f (of it slot reads + MFMA chain %.0f) barrier %.0f (%llu steps)\n",
+                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[7] / h[6], (double)h[5] / h[6], h[6]);
         (void)hipFree(c->d_stamps);
     }
     void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
-                    c->cq, c->sq, c->n_rare, c->n_qt, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
+                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws.release();
@@ -391,6 +393,7 @@ struct CertPlanArgs {
     float* sq;
     int32_t* n_rare;
     int32_t* n_qt;
+    int32_t* n_drop;
     uint8_t* elig;
     uint8_t* overflow;
 };
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
     // defaults: a query outside the fast path contributes nothing to stage 1
     a.rare_term[q * SC_MAXR + lane] = -1;
     a.rare_w[q * SC_MAXR + lane] = 0.f;
-    if (lane == 0) { a.cq[q] = 0.f; a.sq[q] = 0.f; a.n_rare[q] = 0; a.n_qt[q] = 0; a.elig[q] = 0; a.overflow[q] = 0; }
+    if (lane == 0) { a.cq[q] = 0.f; a.sq[q] = 0.f; a.n_rare[q] = 0; a.n_qt[q] = 0; a.n_drop[q] = 0; a.elig[q] = 0; a.overflow[q] = 0; }
     if (q >= a.nq) return;
     const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
     const int n = (int)(te - tb);
@@ -452,10 +455,18 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
     if (!(65535.0f * cqv * (float)nd <= 0.1f)) return;
     const int64_t qb = q / SC_QB;
     const int qn = (int)(q % SC_QB);
-    int rbase = 0;
+    // A rare term's weight is kept as fp16 by the scatter waves.  One below fp16's normal range is LEFT OUT of stage 1 (its postings
+    // are worth less than 32768 * 2^-14 = 2 key units each; the certificate widens by 2.03 per such term), one above it: exact kernels.
+    int rbase = 0, n_drop = 0;
+    bool w_bad = false;
 #pragma unroll
     for (int c = 0; c < SC_MAXQT / 64; ++c) {
-        const bool is_r = term[c] >= 0 && slot[c] < 0;
+        bool is_r = term[c] >= 0 && slot[c] < 0;
+        const float wr = is_r ? (float)(_Float16)(val[c] * sq * 65535.0f / a.vscale) : 1.f;
+        if (is_r && !(wr < 6.0e4f)) w_bad = true;
+        const bool dropped = is_r && wr < 6.2e-5f;
+        n_drop += __popcll(__ballot(dropped));
+        is_r = is_r && !dropped;
         const uint64_t m = __ballot(is_r);
         if (term[c] >= 0 && slot[c] >= 0) {
             const int s = slot[c] >> 4, kk = slot[c] & 15;
@@ -464,10 +475,13 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
         if (is_r) {
             const int j = rbase + __popcll(m & ((1ull << lane) - 1ull));
             a.rare_term[q * SC_MAXR + j] = term[c];
-            a.rare_w[q * SC_MAXR + j] = val[c] * sq * 65535.0f / a.vscale;
+            a.rare_w[q * SC_MAXR + j] = wr;
         }
         rbase += __popcll(m);
     }
+    if (__ballot(w_bad)) return;            // elig stays 0; what stage 1 computes for the query is discarded
+    nr = rbase;
+    if (lane == 0) a.n_drop[q] = n_drop;
     if (lane == 0) { a.cq[q] = cqv; a.sq[q] = sq; a.n_rare[q] = nr; a.n_qt[q] = n; a.elig[q] = 1; }
 }
 
@@ -530,9 +544,9 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
 #ifndef SC_DP
 #define SC_DP 8                       // A fragments in flight per matrix wave
 #endif
-#define SC_ITERS 4                    // 64-lane steps (two postings per lane) of a (query, tile) item whose loads are issued a tile ahead, in registers
-#define SC_LMAX 1024                  // posting PAIRS of an item the flattened walk handles (beyond: run by run)
-#define SC_MARK (SC_LMAX + 64)        // bytes of a wave's mark buffer
+#define SC_ITERS 8                    // 64-lane steps (FOUR postings per lane) of a scatter wave's 4 items whose loads are issued a tile ahead, in registers
+#define SC_QUADS (SC_ITERS * 64)      // quads staged per wave and tile; also the 16-bit entries of a wave's mark buffer
+#define SC_WAVE_LDS (SC_QUADS * 2 + 256 * 4 + 256 * 2)   // bytes per scatter wave: marks, delta table, weight table
 #define SC_SLOT_WORDS (SC_QB * SC_PITCH_W)
 
 template <int KS>
@@ -572,7 +586,9 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         // in a ring of registers at any time, across tile boundaries too - the matrix pipe never waits for a fresh round trip.
         constexpr int NL = 4 * KS;
         constexpr int DP = NL < SC_DP ? NL : SC_DP;
-        // fragment i of the wave's tile slice lies i KB behind the slice's start: wave-uniform base (SGPRs) + 16 lane + immediate
+        // fragment i = (block, k-step) of the wave's tile slice lies i KB behind the slice's start: wave-uniform base (SGPRs) + 16 lane + immediate.
+        // (Measured and dropped, both at the same time per tile step: a per-workgroup rotation of the fragment order, against 32 workgroups
+        // of an XCD reading the same lines of a tile at the same time; an L2 warm-up of the tile three steps ahead by LDS-DMA loads.)
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         auto a_ptr = [&](int tile, int i) -> const f16x8* {
             const char* base = reinterpret_cast<const char*>(a.d16) + (((int64_t)tile * SC_MB + wave_u * 4) * KS) * 1024;
@@ -581,40 +597,51 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         f16x8 af[DP];
 #pragma unroll
         for (int i = 0; i < DP; ++i) af[i] = (SC_DIAG & 2) ? f16x8{} : *a_ptr(tile0, i);
+        // The query block's B fragments stay in registers (4 KS VGPRs): read from LDS in front of every MFMA they cost an LDS round trip
+        // per MFMA behind the scatter waves' atomics (5 000 of a tile step's 9 400 cycles, measured with the MFMAs and loads switched off)
+        f16x8 bq[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = bl[ks * 64 + lane];
         __syncthreads();                                         // step tile0: the scatter waves fill LDS tile tile0 & 1
         const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
-        unsigned long long st_w = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
+        unsigned long long st_w = 0, st_b = 0, st_n = 0, st_m = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
             const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
             uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mbi = 0; mbi < 4; ++mbi) {
+                const int mb = mbi;
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int i = mb * KS + ks;
-                    const f16x8 bq = bl[ks * 64 + lane];
+                for (int ksi = 0; ksi < KS; ++ksi) {
+                    const int i = mbi * KS + ksi;
                     if (!(SC_DIAG & 2)) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq[ksi], acc, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);       // the ring's order is the point: hipcc otherwise re-packs the loads into one register and waits for each
                         af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_m += now - st_t; st_w += now - st_t; st_t = now; }
                 // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1};
-                // + the LDS tile's fixed-point sums of the rare terms (4 consecutive docs: one 8-byte read), which are cleared
+                // + the LDS tile's fixed-point sums of the rare terms
+                uint2 sv[4];
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    const int dl = (wave * 4 + mb) * 32 + 8 * G + 4 * h;         // 4 consecutive docs: one 8-byte read
+                    uint32_t* sp = buf + qn * SC_PITCH_W + (dl >> 1);
+                    sv[G] = *reinterpret_cast<const uint2*>(sp);
+                    *reinterpret_cast<uint2*>(sp) = make_uint2(0u, 0u);
+                }
                 uint32_t key[8];
                 uint32_t any = 0;
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
-                    const int dl = (wave * 4 + mb) * 32 + 8 * G + 4 * h;
-                    uint32_t* sp = buf + qn * SC_PITCH_W + (dl >> 1);
-                    const uint2 sv = *reinterpret_cast<const uint2*>(sp);
-                    *reinterpret_cast<uint2*>(sp) = make_uint2(0u, 0u);
-                    const u16x2 k0 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G] * cq, acc[4 * G + 1] * cq) + __builtin_bit_cast(u16x2, sv.x);
-                    const u16x2 k1 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G + 2] * cq, acc[4 * G + 3] * cq) + __builtin_bit_cast(u16x2, sv.y);
+                    const u16x2 k0 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G] * cq, acc[4 * G + 1] * cq) + __builtin_bit_cast(u16x2, sv[G].x);
+                    const u16x2 k1 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G + 2] * cq, acc[4 * G + 3] * cq) + __builtin_bit_cast(u16x2, sv[G].y);
                     key[2 * G] = __builtin_bit_cast(uint32_t, k0);
                     key[2 * G + 1] = __builtin_bit_cast(uint32_t, k1);
                     any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k0, __builtin_bit_cast(u16x2, cutm1x2)));
@@ -647,29 +674,28 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             __syncthreads();                                     // step tile + 1
             if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
-        if (st_on && lane == 0) { atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); }
+        if (st_on && lane == 0) { atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); atomicAdd(&a.stamps[7], st_m); }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
         // What a (query, tile) item adds: per rare term the run of its postings inside the tile.  Table E gives the run in ONE word per
         // (term, tile) - 16 bytes = 4 consecutive tiles per load, a cache line = 16 tiles: nothing, the single posting itself, or a
         // length (postings in P from the term's running start on; the start at the chunk's first tile comes from table S, once).
         //   single postings: lane j adds its own, one predicated LDS add per item;
-        //   longer runs are walked FLATTENED, two postings per lane: pair f of the item belongs to the run r with b_r <= f < b_r + np_r
-        //   (np = pairs of a run, b = exclusive prefix); r comes from a byte array in LDS holding r + 1 at position b_r (bit 7: the
-        //   pair is the odd tail of its run) and a wave-wide running maximum - every lane busy whatever the run lengths are.
+        //   longer runs are walked FLATTENED, four postings (one 16-byte load) per lane: quad f of the item belongs to the run r with
+        //   b_r <= f < b_r + nq_r (nq = quads of a run, b = exclusive prefix); r comes from a 16-bit array in LDS holding r + 1 at
+        //   position b_r (bits 8..9 at a run's last quad: its postings if fewer than four) and a wave-wide running maximum - every lane
+        //   busy whatever the run lengths are.
         // An item's loads are issued ONE TILE AHEAD (gathers over 4.5 GB take 2-3 us under load) and UNCONDITIONALLY (idle lanes read
         // entry 0): the number of vector-memory instructions per stage is a constant, so the compiler can wait for an item's loads with
         // a counted vmcnt that leaves everything issued after them in flight.
         const int sw = wave - 8;
-        unsigned char* const mark = reinterpret_cast<unsigned char*>(bl + KS * 64) + sw * SC_MARK;
+        unsigned short* const mark = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(bl + KS * 64) + sw * SC_WAVE_LDS);
         int32_t term[4];
-        float w[4];
         uint32_t cur[4];            // running start (index into P) of every rare term's next run, at the tile being staged
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const int64_t q = (int64_t)qb * SC_QB + sw * 4 + qi;
             term[qi] = a.rare_term[q * SC_MAXR + lane];
-            w[qi] = a.rare_w[q * SC_MAXR + lane];
             cur[qi] = term[qi] >= 0 ? a.S[(int64_t)term[qi] * a.s_stride + tile0] : 0u;
         }
         // the E words of tile pair g (tiles 2 g, 2 g + 1); pairs behind the chunk read the row's zero padding or a later chunk's words
@@ -679,105 +705,14 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             for (int qi = 0; qi < 4; ++qi)
                 e2[qi] = *reinterpret_cast<const uint2*>(a.E + (int64_t)(term[qi] >= 0 && !(SC_DIAG & 4) ? term[qi] : 0) * a.e_stride + 2 * g);
         };
-        auto run_of = [&](int it, int& carry, int& odd) -> int {
-            const int m = (int)mark[it * 64 + lane];
-            odd = m >> 7;
-            int v = sc_scan_max(max(m & 0x7f, carry));
-            carry = __builtin_amdgcn_readlane(v, 63);
-            return (v - 1) & 63;
-        };
-        auto write_marks = [&](int Lp, int b, int np, int ln) {
-            for (int f0 = 0; f0 < Lp; f0 += 64) mark[f0 + lane] = 0;
-            if (np == 1) mark[b] = (unsigned char)((lane + 1) | ((ln & 1) << 7));
-            else if (np > 1) {
-                mark[b] = (unsigned char)(lane + 1);
-                if (ln & 1) mark[b + np - 1] = 0x80;
-            }
-        };
-        struct Staged { uint2 pp[SC_ITERS]; uint32_t rr; int Lp; };
-        // ln = postings of the lane's run when it has two or more (else 0), st = its first posting
-        auto stage = [&](uint32_t st, int ln, Staged& g) {
-            const int np = (ln + 1) >> 1;
-            const int e = sc_scan_add(np);
-            const int Lp = __builtin_amdgcn_readlane(e, 63);
-            g.Lp = Lp;
-            const int b = e - np;
-            const uint32_t delta = st - 2u * (uint32_t)b;        // posting index of pair f of run r: 2 f + delta_r
-            const bool flat = Lp > 0 && Lp <= SC_LMAX;           // wave-uniform
-            if (flat) write_marks(Lp, b, np, ln);
-            int rid[SC_ITERS];
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) rid[it] = (flat && it * 64 < Lp) ? (int)mark[it * 64 + lane] : 0;
-            int carry = 0;
-            g.rr = 0u;
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) {
-                if (flat && it * 64 < Lp) {                      // wave-uniform
-                    const int odd = rid[it] >> 7;
-                    const int v = sc_scan_max(max(rid[it] & 0x7f, carry));
-                    carry = __builtin_amdgcn_readlane(v, 63);
-                    rid[it] = (v - 1) & 63;
-                    g.rr |= (uint32_t)(rid[it] | (odd << 7)) << (8 * it);
-                }
-            }
-            uint32_t pidx[SC_ITERS];
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) pidx[it] = (uint32_t)__shfl((int)delta, rid[it]);
-#pragma unroll
-            for (int it = 0; it < SC_ITERS; ++it) {
-                const uint32_t pi = (flat && it * 64 + lane < Lp) ? pidx[it] + 2u * (uint32_t)(it * 64 + lane) : 0u;
-                const u32x2_u v2 = *reinterpret_cast<const u32x2_u*>(a.P + pi);
-                g.pp[it] = make_uint2(v2.x, v2.y);
-            }
-        };
-        // e = the item's E word of the lane's term (its single posting, if any), st / ln as for stage (the paths beyond the registers)
-        auto consume = [&](uint32_t* row, uint32_t e, uint32_t st, int ln, float wq, const Staged& g) {
-            if (e != 0u && (e >> 16) != 0xffffu) cert_add_posting(row, e, wq);
-            const int Lp = g.Lp;
-            if (Lp == 0) return;
-            if (Lp <= SC_LMAX) {
-                float wv[SC_ITERS];
-#pragma unroll
-                for (int it = 0; it < SC_ITERS; ++it) wv[it] = __shfl(wq, (int)((g.rr >> (8 * it)) & 63u));
-#pragma unroll
-                for (int it = 0; it < SC_ITERS; ++it)
-                    if (it * 64 + lane < Lp) {
-                        cert_add_posting(row, g.pp[it].x, wv[it]);
-                        if (!((g.rr >> (8 * it + 7)) & 1u)) cert_add_posting(row, g.pp[it].y, wv[it]);
-                    }
-                if (Lp > SC_ITERS * 64) {                        // the steps beyond the registers: marks again, then load and add one by one
-                    const int np = (ln + 1) >> 1;
-                    const int e2 = sc_scan_add(np);
-                    const int b = e2 - np;
-                    const uint32_t delta = st - 2u * (uint32_t)b;
-                    write_marks(Lp, b, np, ln);
-                    int carry = 0;
-                    for (int it = 0; it * 64 < Lp; ++it) {
-                        int odd;
-                        const int rr = run_of(it, carry, odd);
-                        const uint32_t pi = 2u * (uint32_t)(it * 64 + lane) + (uint32_t)__shfl((int)delta, rr);     // shuffles with every lane active
-                        const float wv1 = __shfl(wq, rr);
-                        if (it >= SC_ITERS && it * 64 + lane < Lp) {
-                            cert_add_posting(row, a.P[pi], wv1);
-                            if (!odd) cert_add_posting(row, a.P[pi + 1u], wv1);
-                        }
-                    }
-                }
-            } else {                                             // more pairs than the mark buffer holds: run by run, 64 postings per step
-                uint64_t m = __ballot(ln > 0);
-                while (m) {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t* pb = a.P + (uint32_t)__builtin_amdgcn_readlane((int)st, j);
-                    const int nj = __builtin_amdgcn_readlane(ln, j);
-                    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq), j));
-                    for (int off = 0; off < nj; off += 64)
-                        if (off + lane < nj) cert_add_posting(row, pb[off + lane], wj);
-                }
-            }
-        };
         auto multi_len = [&](uint32_t e) -> int { return (e >> 16) == 0xffffu ? (int)(e & 0xffffu) : 0; };
         auto run_len = [&](uint32_t e) -> uint32_t { return (e >> 16) == 0xffffu ? (e & 0xffffu) : (e != 0u ? 1u : 0u); };
+        auto add_quad = [&](uint32_t* row, const uint4& p4, int tail, float wv) {
+            cert_add_posting(row, p4.x, wv);
+            if (tail != 1) cert_add_posting(row, p4.y, wv);
+            if (tail == 0 || tail == 3) cert_add_posting(row, p4.z, wv);
+            if (tail == 0) cert_add_posting(row, p4.w, wv);
+        };
         // E words: ecur = the pair holding the tile being STAGED, enext = the pair behind it (loaded a pair ahead)
         uint2 ecur[4], enext[4];
         load_group(tile0 >> 1, ecur);
@@ -786,14 +721,126 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
         }
+        // The quads of the wave's 4 items form ONE flat sequence (item 0's runs, then item 1's, ...): SC_QUADS = 64 SC_ITERS quads are
+        // staged per step whatever their split over the items.  Per item the count varies a lot (mean ~70, one query in ten above 128
+        // at the MSMARCO shape) and a step waits for its slowest wave, so a per-item capacity met its overflow path in almost every
+        // step; the sum over 4 items exceeds 512 in about one wave-step in a hundred.
+        // Run (qi, lane) has the id 64 qi + lane; its delta (posting index of quad f = 4 f + delta) is looked up in an LDS table by id,
+        // its weight (fp16) in a second one written once.
+        uint32_t* const tab_delta = reinterpret_cast<uint32_t*>(mark + SC_QUADS);
+        _Float16* const tab_w = reinterpret_cast<_Float16*>(tab_delta + 256);
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+            tab_w[qi * 64 + lane] = (_Float16)a.rare_w[((int64_t)qb * SC_QB + sw * 4 + qi) * SC_MAXR + lane];
+        uint4 pp[SC_ITERS];
+        uint32_t rid8[SC_ITERS / 4];      // run id of the lane's quad per step, 8 bits each
+        uint32_t tail2;                   // tail code per step, 2 bits each
+        int Ltot;
         uint32_t e_cons[4];
-        Staged sg[4];
-        // stages query slot qi for `tile` from ecur.x (zero behind the chunk)
-        auto stage_slot = [&](int tile, int qi) {
-            const uint32_t e = (tile < tile1 && term[qi] >= 0 && !(SC_DIAG & 1)) ? ecur[qi].x : 0u;
-            e_cons[qi] = e;
-            stage(cur[qi], multi_len(e), sg[qi]);
-            cur[qi] += run_len(e);
+        auto stage_all = [&](int tile) {
+            int nq4[4], bq4[4], Lq[4];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const uint32_t e = (tile < tile1 && term[qi] >= 0 && !(SC_DIAG & 1)) ? ecur[qi].x : 0u;
+                e_cons[qi] = e;
+                nq4[qi] = (multi_len(e) + 3) >> 2;
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const int es = sc_scan_add(nq4[qi]);
+                Lq[qi] = __builtin_amdgcn_readlane(es, 63);
+                bq4[qi] = es - nq4[qi];
+            }
+            int base = 0;
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                bq4[qi] += base;                                 // position of the lane's run in the wave's flat sequence
+                base += Lq[qi];
+                tab_delta[qi * 64 + lane] = cur[qi] - 4u * (uint32_t)bq4[qi];
+            }
+            Ltot = base;
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) mark[it * 64 + lane] = 0;
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const int ln = multi_len(e_cons[qi]);
+                const int last = bq4[qi] + nq4[qi] - 1;
+                const int id1 = qi * 64 + lane + 1;
+                if (nq4[qi] == 1) {
+                    if (bq4[qi] < SC_QUADS) mark[bq4[qi]] = (unsigned short)(id1 | ((ln & 3) << 9));
+                } else if (nq4[qi] > 1) {
+                    if (bq4[qi] < SC_QUADS) mark[bq4[qi]] = (unsigned short)id1;
+                    if (last < SC_QUADS) mark[last] = (unsigned short)((ln & 3) << 9);
+                }
+            }
+            int rid[SC_ITERS];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) rid[it] = (int)mark[it * 64 + lane];
+            int carry = 0;
+            tail2 = 0u;
+#pragma unroll
+            for (int it = 0; it < SC_ITERS / 4; ++it) rid8[it] = 0u;
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) {
+                tail2 |= (uint32_t)(rid[it] >> 9) << (2 * it);
+                const int v = sc_scan_max(max(rid[it] & 0x1ff, carry));
+                carry = __builtin_amdgcn_readlane(v, 63);
+                rid[it] = (v - 1) & 255;
+                rid8[it / 4] |= (uint32_t)rid[it] << (8 * (it % 4));
+            }
+            uint32_t dl[SC_ITERS];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) dl[it] = tab_delta[rid[it]];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) {
+                const uint32_t pi = it * 64 + lane < Ltot ? dl[it] + 4u * (uint32_t)(it * 64 + lane) : 0u;
+                const u32x4_u v4 = *reinterpret_cast<const u32x4_u*>(a.P + pi);
+                pp[it] = make_uint4(v4.x, v4.y, v4.z, v4.w);
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) cur[qi] += run_len(e_cons[qi]);
+        };
+        // Adds what was staged a step ago.  cur is the start of the NEXT tile's run at this point: an item's run began run_len earlier.
+        auto consume_all = [&](uint32_t* buf) {
+            uint32_t* const wrow = buf + sw * 4 * SC_PITCH_W;
+            _Float16 wv[SC_ITERS];
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) wv[it] = tab_w[(rid8[it / 4] >> (8 * (it % 4))) & 255u];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const uint32_t e = e_cons[qi];
+                if (e != 0u && (e >> 16) != 0xffffu) cert_add_posting(wrow + qi * SC_PITCH_W, e, (float)tab_w[qi * 64 + lane]);      // the lane's single posting
+            }
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it)
+                if (it * 64 + lane < Ltot) {
+                    const uint32_t id = (rid8[it / 4] >> (8 * (it % 4))) & 255u;
+                    add_quad(wrow + (id >> 6) * SC_PITCH_W, pp[it], (int)((tail2 >> (2 * it)) & 3u), (float)wv[it]);
+                }
+            if (Ltot > SC_QUADS) {                               // wave-uniform, rare: the quads beyond the staged ones, run by run, 64 postings per step
+                int base = 0;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const int ln = multi_len(e_cons[qi]);
+                    const int nq = (ln + 3) >> 2;
+                    const int es = sc_scan_add(nq);
+                    const int b = base + es - nq;
+                    base += __builtin_amdgcn_readlane(es, 63);
+                    const uint32_t st = cur[qi] - run_len(e_cons[qi]);
+                    const int skip = b >= SC_QUADS ? 0 : (SC_QUADS - b) * 4;      // postings of the lane's run that were staged
+                    uint64_t m = __ballot(ln > skip);
+                    while (m) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int sk = __builtin_amdgcn_readlane(skip, j);
+                        const uint32_t* pb = a.P + (uint32_t)__builtin_amdgcn_readlane((int)st, j) + (uint32_t)sk;
+                        const int nj = __builtin_amdgcn_readlane(ln, j) - sk;
+                        const float wj = (float)tab_w[qi * 64 + j];
+                        for (int off = 0; off < nj; off += 64)
+                            if (off + lane < nj) cert_add_posting(wrow + qi * SC_PITCH_W, pb[off + lane], wj);
+                    }
+                }
+            }
         };
         auto advance_queue = [&](int tile) {
             if (tile & 1) {                                      // wave-uniform: the next pair becomes current, the one behind it is fetched
@@ -805,23 +852,16 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
             }
         };
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) stage_slot(tile0, qi);
+        stage_all(tile0);
         advance_queue(tile0);
         const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 8;
         unsigned long long st_c = 0, st_s = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
-            uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
-            // per query slot: add the item whose loads were issued a step ago, then stage the slot for the next tile
-#pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                // cur is the start of the NEXT tile's run until the slot is staged again: this item's run began run_len earlier
-                consume(buf + (sw * 4 + qi) * SC_PITCH_W, e_cons[qi], cur[qi] - run_len(e_cons[qi]), multi_len(e_cons[qi]), w[qi], sg[qi]);
-                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_c += now - st_t; st_t = now; }
-                stage_slot(tile + 1, qi);
-                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_s += now - st_t; st_t = now; }
-            }
+            consume_all(slots + (tile & 1) * SC_SLOT_WORDS);     // the loads were issued a step ago
+            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_c += now - st_t; st_t = now; }
+            stage_all(tile + 1);
             advance_queue(tile + 1);
+            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_s += now - st_t; st_t = now; }
             __syncthreads();                                     // step tile + 1
             if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
@@ -841,6 +881,7 @@ struct CertSelectArgs {
     const uint8_t* overflow;
     const int32_t* n_rare;
     const int32_t* n_qt;
+    const int32_t* n_drop;
     int32_t* m_count;
     uint8_t* uncert;
     int* n_uncert;
@@ -859,7 +900,8 @@ __global__ void cert_select_kernel(CertSelectArgs a) {
         const double gamma = ((double)a.n_qt[q] + 2.0) * 6.0e-8 * 1.01;
         const double Kk = (double)sc[a.k - 1];
         const double lb = (Kk - 1.2 - 1.01 * (double)a.n_rare[q]) / (1.0 + dd);           // lower bound of the k-th true_fix
-        const double cutd = floor(lb * (1.0 - gamma) * (1.0 - dd) / (1.0 + gamma) - 1.2) - 1.0;
+        // a doc's true_fix is at most (key + 1.2) / (1 - dd) + 2.03 per rare term that stage 1 left out
+        const double cutd = floor((lb * (1.0 - gamma) / (1.0 + gamma) - 2.03 * (double)a.n_drop[q]) * (1.0 - dd) - 1.2) - 1.0;
         if (cutd >= 1.0) {
             const float cutf = (float)cutd;
             // the list is complete down to its last key: certified if it is not truncated, or if the truncation lies below the cut
@@ -958,7 +1000,7 @@ static int cert_realloc(T*& p, size_t n) {
 template <int KS>
 static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
     static DeviceOnce lds_set;
-    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_MARK);
+    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_WAVE_LDS);
     if (bool* slot = lds_set.pending()) {
         SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         *slot = true;
@@ -983,6 +1025,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         SR_TRY(cert_realloc(c->sq, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->n_rare, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->n_qt, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->n_drop, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->elig, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->overflow, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->m_count, (size_t)nq_pad));
@@ -1008,7 +1051,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     CertPlanArgs pa;
     pa.q_indptr = d_q_indptr; pa.q_cols = d_q_cols; pa.q_vals = d_q_vals; pa.nq = nq; pa.n_terms = idx->n_terms;
     pa.indptr = idx->indptr; pa.dslot = c->dslot; pa.vmax = c->vmax; pa.KS = c->KS; pa.vscale = c->vscale;
-    pa.bfrag = c->bfrag; pa.rare_term = c->rare_term; pa.rare_w = c->rare_w; pa.cq = c->cq; pa.sq = c->sq; pa.n_rare = c->n_rare; pa.n_qt = c->n_qt;
+    pa.bfrag = c->bfrag; pa.rare_term = c->rare_term; pa.rare_w = c->rare_w; pa.cq = c->cq; pa.sq = c->sq; pa.n_rare = c->n_rare; pa.n_qt = c->n_qt; pa.n_drop = c->n_drop;
     pa.elig = c->elig; pa.overflow = c->overflow;
     hipLaunchKernelGGL(cert_plan_kernel, dim3((unsigned)ceil_div64(nq_pad, 4)), dim3(256), 0, s, pa);
     SR_CHECK_LAUNCH();
@@ -1060,7 +1103,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     // stage 2: certificate, exact re-score of the candidates, exact top-k of those
     CertSelectArgs sa;
     sa.ap_scores = c->ap_scores; sa.ap_counts = c->ap_counts; sa.nq = nq; sa.k = k; sa.k_eff = k_eff; sa.T = c->T;
-    sa.elig = c->elig; sa.overflow = c->overflow; sa.n_rare = c->n_rare; sa.n_qt = c->n_qt; sa.m_count = c->m_count;
+    sa.elig = c->elig; sa.overflow = c->overflow; sa.n_rare = c->n_rare; sa.n_qt = c->n_qt; sa.n_drop = c->n_drop; sa.m_count = c->m_count;
     sa.uncert = d_uncert; sa.n_uncert = c->d_n_uncert;
     hipLaunchKernelGGL(cert_select_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, sa);
     SR_CHECK_LAUNCH();
@@ -1099,7 +1142,7 @@ extern "C" int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8) {
 
 // Debug / test hook: after enable = 1 every search keeps the stage-1 keys of all (query, doc) pairs; enable = 2 copies the keys of
 // the last search to h_keys [nq_pad][n_tiles * 1024] (uint16) and returns the per-query constants the bound needs:
-// h_consts [nq_pad][4] = {cq (0: the query is outside the fast path), s_q, n_rare, n_query_terms}.  *vscale / *T: the index-side constants.
+// h_consts [nq_pad][5] = {cq (0: the query is outside the fast path), s_q, rare terms in stage 1, query terms, rare terms left out}.  *vscale / *T: the index-side constants.
 extern "C" int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_keys, int64_t keys_capacity, float* h_consts,
                                           int64_t nq_pad, float* vscale, int32_t* T) {
     SR_REQUIRE(idx, "sr_sparse_index_cert_debug: null index");
@@ -1116,16 +1159,18 @@ extern "C" int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint
     SR_CHECK_HIP(hipDeviceSynchronize());
     SR_CHECK_HIP(hipMemcpy(h_keys, c->dump, sizeof(uint16_t) * (size_t)(nq_pad * stride), hipMemcpyDeviceToHost));
     std::vector<float> cqv((size_t)nq_pad), sqv((size_t)nq_pad);
-    std::vector<int32_t> nr((size_t)nq_pad), nt((size_t)nq_pad);
+    std::vector<int32_t> nr((size_t)nq_pad), nt((size_t)nq_pad), nd((size_t)nq_pad);
     SR_CHECK_HIP(hipMemcpy(cqv.data(), c->cq, sizeof(float) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     SR_CHECK_HIP(hipMemcpy(sqv.data(), c->sq, sizeof(float) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     SR_CHECK_HIP(hipMemcpy(nr.data(), c->n_rare, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     SR_CHECK_HIP(hipMemcpy(nt.data(), c->n_qt, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    SR_CHECK_HIP(hipMemcpy(nd.data(), c->n_drop, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     for (int64_t q = 0; q < nq_pad; ++q) {
-        h_consts[4 * q] = cqv[(size_t)q];
-        h_consts[4 * q + 1] = sqv[(size_t)q];
-        h_consts[4 * q + 2] = (float)nr[(size_t)q];
-        h_consts[4 * q + 3] = (float)nt[(size_t)q];
+        h_consts[5 * q] = cqv[(size_t)q];
+        h_consts[5 * q + 1] = sqv[(size_t)q];
+        h_consts[5 * q + 2] = (float)nr[(size_t)q];
+        h_consts[5 * q + 3] = (float)nt[(size_t)q];
+        h_consts[5 * q + 4] = (float)nd[(size_t)q];
     }
     if (vscale) *vscale = c->vscale;
     if (T) *T = c->T;
