@@ -266,96 +266,126 @@ def sparse_leg(args, device):
     log(f"[sparse] {nnz} postings ({nnz * 8 / 1e9:.2f} GB) built in {time.time() - t0:.1f}s")
     lens = indptr[1:] - indptr[:-1]
     touched = lens[q_cols.long()].reshape(nq, L0_q).sum(1).double()
-    # bytes of index a batch of queries needs at least once: the posting lists of its DISTINCT terms (sr_sparse_search
-    # walks the query set in batches of 1024)
-    unique_bytes = 0.0
+    # bytes of index a batch of queries needs at least once: the posting lists of its DISTINCT terms.  The exact kernels walk the
+    # query set in batches of 1024 (round 4's figure), the certified scorer takes it in one batch
+    unique_bytes_1024 = 0.0
     for qb in range(0, nq, 1024):
         terms = torch.unique(q_cols[qb * L0_q:min(nq, qb + 1024) * L0_q].long())
-        unique_bytes += 8.0 * float(lens[terms].sum().item())
-    idx.search(q_indptr, q_cols, q_vals, k)
-    torch.cuda.synchronize()
-    steps = 3
-    _lib.check(lib.sr_sparse_index_profile(idx._h, 1))
-    ts = time.perf_counter()
-    for _ in range(steps):
-        s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - ts) / steps
-    n_l, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
-    _lib.check(lib.sr_sparse_index_profile_read(idx._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by)))
-    _lib.check(lib.sr_sparse_index_profile(idx._h, 0))
-    kernel_s = ms.value * 1e-3 / steps
-    # what the query-block kernel really loads and applies in one pass (device counters, one extra untimed pass)
-    idx.work_counters(True)
-    idx.search(q_indptr, q_cols, q_vals, k)
-    wc = idx.work_counters(False)
-    TILE = 4096
-    valu_ops = 2.0 * wc["dense_column_applications"] * TILE          # unfused multiply + add per (column, query, doc)
-    rmw = float(wc["light_postings"] + wc["grouped_postings"])        # one LDS read-modify-write per posting of a scatter run
-    bytes_loaded = 4.0 * TILE * wc["dense_columns_loaded"] + 8.0 * rmw + 40.0 * wc["plan_entries"]
-    lds_peak, lds_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_lds_rmw.json")) as f:
-            mb = json.load(f)
-        lds_peak = max(v for kk, v in mb.items() if kk.startswith("random_b32_wg"))
-        lds_src = "profiles/r02_lds_rmw.json (tools/micro/lds_rmw.hip: random ds_read_b32 + ds_write_b32 on a 32 KB tile, no global traffic)"
-    except Exception:
-        pass
-    # HBM / fabric bytes per pass of the query-block kernel, from the committed PMC passes (rocprofv3 cannot run inside this
-    # process): used only for the same shape and the same kernel source
+        unique_bytes_1024 += 8.0 * float(lens[terms].sum().item())
+    unique_bytes_all = 8.0 * float(lens[torch.unique(q_cols.long())].sum().item())
+    def timed(steps=3):
+        idx.search(q_indptr, q_cols, q_vals, k)
+        torch.cuda.synchronize()
+        _lib.check(lib.sr_sparse_index_profile(idx._h, 1))
+        ts = time.perf_counter()
+        for _ in range(steps):
+            r = idx.search(q_indptr, q_cols, q_vals, k)
+        torch.cuda.synchronize()
+        dt_ = (time.perf_counter() - ts) / steps
+        n_l, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(lib.sr_sparse_index_profile_read(idx._h, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by)))
+        _lib.check(lib.sr_sparse_index_profile(idx._h, 0))
+        return r, dt_, ms.value * 1e-3 / steps, int(n_l.value) // steps
+
+    cs0 = idx.cert_stats()
+    (s, i, c), dt, kernel_s, launches = timed()
+    cs1 = idx.cert_stats()
+    certified = cs1["present"] == 1 and cs1["searches"] > cs0["searches"]
+    redone = (cs1["redone_exact"] - cs0["redone_exact"]) // max(1, cs1["searches"] - cs0["searches"])
+    # the exact kernels alone on the same queries (dev switch): the product path must return their bits
+    exact = None
+    if certified:
+        old = {kk: os.environ.get(kk) for kk in ("SR_DEV_SWITCHES", "SR_SPARSE_CERT_SEARCH")}
+        os.environ["SR_DEV_SWITCHES"], os.environ["SR_SPARSE_CERT_SEARCH"] = "1", "0"
+        try:
+            (s0, i0, c0), dt0, kernel0_s, launches0 = timed(steps=2)
+        finally:
+            for kk, vv in old.items():
+                if vv is None:
+                    os.environ.pop(kk, None)
+                else:
+                    os.environ[kk] = vv
+        assert torch.equal(s, s0) and torch.equal(i, i0) and torch.equal(c, c0), "certified scorer and exact kernels disagree"
+        exact = {"queries_per_s": round(nq / dt0, 1), "ms_per_pass": round(dt0 * 1e3, 1), "kernel_ms_per_pass": round(kernel0_s * 1e3, 1),
+                 "launches_per_pass": launches0, "kernels": "sparse_block_kernel / sparse_score_kernel (exact term-serial chain for every (query, doc))",
+                 "same_bits_as_the_product_path": True}
+        del s0, i0, c0
+    unique_bytes = unique_bytes_all if certified else unique_bytes_1024
+    hbm_gbps = unique_bytes / kernel_s / 1e9
+    T = cs1["dense_terms"] if certified else 0
+    if certified:
+        # work of cert_score_kernel per pass, from the index and the query set themselves
+        nq_pad, n_tiles = (nq + 31) // 32 * 32, cs1["doc_tiles"]
+        flop = 2.0 * nq_pad * T * n_tiles * 1024                           # fp16 MFMA product of the heavy terms, every (query, doc)
+        a_bytes = (nq_pad // 32) * float(n_tiles) * 1024 * T * 2           # the [docs x T] operand is streamed once per block of 32 queries
+        order = torch.argsort(lens, descending=True)
+        is_rare = torch.ones(V, dtype=torch.bool, device=device)
+        is_rare[order[:T]] = False
+        rare_adds = float((lens * is_rare)[q_cols.long()].double().sum().item())   # one fixed-point LDS atomic per posting of a rare query term
+        lds_peak, lds_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_lds_rmw.json")) as f:
+                mb = json.load(f)
+            lds_peak = max(v for kk, v in mb.items() if kk.startswith("random_b32_wg"))
+            lds_src = "profiles/r02_lds_rmw.json (tools/micro/lds_rmw.hip: random read-modify-writes on a 32 KB LDS tile; the atomics' own peak was not measured)"
+        except Exception:
+            pass
+        bounds = {
+            "mfma_heavy_terms": {"bound": "mfma", "achieved": round(flop / kernel_s / 1e12, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s (fp16 in, fp32 accumulate)",
+                                 "frac": round(flop / kernel_s / 1e12 / PEAK_BF16_MFMA_TF, 4), "flop_per_pass": flop,
+                                 "floor_ms_per_pass": round(flop / (PEAK_BF16_MFMA_TF * 1e12) * 1e3, 1)},
+            "l2_matrix_operand": {"bound": "l2", "achieved": round(a_bytes / kernel_s / 1e9, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s out of L2 (MI355X_MICROARCH.md)",
+                                  "frac": round(a_bytes / kernel_s / 1e9 / PEAK_L2_GBPS, 4), "bytes_per_pass": a_bytes,
+                                  "floor_ms_per_pass": round(a_bytes / (PEAK_L2_GBPS * 1e9) * 1e3, 1),
+                                  "note": "32 queries per workgroup (what 128 KB of 16-bit LDS slots for two 1 024-doc tiles allow): one MFMA per 1 KB fragment"},
+            "lds_rare_postings": {"bound": "lds", "achieved": rare_adds / kernel_s, "peak": lds_peak, "unit": "LDS atomic adds/s, chip-wide",
+                                  "frac": round(rare_adds / kernel_s / lds_peak, 4) if lds_peak else None, "adds_per_pass": rare_adds, "peak_source": lds_src,
+                                  "floor_ms_per_pass": round(rare_adds / lds_peak * 1e3, 1) if lds_peak else None},
+        }
+        fl_ = [bounds[b_]["floor_ms_per_pass"] for b_ in bounds if bounds[b_]["floor_ms_per_pass"]]
+        bounds["sum_of_floors_ms"] = round(sum(fl_), 1)
+        bounds["kernel_over_sum_of_floors"] = round(kernel_s * 1e3 / max(sum(fl_), 1e-9), 2)
+        bounds["note"] = ("the matrix waves (MFMA + operand stream) and the scatter waves (LDS atomics) of a workgroup work side by side on different "
+                          "tiles, so the floors overlap rather than add; their sum is the conservative yardstick")
+    else:
+        bounds = None
+    # fabric traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process)
     sp_traffic, sp_traffic_src = None, None
     try:
         import hashlib
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_sparse_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_pmc_sparse_traffic.json")) as f:
             pm = json.load(f)
         with open(os.path.join(ROOT, pm["kernel_source"]["file"]), "rb") as f:
             same = hashlib.sha256(f.read()).hexdigest() == pm["kernel_source"]["sha256"]
         sh = pm["shape"]
         if same and (sh["V"], sh["N"], sh["L0_d"], sh["L0_q"], sh["nq"]) == (V, N, L0_d, L0_q, nq):
-            kk_ = [v for kname, v in pm["kernels"].items() if kname.startswith("sparse_block_kernel")][0]
-            sp_traffic = int(kk_["traffic_bytes"] * kk_["dispatches"] / pm["passes_profiled"])
-            sp_traffic_src = "profiles/r04_pmc_sparse_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes; bytes per pass of 6 980 queries, " + pm.get("commit", "?") + ")"
+            sp_traffic = int(pm["traffic_bytes_per_pass"])
+            sp_traffic_src = "profiles/r05_pmc_sparse_traffic.json (" + pm.get("how", "") + ")"
     except Exception:
         sp_traffic = None
-    hbm_gbps = unique_bytes / kernel_s / 1e9
-    valu_rate = valu_ops / kernel_s
-    l2_rate = bytes_loaded / kernel_s
-    bounds = {
-        "valu_dense_columns": {"bound": "valu", "achieved": round(valu_rate / 1e12, 2), "peak": round(PEAK_VALU_F32_OPS / 1e12, 1),
-                               "unit": "T unfused fp32 lane-operations/s (v_pk_mul_f32 + v_pk_add_f32; 256 CUs x 4 SIMDs x 16 lanes x 2 packed x 2.4 GHz)",
-                               "frac": round(valu_rate / PEAK_VALU_F32_OPS, 4), "ops_per_pass": valu_ops,
-                               "floor_ms_per_pass": round(valu_ops / PEAK_VALU_F32_OPS * 1e3, 1)},
-        "l2_bytes_loaded": {"bound": "l2", "achieved": round(l2_rate / 1e9, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s out of L2 (MI355X_MICROARCH.md, "
-                            "L2 per XCD: ~34.5 TB/s aggregate)", "frac": round(l2_rate / 1e9 / PEAK_L2_GBPS, 4),
-                            "bytes_per_pass": bytes_loaded, "floor_ms_per_pass": round(bytes_loaded / (PEAK_L2_GBPS * 1e9) * 1e3, 1),
-                            "of_which_dense_columns": 4.0 * TILE * wc["dense_columns_loaded"], "of_which_postings": 8.0 * rmw},
-        "lds_scatter": {"bound": "lds", "achieved": rmw / kernel_s, "peak": lds_peak, "unit": "read-modify-writes/s, chip-wide",
-                        "frac": round(rmw / kernel_s / lds_peak, 4) if lds_peak else None, "rmw_per_pass": rmw, "peak_source": lds_src,
-                        "floor_ms_per_pass": round(rmw / lds_peak * 1e3, 1) if lds_peak else None},
-        "work_counters_per_pass": wc,
-    }
     out = {"metric": "sparse inverted-index queries/s (index resident in HBM, top-%d)" % k, "value": round(nq / dt, 1), "unit": "queries/s",
            "ms_per_pass": round(dt * 1e3, 1), "dtype": "f32", "data": "synthetic",
            "config": {"workload": "Lion-SP-1B sparse scoring (BASELINE.json configs[2]), synthetic Zipf(1.0) index", "V": V, "N": N, "L0_d": L0_d,
                       "L0_q": L0_q, "nq": nq, "k": k, "postings": nnz, "mean_postings_touched_per_query": float(touched.mean().item())},
-           "roofline": {"kernel": "sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel",
-                        "dense_column_terms": idx.block_stats()["dense_terms"],
+           "path": ({"scorer": "certified two-stage (csrc/sparse_cert.hip): fp16 MFMA + fixed-point LDS atomics -> certificate -> exact fp32 chain of the candidates",
+                     "heavy_terms_on_the_matrix_pipe": T, "queries_redone_by_the_exact_kernels_per_pass": redone} if certified else
+                    {"scorer": "exact kernels only (this index / k has no certified scorer)"}),
+           "roofline": {"kernel": "cert_score_kernel" if certified else ("sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel"),
                         "bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / PEAK_HBM_GBPS, 4), "traffic": sp_traffic, "traffic_source": sp_traffic_src,
                         "traffic_unit": "bytes beyond L2 per pass of the whole query set (the algorithmic figure beside it: unique_index_bytes_per_pass)",
-                        "launches": int(n_l.value),
+                        "launches": launches,
                         "kernel_ms_per_pass": round(kernel_s * 1e3, 1), "unique_index_bytes_per_pass": unique_bytes,
+                        "unique_index_bytes_per_pass_in_batches_of_1024": unique_bytes_1024,
+                        "frac_on_the_batches_of_1024_figure": round(unique_bytes_1024 / kernel_s / 1e9 / PEAK_HBM_GBPS, 4),
                         "hbm_floor_ms_per_pass": round(unique_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3, 2),
-                        "note": "achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per posting) / "
-                                "kernel time: the HBM floor is a small fraction of the kernel time, i.e. this kernel is NOT HBM-bound.  `bounds` prices "
-                                "the work the kernel really does, counted on the device in an extra pass: the unfused multiply-adds of the "
-                                "dense-column terms against the fp32 VALU rate, the bytes it loads (columns + postings + plan) against the L2 rate, "
-                                "the postings it scatters against the LDS read-modify-write rate of tools/micro/lds_rmw.hip - the three run one "
-                                "after another inside a workgroup, so their floors ADD (sum_of_floors_ms)"},
-           "bounds": bounds}
-    fl_ = [bounds[b_]["floor_ms_per_pass"] for b_ in ("valu_dense_columns", "l2_bytes_loaded", "lds_scatter") if bounds[b_]["floor_ms_per_pass"]]
-    out["bounds"]["sum_of_floors_ms"] = round(sum(fl_), 1)
-    out["bounds"]["kernel_over_sum_of_floors"] = round(kernel_s * 1e3 / max(sum(fl_), 1e-9), 2)
+                        "other_kernels_ms_per_pass": round((dt - kernel_s) * 1e3, 1),
+                        "note": "SURVEY.md 8(d) convention: achieved = posting bytes the query batches need at least once (lists of their distinct terms, 8 B per "
+                                "posting) / time of the dominant kernel.  The kernel is not HBM-bound; `bounds` prices what it does: the MFMA product of "
+                                "the heavy terms, the operand bytes it pulls out of L2, the LDS atomics of the other terms' postings.  "
+                                "other_kernels_ms_per_pass: plan, top-k compaction of every launch, the sort of k + 1024 keys per query, certificate, "
+                                "exact re-score, final top-k"},
+           "bounds": bounds, "exact_kernels": exact}
     from oracle import scoring as SC
     h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
     nqc = max(args.sparse_cpu_queries, 4)
@@ -386,6 +416,7 @@ def sparse_leg(args, device):
     idx.close()
     del idx, h_indptr, h_ids, h_vals
     torch.cuda.empty_cache()
+    out["index_build"] = sparse_build_only(indptr, doc_ids, vals, V, N, device)
     if not args.no_drop_in:
         with contextlib.redirect_stdout(sys.stderr):          # the reference-shaped classes print like the reference does
             out["drop_in"] = drop_in_sparse_leg(args, dict(LION_1B), (indptr, doc_ids, vals, N), (q_indptr, q_cols, q_vals, nq), device)
@@ -394,6 +425,131 @@ def sparse_leg(args, device):
     if not args.no_sparse_sweep:
         out["sparse_sweep"] = sparse_sweep_leg(args, device)
     return out
+
+
+def sparse_build_only(indptr, doc_ids, vals, V, N, device):
+    """sr_sparse_csr_build (csrc/sparse_build.hip) on the whole MSMARCO-shaped collection: the index's postings are first turned into
+    the doc-major triples SparseIndexer.index collects (insertion order = ascending doc, terms ascending inside a doc: itself a
+    sr_sparse_csr_build, by doc), then the CSR by term is rebuilt from them, timed, and compared bit for bit with the index it came from
+    (a stable sort by term of doc-ordered triples gives posting lists ascending by doc)."""
+    from scaling_retriever_amd.scoring import sparse_csr_build, sparse_csr_expand_terms
+    nnz = int(doc_ids.numel())
+    term_of = sparse_csr_expand_terms(indptr, nnz)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f_indptr, f_terms, f_vals = sparse_csr_build(term_of, doc_ids, vals, N)          # "terms" = docs here: the forward (doc-major) index
+    torch.cuda.synchronize()
+    t_fwd = time.perf_counter() - t0
+    del term_of
+    rows = sparse_csr_expand_terms(f_indptr, nnz)
+    del f_indptr
+    sparse_csr_build(rows[:1 << 20], f_terms[:1 << 20], f_vals[:1 << 20], V)          # warm-up (allocator, code objects)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        b_indptr, b_ids, b_vals = sparse_csr_build(rows, f_terms, f_vals, V)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    same = bool(torch.equal(b_indptr, indptr) and torch.equal(b_ids, doc_ids) and torch.equal(b_vals, vals))
+    assert same, "sr_sparse_csr_build does not reproduce the index"
+    t = min(ts)
+    n_pass = 2 if V > 512 else 1
+    alg_bytes = nnz * (n_pass * (4.0 + 12.0 + 12.0)) + 8.0 * V            # per pass: keys for the histogram, triples in, triples out
+    out = {"workload": f"CSR by term from {nnz} doc-major postings ({N} docs x V = {V}): stable radix sort, {n_pass} passes of 9-bit digits",
+           "postings_per_s": round(nnz / t, 1), "seconds": round(t, 4), "passages_per_s_at_this_L0_d": round(N / t, 1),
+           "bit_identical_to_the_source_index": same,
+           "roofline": {"kernel": "radix_scatter_kernel + radix_hist_kernel", "bound": "hbm", "achieved": round(alg_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBPS,
+                        "unit": "GB/s", "frac": round(alg_bytes / t / 1e9 / PEAK_HBM_GBPS, 4), "algorithmic_bytes": alg_bytes,
+                        "note": "wall time of the call incl. its allocations and the two exclusive scans; 28 B per posting and pass"},
+           "forward_index_by_doc": {"seconds": round(t_fwd, 4), "postings_per_s": round(nnz / t_fwd, 1),
+                                    "note": "the same call with the docs as sort key (24 bits: 3 passes), from term-major input"}}
+    log("[sparse index_build]", out)
+    del rows, f_terms, f_vals, b_indptr, b_ids, b_vals
+    torch.cuda.empty_cache()
+    return out
+
+
+class _ThresholdedSparseDocs:
+    """Stands where SparseIndexer expects the model.  Random-init weights give document reps with about half the vocabulary active
+    (a trained Lion-SP model: L0_d ~ 100-200), so the REAL HIP encoder + sparse head run on every batch and a constant is subtracted
+    from the reps (relu after it) that leaves ~L0_d entries per passage: encode, compaction and index build then see realistic sizes."""
+
+    def __init__(self, model, shift):
+        self.model, self.shift = model, float(shift)
+        self.vocab_size = model.vocab_size
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def encode(self, **inputs):
+        reps = self.model.encode(**inputs)
+        return reps.sub_(self.shift).clamp_min_(0.0)
+
+
+def sparse_index_leg(args, device):
+    """BASELINE.json's 'passages/sec encode' for configs[2]: SparseIndexer.index (indexer.py:239-308) over synthetic passages at
+    Lion-SP-1B dims - LlamaBiSparse.doc_encode (body + the 128 256-wide head), sr_sparse_compact per batch, sr_sparse_csr_build at the end."""
+    from scaling_retriever_amd.dataset.pipeline import TokenBudgetCollectionLoader
+    from scaling_retriever_amd.indexer import SparseIndexer
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiSparse
+    cfg = dict(LION_1B)
+    V, H = cfg["vocab_size"], cfg["hidden_size"]
+    n_pass = args.sparse_index_passages
+    model = LlamaBiSparse.from_weights(cfg, random_weights(cfg, device, seed=9), max_batch_tokens=args.token_budget, max_batch_seqs=4096,
+                                       fp32_planes=0).to(device).eval()
+    chunks, lens = synth_token_chunks(n_pass, 4.25, 0.35, 8, 192, V, 5, (0, n_pass))
+
+    def loader():
+        return TokenBudgetCollectionLoader(tokenized=chunks, max_length=192, max_tokens=args.token_budget // 2, max_seqs=512,
+                                           window=32768, pad_token_id=V - 1, padding_side="left")
+    first = next(iter(loader()))
+    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+        reps = model.encode(input_ids=first["input_ids"].to(device), attention_mask=first["attention_mask"].to(device))
+    shift = float(torch.topk(reps[:64], 128, dim=1).values[:, -1].float().mean().item())
+    del reps
+    stub = _ThresholdedSparseDocs(model, shift)
+    with contextlib.redirect_stdout(sys.stderr):
+        SparseIndexer(stub, None, device, compute_stats=True, dim_voc=V).index(
+            TokenBudgetCollectionLoader(tokenized=chunks[:1], max_length=192, max_tokens=args.token_budget // 2, max_seqs=512,
+                                        pad_token_id=V - 1, padding_side="left"))                     # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = SparseIndexer(stub, None, device, compute_stats=True, dim_voc=V).index(loader())
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+    indptr, rows, vals, n_docs = res["device_csr"]
+    nnz = int(rows.numel())
+    assert n_docs == n_pass and int(indptr[-1]) == nnz and len(res["ids_mapping"]) <= n_pass
+    # every posting list ascends by doc (insertion order of a single rank), checked on the device
+    seg = sparse_csr_expand_terms_cached(indptr, nnz)
+    assert bool(((rows[1:] > rows[:-1]) | (seg[1:] != seg[:-1])).all()), "posting lists do not ascend by doc"
+    tokens = int(lens.sum())
+    flop = tokens * (FLOP_PER_TOKEN_1B + 2.0 * H * V) + 4.0 * float((lens.astype(np.float64) ** 2).sum()) * H * cfg["num_hidden_layers"]
+    ach = flop / t / 1e12
+    out = {"workload": f"SparseIndexer.index: {n_pass} synthetic passages (mean {tokens / n_pass:.1f} tokens) at Lion-SP-1B dims, token-budget loader, real HIP "
+                       f"encoder + sparse head, reps thresholded to L0_d ~ 128 (random weights give no realistic sparsity), sr_sparse_compact per batch, "
+                       f"sr_sparse_csr_build at the end, index kept on the device",
+           "passages_per_s": round(n_pass / t, 1), "seconds": round(t, 2), "tokens_per_s": round(tokens / t, 1), "L0_d": round(nnz / n_pass, 1),
+           "postings": nnz, "stats": {k_: round(float(v_), 2) for k_, v_ in res.get("stats", {}).items()},
+           "roofline": {"kernel": "gemm_bf16_kernel (encoder body + lm_head with the segmented-max epilogue)", "bound": "mfma", "achieved": round(ach, 1),
+                        "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TF, 4),
+                        "flop_per_token": FLOP_PER_TOKEN_1B + 2.0 * H * V,
+                        "note": "SURVEY.md 8(d): 1.946 GFLOP/token body + 0.525 GFLOP/token head + attention; wall time of index() incl. the loader, "
+                                "compaction, the doc id dict and the final CSR build"},
+           "msmarco_extrapolation_minutes": round(8_841_823 / (n_pass / t) / 60.0, 1)}
+    log("[sparse_index]", out)
+    del model, stub, res
+    torch.cuda.empty_cache()
+    return out
+
+
+def sparse_csr_expand_terms_cached(indptr, nnz):
+    from scaling_retriever_amd.scoring import sparse_csr_expand_terms
+    return sparse_csr_expand_terms(indptr, nnz)
 
 
 def sparse_sweep_leg(args, device):
@@ -416,12 +572,14 @@ def sparse_sweep_leg(args, device):
                 s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
                 torch.cuda.synchronize()
                 st0 = idx.block_stats()
+                cs0 = idx.cert_stats()
                 t0 = time.perf_counter()
                 for _ in range(2):
                     s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / 2
                 st1 = idx.block_stats()
+                cs1 = idx.cert_stats()
                 n_check = 64
                 if host is None:
                     host = (indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy())
@@ -433,8 +591,11 @@ def sparse_sweep_leg(args, device):
                     assert np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), (name, L0_d, L0_q, q)
                 touched = float((indptr[1:] - indptr[:-1])[q_cols.long()].reshape(nq, L0_q).sum(1).double().mean().item())
                 rows.append({"index": name, "L0_d": L0_d, "L0_q": L0_q, "queries_per_s": round(nq / dt, 1), "ms_per_1k_queries": round(dt / nq * 1e6, 1),
-                             "kernel": ("sparse_block_kernel" if st1["block_calls"] > st0["block_calls"] and st1["fallback_calls"] == st0["fallback_calls"]
-                                        else ("sparse_score_kernel" if st1["block_calls"] == st0["block_calls"] else "both")),
+                             "kernel": ("cert_score_kernel" if cs1["searches"] > cs0["searches"] else
+                                        ("sparse_block_kernel" if st1["block_calls"] > st0["block_calls"] and st1["fallback_calls"] == st0["fallback_calls"]
+                                         else ("sparse_score_kernel" if st1["block_calls"] == st0["block_calls"] else "both"))),
+                             "queries_redone_by_the_exact_kernels": (cs1["redone_exact"] - cs0["redone_exact"]) // 2,
+                             "heavy_terms_on_the_matrix_pipe": cs1["dense_terms"],
                              "dense_column_terms": st1["dense_terms"], "postings": int(doc_ids.numel()),
                              "mean_postings_touched_per_query": touched, "queries_bit_exact_vs_oracle": n_check})
                 log("[sparse_sweep]", rows[-1])
@@ -715,6 +876,46 @@ def config5_leg(args, device):
                                                    "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}}}
 
 
+def launch_ranks(n, argv, dry_run=False):
+    """Start `n` ranks of this script on this node (one per GPU) through torch.distributed.run and relay rank 0's line.
+    Returns the exit status: 0 only if every rank exited cleanly.  Called before any GPU call of this process."""
+    import socket
+    import subprocess
+    share = os.environ.get("SR_BENCH_SHARE_GPU") == "1"          # dry run of the multi-rank path on a one-GPU box (gloo, every rank on cuda:0)
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        log(f"error: --gpus {n} needs {n} visible GPUs, found {have} (set SR_BENCH_SHARE_GPU=1 only for a plumbing dry run on one GPU)")
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--print-launch"]
+    if dry_run:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    log("[launch]", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    last = None
+    for line in proc.stdout:                                    # the children's stderr goes straight through
+        if line.startswith("{"):
+            last = line
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        log(f"error: the {n}-rank run exited with status {rc}")
+        return rc if 0 < rc < 256 else 1
+    if last is None:
+        log("error: the ranks exited cleanly but rank 0 printed no result line")
+        return 1
+    sys.stdout.write(last)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -741,14 +942,23 @@ def main():
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in legs (the reference's own call path: loader batches of 128 -> "
                     "get_top_docs / SparseRetrieval.retrieve -> run.json)")
     ap.add_argument("--no-sparse-sweep", action="store_true", help="skip the L0_d x L0_q / flat-distribution sweep of the sparse scorer")
+    ap.add_argument("--no-sparse-index", action="store_true", help="skip the SparseIndexer.index leg (sparse passages/s)")
+    ap.add_argument("--sparse-index-passages", type=int, default=131072, help="synthetic passages of the sparse_index leg")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the command that would start the ranks and exit")
     ap.add_argument("--no-robustness", action="store_true", help="skip the filter_robustness legs (anisotropic / near-duplicate corpora at full shape)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (before anything touches a GPU:
+    # device_count() does not initialise one): one child `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`,
+    # whose stdout (rank 0's JSON line) is relayed; the exit status is the child's.  Nothing is retried or re-executed in place.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.print_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        sys.exit(2)
     # SR_BENCH_SHARE_GPU=1: dry run of the multi-rank path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL,
     # which refuses two ranks on one device); the driver's real runs leave it unset
     share_gpu = os.environ.get("SR_BENCH_SHARE_GPU") == "1"
@@ -1184,6 +1394,9 @@ def main():
         del model
         torch.cuda.empty_cache()
         sparse = sparse_leg(args, device)
+        if not args.no_sparse_index:
+            torch.cuda.empty_cache()
+            sparse["sparse_index"] = sparse_index_leg(args, device)
     config5 = None
     if rank == 0 and world == 1 and not args.no_config5 and not args.layers:
         torch.cuda.empty_cache()

@@ -192,6 +192,10 @@ int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_key
  * reference's posting order; sort_docs = 1 additionally orders every posting list by ascending doc row (needs n_docs >
  * every row), which is what sr_sparse_index_create requires of a merged multi-rank index.  Outputs: d_indptr int64
  * [n_terms + 1], d_out_rows int32 [nnz], d_out_vals fp32 [nnz] (must not alias the inputs).  Synchronises the stream.       */
+/* Term of every posting of a CSR-by-term index: d_out_terms int32 [nnz][p] = t for d_indptr[t] <= p < d_indptr[t + 1]
+ * (the per-term arrays of IndexDictOfArray, inverted_index.py:22-55, flattened back to triples for a re-sort).            */
+int sr_sparse_csr_expand_terms(const int64_t* d_indptr, int64_t n_terms, int64_t nnz, int32_t* d_out_terms,
+                               sr_stream stream);
 int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols, const float* d_vals, int64_t nnz,
                         int64_t n_terms, int64_t n_docs, int sort_docs, int64_t* d_indptr,
                         int32_t* d_out_rows, float* d_out_vals, sr_stream stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sr_sparse_index_cert_stats": (c_int, [c_void_p, ctypes.POINTER(c_int64)]),
     "sr_sparse_index_cert_debug": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                                            ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_int32)]),
+    "sr_sparse_csr_expand_terms": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "sr_sparse_csr_build": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "sr_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -228,6 +228,27 @@ __global__ void csr_indptr_kernel(const int32_t* __restrict__ sorted_terms, int6
     indptr[t] = lo;
 }
 
+// term of posting p: the last t with indptr[t] <= p (binary search per posting; empty lists are skipped by the "last")
+__global__ void csr_expand_terms_kernel(const int64_t* __restrict__ indptr, int64_t n_terms, int64_t nnz, int32_t* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int64_t lo = 0, hi = n_terms;       // first t with indptr[t] > p
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= p) lo = mid + 1; else hi = mid;
+    }
+    out[p] = (int32_t)(lo - 1);
+}
+
+extern "C" int sr_sparse_csr_expand_terms(const int64_t* d_indptr, int64_t n_terms, int64_t nnz, int32_t* d_out_terms, sr_stream stream) {
+    SR_REQUIRE(n_terms >= 1 && nnz >= 0, "sr_sparse_csr_expand_terms: bad sizes");
+    if (nnz == 0) return SR_OK;
+    SR_REQUIRE(d_indptr && d_out_terms, "sr_sparse_csr_expand_terms: null pointer");
+    hipLaunchKernelGGL(csr_expand_terms_kernel, dim3((unsigned)ceil_div64(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_indptr, n_terms, nnz, d_out_terms);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 static int bits_for(int64_t n_values) {
     int b = 1;
     while (b < 31 && (1ll << b) < n_values) ++b;

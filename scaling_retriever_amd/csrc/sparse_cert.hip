@@ -41,7 +41,7 @@
 #define SC_BAND 1024                  // keys kept beyond k
 #define SC_CAND_CAP 16384             // candidate slots per query and launch
 #define SC_MAXQT 256                  // terms of a fast-path query
-#define SC_TMAX 256                   // dense terms (MFMA K), at most
+#define SC_TMAX 128                   // dense terms (MFMA K), at most: 8 k-steps of B fragments in registers, 8 KB of them in LDS
 #define SC_FWD_MAX 1024               // postings per doc the forward-index sort handles
 #ifndef SC_DIAG
 #define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups, 8 no LDS adds, 16 plain LDS read-modify-write
@@ -301,8 +301,8 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         int n_heavy = (int)std::min<size_t>(heavy.size(), (size_t)t_max);
         c->T = std::max(16, (n_heavy + 15) / 16 * 16);
         c->KS = c->T / 16;
-        if (c->KS != 1 && c->KS != 2 && c->KS != 4 && c->KS != 8 && c->KS != 16) {     // instantiated k-step counts
-            c->KS = c->KS < 4 ? 4 : (c->KS < 8 ? 8 : 16);
+        if (c->KS != 1 && c->KS != 2 && c->KS != 4 && c->KS != 8) {     // instantiated k-step counts
+            c->KS = c->KS < 4 ? 4 : 8;
             c->T = c->KS * 16;
         }
         std::vector<int32_t> h_slot((size_t)V, -1), h_terms((size_t)std::max(1, n_heavy));
@@ -1090,7 +1090,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
             case 2: rc = cert_launch_score<2>(a, grid, s); break;
             case 4: rc = cert_launch_score<4>(a, grid, s); break;
             case 8: rc = cert_launch_score<8>(a, grid, s); break;
-            default: rc = cert_launch_score<16>(a, grid, s); break;
+            default: sr_set_error("sparse_cert_search: %d k-steps are not instantiated", c->KS); rc = SR_ERR_INVALID; break;
         }
         idx->prof.end(s, 0, 0);
         SR_TRY(rc);

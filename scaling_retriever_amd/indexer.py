@@ -25,7 +25,7 @@ import torch
 from tqdm import tqdm
 
 from . import _lib
-from .scoring import DenseIndexHIP, SparseIndexHIP
+from .scoring import DenseIndexHIP, SparseIndexHIP, sparse_csr_build, sparse_csr_expand_terms
 from .utils.inverted_index import IndexDictOfArray
 from .utils.run_file import IdTable, RunResult, to_host
 from .utils.utils import get_rank, get_world_size, is_first_worker, to_list
@@ -447,20 +447,18 @@ class SparseIndexer:
             dev_rows.append((row * self.world_size + self.local_rank).to(torch.int32))   # g_row = (row + count) * W + rank
             dev_cols.append(col.clone())
             dev_vals.append(data.clone())
-            has_posting = (nnz_per_row > 0).cpu().numpy()
-            all_idxes = (count + np.arange(len(batch_ids))) * self.world_size + self.local_rank
-            for _i, _idx in enumerate(all_idxes):            # docs without any posting get no entry (:271-283)
-                if has_posting[_i]:
-                    doc_ids[int(_idx)] = batch_ids[_i]
+            has_posting = np.nonzero((nnz_per_row > 0).cpu().numpy())[0]       # docs without any posting get no entry (:271-283)
+            all_idxes = (count + has_posting) * self.world_size + self.local_rank
+            doc_ids.update(zip(all_idxes.tolist(), (batch_ids[_i] for _i in has_posting.tolist())))
             count += len(batch_ids)
         if dev_rows:
             rows_t, cols_t, vals_t = torch.cat(dev_rows), torch.cat(dev_cols), torch.cat(dev_vals)
             del dev_rows, dev_cols, dev_vals
-            order = torch.sort(cols_t.to(torch.int32), stable=True).indices      # insertion order kept inside a term
             V = max(int(self.sparse_index.dim_voc or 0), int(cols_t.max().item()) + 1 if cols_t.numel() else 0)
-            counts = torch.bincount(cols_t.long(), minlength=V)
-            indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=counts.device), torch.cumsum(counts, 0)])
-            rows_t, vals_t = rows_t[order].contiguous(), vals_t[order].contiguous()
+            # sr_sparse_csr_build (csrc/sparse_build.hip): this library's stable radix sort by term - insertion order kept inside a
+            # term, i.e. the posting lists add_batch_document's appends would hold (inverted_index.py:67-76)
+            indptr, rows_t, vals_t = sparse_csr_build(rows_t, cols_t, vals_t, V)
+            del cols_t
             n_docs = (count - 1) * self.world_size + self.local_rank + 1 if self.world_size > 1 else count   # nb_docs() = max g_row + 1
             if self.index_dir is not None:       # the host copy is needed to write the files; the 12 B per posting in HBM are released
                 self.sparse_index.set_csr(indptr.cpu().numpy(), rows_t.cpu().numpy(), vals_t.cpu().numpy(), n_docs)
@@ -497,10 +495,10 @@ def _csr_sorted_by_doc(indptr, doc_ids, vals, device):
     ids_t = torch.from_numpy(np.ascontiguousarray(doc_ids)).to(device)
     vals_t = torch.from_numpy(np.ascontiguousarray(vals)).to(device)
     if ids_t.numel():
-        term = torch.repeat_interleave(torch.arange(len(indptr) - 1, device=device), indptr_t[1:] - indptr_t[:-1])
-        key = term * (int(ids_t.max().item()) + 1) + ids_t.long()
-        order = torch.argsort(key)
-        ids_t, vals_t = ids_t[order].contiguous(), vals_t[order].contiguous()
+        # sr_sparse_csr_build with sort_docs: stable radix passes over the doc rows, then over the terms (csrc/sparse_build.hip)
+        term = sparse_csr_expand_terms(indptr_t, ids_t.numel())
+        indptr2, ids_t, vals_t = sparse_csr_build(ids_t, term, vals_t, len(indptr) - 1, n_docs=int(ids_t.max().item()) + 1, sort_docs=True)
+        assert torch.equal(indptr2, indptr_t.to(torch.int64))
     return indptr_t, ids_t, vals_t
 
 

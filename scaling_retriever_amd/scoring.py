@@ -357,6 +357,18 @@ def sparse_csr_build(rows, cols, vals, n_terms, n_docs=0, sort_docs=False):
     return indptr, out_rows[:nnz], out_vals[:nnz]
 
 
+def sparse_csr_expand_terms(indptr, nnz):
+    """Term of every posting of a CSR-by-term index (indptr int64 [V + 1] on the device) -> int32 [nnz]: sr_sparse_csr_expand_terms."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    indptr = indptr.to(torch.int64).contiguous()
+    out = torch.empty(max(1, int(nnz)), dtype=torch.int32, device=indptr.device)
+    with torch.cuda.device(indptr.device):
+        _lib.check(lib.sr_sparse_csr_expand_terms(_ptr(indptr), indptr.numel() - 1, int(nnz), _ptr(out), _lib.stream_ptr()),
+                   "sr_sparse_csr_expand_terms")
+    return out[:int(nnz)]
+
+
 def topk_merge(scores, ids, pad_score=-3.402823466e38):
     """Merge per-shard top-k lists: scores fp32 [W, nq, k], ids int64 [W, nq, k] (cuda) -> ([nq,k], [nq,k])."""
     _lib.require_gpu()

@@ -64,14 +64,16 @@ def test_bench_multi_rank_path_dry_run():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SR_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-docs", "300000",
+    env.pop("WORLD_SIZE", None)
+    # no launcher on the command line: `bench.py --gpus 2` starts its two ranks itself (the driver's command shape)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-docs", "300000",
            "--encode-passages", "4096", "--layers", "2", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert res["config"]["ranks"]["world_size"] == 2 and len(res["config"]["ranks"]["shard_docs"]) == 2
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
     assert res["fast_mode"]["value"] > 0 and res["small_batch"][0]["nq"] == 1
     assert res["encode"]["value"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
