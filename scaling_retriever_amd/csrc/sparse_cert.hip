@@ -314,6 +314,7 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         const size_t s_words = (size_t)V * (size_t)(c->n_tiles + 1);
         c->e_stride = (c->n_tiles + 3) / 4 * 4 + 4;
         const size_t e_words = (size_t)V * (size_t)c->e_stride;
+        if (e_words >= 0xffffffffull) break;      // the kernel addresses table E with 32-bit word offsets
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { rc = SR_ERR_HIP; break; }
         const size_t need = d16_halves * 2 + (size_t)nnz * 12 + (s_words + e_words) * 4 + (size_t)N * 16 + (64u << 20);
@@ -549,6 +550,75 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
 #define SC_WAVE_LDS (SC_QUADS * 2 + 256 * 4 + 256 * 2)   // bytes per scatter wave: marks, delta table, weight table
 #define SC_SLOT_WORDS (SC_QB * SC_PITCH_W)
 
+// The quads of a scatter wave's 4 items beyond the SC_QUADS staged ones: further windows of SC_QUADS through the same flat walk, loads
+// and adds back to back (one memory round trip per 2 048 postings).  Not inlined: the kernel's register allocation is sized for the
+// staged path, this one saves and restores around itself and runs once in about a hundred wave-steps at the MSMARCO shape.
+__device__ __noinline__ void cert_overflow_windows(unsigned short* mark, const uint32_t* tab_delta, const _Float16* tab_w, const uint32_t* P,
+                                                   uint32_t* wrow, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, int Ltot) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t ev[4] = {e0, e1, e2, e3};
+    int nq4[4], bq4[4], lnv[4];
+    int base = 0;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        lnv[qi] = (ev[qi] >> 16) == 0xffffu ? (int)(ev[qi] & 0xffffu) : 0;
+        nq4[qi] = (lnv[qi] + 3) >> 2;
+        const int es = sc_scan_add(nq4[qi]);
+        bq4[qi] = base + es - nq4[qi];
+        base += __builtin_amdgcn_readlane(es, 63);
+    }
+    for (int win = SC_QUADS; win < Ltot; win += SC_QUADS) {
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it) mark[it * 64 + lane] = 0;
+        int carry = 0;                                           // id + 1 of the run that straddles the window's first quad
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const int first = bq4[qi] - win, last = first + nq4[qi] - 1;
+            const int id1 = qi * 64 + lane + 1;
+            if (nq4[qi] > 0) {
+                if (first >= 0 && first < SC_QUADS) mark[first] = (unsigned short)id1;
+                if (last >= 0 && last < SC_QUADS) {
+                    if (last == first) mark[last] = (unsigned short)(id1 | ((lnv[qi] & 3) << 9));
+                    else mark[last] = (unsigned short)((lnv[qi] & 3) << 9);
+                }
+            }
+            const uint64_t strad = __ballot(nq4[qi] > 0 && first < 0 && last >= 0);
+            if (strad) carry = qi * 64 + __builtin_ctzll(strad) + 1;
+        }
+        const int nwin = Ltot - win < SC_QUADS ? Ltot - win : SC_QUADS;
+        int mk[SC_ITERS], idw[SC_ITERS];
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it) mk[it] = (int)mark[it * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it) {
+            const int v = sc_scan_max(max(mk[it] & 0x1ff, carry));
+            carry = __builtin_amdgcn_readlane(v, 63);
+            idw[it] = (v - 1) & 255;
+        }
+        uint32_t dlw[SC_ITERS];
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it) dlw[it] = tab_delta[idw[it]];
+        uint4 pw[SC_ITERS];
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it) {                  // the window's loads go out together
+            const uint32_t pi = it * 64 + lane < nwin ? dlw[it] + 4u * (uint32_t)(win + it * 64 + lane) : 0u;
+            const u32x4_u v4 = *reinterpret_cast<const u32x4_u*>(P + pi);
+            pw[it] = make_uint4(v4.x, v4.y, v4.z, v4.w);
+        }
+#pragma unroll
+        for (int it = 0; it < SC_ITERS; ++it)
+            if (it * 64 + lane < nwin) {
+                uint32_t* row = wrow + (idw[it] >> 6) * SC_PITCH_W;
+                const float wv = (float)tab_w[idw[it]];
+                const int tail = mk[it] >> 9;
+                cert_add_posting(row, pw[it].x, wv);
+                if (tail != 1) cert_add_posting(row, pw[it].y, wv);
+                if (tail == 0 || tail == 3) cert_add_posting(row, pw[it].z, wv);
+                if (tail == 0) cert_add_posting(row, pw[it].w, wv);
+            }
+    }
+}
+
 template <int KS>
 __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     extern __shared__ uint32_t slots[];                          // 2 x [SC_QB][SC_PITCH_W] | B fragments | mark buffers
@@ -700,10 +770,14 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         }
         // the E words of tile pair g (tiles 2 g, 2 g + 1); pairs behind the chunk read the row's zero padding or a later chunk's words
         // (never used: the per-tile guard below)
+        // row of the lane's term in table E as a 32-bit word offset (V * e_stride < 2^32 is checked at build time): wave-uniform base in
+        // SGPRs + one VGPR offset per load, no 64-bit vector address held (or spilled) across the tile loop
+        uint32_t erow[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) erow[qi] = (term[qi] >= 0 && !(SC_DIAG & 4)) ? (uint32_t)term[qi] * (uint32_t)a.e_stride : 0u;
         auto load_group = [&](int g, uint2 (&e2)[4]) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi)
-                e2[qi] = *reinterpret_cast<const uint2*>(a.E + (int64_t)(term[qi] >= 0 && !(SC_DIAG & 4) ? term[qi] : 0) * a.e_stride + 2 * g);
+            for (int qi = 0; qi < 4; ++qi) e2[qi] = *reinterpret_cast<const uint2*>(a.E + (erow[qi] + 2u * (uint32_t)g));
         };
         auto multi_len = [&](uint32_t e) -> int { return (e >> 16) == 0xffffu ? (int)(e & 0xffffu) : 0; };
         auto run_len = [&](uint32_t e) -> uint32_t { return (e >> 16) == 0xffffu ? (e & 0xffffu) : (e != 0u ? 1u : 0u); };
@@ -817,30 +891,8 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                     const uint32_t id = (rid8[it / 4] >> (8 * (it % 4))) & 255u;
                     add_quad(wrow + (id >> 6) * SC_PITCH_W, pp[it], (int)((tail2 >> (2 * it)) & 3u), (float)wv[it]);
                 }
-            if (Ltot > SC_QUADS) {                               // wave-uniform, rare: the quads beyond the staged ones, run by run, 64 postings per step
-                int base = 0;
-#pragma unroll
-                for (int qi = 0; qi < 4; ++qi) {
-                    const int ln = multi_len(e_cons[qi]);
-                    const int nq = (ln + 3) >> 2;
-                    const int es = sc_scan_add(nq);
-                    const int b = base + es - nq;
-                    base += __builtin_amdgcn_readlane(es, 63);
-                    const uint32_t st = cur[qi] - run_len(e_cons[qi]);
-                    const int skip = b >= SC_QUADS ? 0 : (SC_QUADS - b) * 4;      // postings of the lane's run that were staged
-                    uint64_t m = __ballot(ln > skip);
-                    while (m) {
-                        const int j = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int sk = __builtin_amdgcn_readlane(skip, j);
-                        const uint32_t* pb = a.P + (uint32_t)__builtin_amdgcn_readlane((int)st, j) + (uint32_t)sk;
-                        const int nj = __builtin_amdgcn_readlane(ln, j) - sk;
-                        const float wj = (float)tab_w[qi * 64 + j];
-                        for (int off = 0; off < nj; off += 64)
-                            if (off + lane < nj) cert_add_posting(wrow + qi * SC_PITCH_W, pb[off + lane], wj);
-                    }
-                }
-            }
+            if (Ltot > SC_QUADS)                                 // wave-uniform, rare at the shape this kernel is sized for
+                cert_overflow_windows(mark, tab_delta, tab_w, a.P, wrow, e_cons[0], e_cons[1], e_cons[2], e_cons[3], Ltot);
         };
         auto advance_queue = [&](int tile) {
             if (tile & 1) {                                      // wave-uniform: the next pair becomes current, the one behind it is fetched

@@ -76,13 +76,13 @@ def test_csr_build_keeps_insertion_order_inside_a_term_and_handles_the_edges():
 
 
 def test_csr_build_large_and_the_index_it_feeds():
-    """1.3 M docs x 24 postings (31 M postings, several thousand waves per pass): equals the stable sort, and the index built from it
+    """1.3 M docs x 24 postings at V = 128 256 (31 M postings, two 9-bit passes, several thousand waves each): equals the stable sort, and the index built from it
     scores like the oracle."""
     from oracle import scoring as O
     from scaling_retriever_amd.scoring import SparseIndexHIP, sparse_csr_build
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(5)
-    n_docs, V, L = 1_300_000, 30000, 24
+    n_docs, V, L = 1_300_000, 128256, 24
     # L distinct terms per doc: a random start + distinct offsets from a Zipf-ish table, ascending inside the doc
     w = 1.0 / torch.arange(1, V + 1, device=dev, dtype=torch.float32)
     cols = torch.multinomial(w.expand(4096, V), L, replacement=False, generator=g)
