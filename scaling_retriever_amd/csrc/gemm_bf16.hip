@@ -276,7 +276,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         } while (0)
 #define KL_DSR(DST, BASE, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "n"(OFF))
 #define KL_DMA(SRD, VOFF, KOFF, M0B, M0OFF)                                                                         \
-        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(KOFF), "s"(M0B), "n"(M0OFF) : "memory", "scc")
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(KOFF), "s"(M0B), "n"(M0OFF) : "memory", "scc", "m0")
         // MFMA number n (0..63) of a k-half: row block n / 8 of the weights x token block n % 8
 #define KL_MMA_N(n, WS, AS) KL_MMA(acc[(n) >> 3][(n) & 7], WS[(n) >> 3], AS[(n) & 7], (((n) >> 3) == 7))
         // fragment read number r (0..15): 0-7 weight blocks, 8-15 token blocks, of k-half KH

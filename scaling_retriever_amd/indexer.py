@@ -201,18 +201,24 @@ class DenseIndexer(object):
 
     def _update_id_mapping(self, db_ids: List):
         self.index_id_to_db_id.extend(db_ids)
+        self._id_table = self._run_table = None
         return len(self.index_id_to_db_id)
 
     def id_table(self):
         """index_id_to_db_id as one object array (+ a trailing None for faiss' label -1), rebuilt when the list grew: the id
         mapping of search_knn is ONE numpy take instead of a Python loop over every hit (indexer.py:212-213)."""
-        n = len(self.index_id_to_db_id)
+        ids = self.index_id_to_db_id
+        n = len(ids)
+        # the reference lets callers assign or edit index_id_to_db_id directly (deserialize, :189): the cache is tied to the list object,
+        # its length and its first / last entries, so a re-assigned or re-loaded list of the same length is not served stale ids
+        stamp = (id(ids), n, ids[0] if n else None, ids[-1] if n else None)
         cached = getattr(self, "_id_table", None)
-        if cached is None or len(cached) != n + 1:
+        if cached is None or getattr(self, "_id_table_stamp", None) != stamp:
             cached = np.empty(n + 1, dtype=object)
-            cached[:n] = self.index_id_to_db_id
+            cached[:n] = ids
             cached[n] = None
             self._id_table = cached
+            self._id_table_stamp = stamp
             self._run_table = None
         return cached
 
@@ -562,13 +568,22 @@ def _doc_id_table(doc_ids, n_docs):
     n = max(int(n_docs), (max(doc_ids) + 1) if len(doc_ids) else 0)
     keys = np.fromiter(doc_ids.keys(), dtype=np.int64, count=len(doc_ids))
     vals = list(doc_ids.values())
+    # Docs without a posting have no id (they can never be hits); their slots get DISTINCT placeholders, so that a few empty documents
+    # in a real collection do not make the id table look like it held duplicates (which sends run.json through the dict path)
+    holes = np.ones(n, dtype=bool)
+    holes[keys] = False
+    hole_pos = np.nonzero(holes)[0]
     if vals and all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in vals):
         table = np.full(n, -1, dtype=np.int64)
         table[keys] = np.asarray(vals, dtype=np.int64)
+        if len(hole_pos):
+            lo = min(int(table[keys].min()) if len(keys) else 0, 0)
+            table[hole_pos] = lo - 1 - np.arange(len(hole_pos), dtype=np.int64)       # below every real id
         return table
     table = np.empty(n, dtype=object)
-    table[:] = ""
     table[keys] = np.asarray(vals, dtype=object)
+    for j, pos in enumerate(hole_pos.tolist()):
+        table[pos] = f"\x00no-posting-{j}"
     return table
 
 

@@ -9,8 +9,13 @@ Here the result stays in the typed arrays the search returned:
   IdTable     the index-position -> document-id table as typed arrays (int64, fixed-width ASCII, or escaped JSON string bodies);
   RunResult   what `retrieve()` returns: a read-only Mapping with the dict's behaviour (res[qid][docid] -> float, iteration,
               len, == with a dict of dicts, .to_dict()) that materialises a query's dict only when it is asked for;
-  write_run_json   the file, written by libsr_hip.so's sr_write_run_json (host threads): byte for byte what json.dump writes
-              for the nested dict.
+  write_run_json   the file, written by libsr_hip.so's sr_write_run_json (host threads): byte for byte what Python's json.dump
+              writes for the nested dict - which is what the reference's sparse path calls (indexer.py:537-538).  Its dense path
+              calls ujson.dump (eval_dense.py:240): same content - json.load gives equal dicts - but compact separators, its own
+              float text and "\\/" escapes, so the BYTES of that file differ.
+
+RunResult is a read-only Mapping, not a dict: callers that json.dump() it or assign into res[qid] need res.to_dict() first (the
+reference's own callers only read it, write it or hand it to the metrics; utils/metrics.py accepts both).
 """
 import ctypes
 import json
