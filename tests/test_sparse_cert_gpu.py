@@ -254,3 +254,40 @@ def test_auto_mode_keeps_small_collections_on_the_exact_kernels():
     indptr, ids, vals = _zipf_index(rng, 500, 12000, 20)
     idx = SparseIndexHIP(indptr, ids, vals, 12000)
     assert idx.cert_stats()["present"] == 0
+
+
+def test_more_rare_postings_per_tile_than_a_wave_stages(forced, monkeypatch):
+    """Only 16 terms on the matrix pipe and a dense-ish index: the runs of a wave's 4 queries inside a tile hold several times the 512
+    quads staged per step, so most of them go through the overflow windows of the flat walk (and, with runs of > 1 000 postings, past
+    every per-window size).  Same bits as the oracle."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    monkeypatch.setenv("SR_SPARSE_CERT_T", "16")
+    rng = np.random.default_rng(61)
+    V, N = 300, 23000
+    indptr, ids, vals = _zipf_index(rng, V, N, 90, cap=0.6)          # every second term in a third of the docs or more
+    qi, qc, qv = _zipf_queries(rng, V, 37, 60)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    st = idx.cert_stats()
+    assert st["present"] == 1 and st["dense_terms"] == 16
+    _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, 100)
+    st = idx.cert_stats()
+    assert st["searches"] == 1 and st["redone_exact"] <= 4, st
+
+
+def test_tiny_rare_weights_are_left_out_of_stage_one_and_still_exact(forced):
+    """A rare term whose weight falls below fp16's normal range after the query's scaling is not scored in stage 1; the certificate
+    widens by its bounded worth and the exact re-score brings it back: certified, same bits."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(71)
+    V, N = 2500, 30000
+    indptr, ids, vals = _zipf_index(rng, V, N, 40)
+    qi, qc, qv = _zipf_queries(rng, V, 32, 24)
+    rare = qc >= 200
+    qv[rare & (np.arange(len(qv)) % 3 == 0)] *= np.float32(3e-7)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    idx.cert_record_keys(True)
+    _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, 100)
+    _, consts, _, _ = idx.cert_recorded_keys(32)
+    idx.cert_record_keys(False)
+    assert (consts[:32, 4] > 0).sum() >= 16          # most queries had a term left out ...
+    assert idx.cert_stats()["redone_exact"] <= 2      # ... and were certified all the same
