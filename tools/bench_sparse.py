@@ -73,7 +73,8 @@ def main():
            "config": {"workload": "Lion-SP-1B sparse scoring, synthetic Zipf(1.0) index", "V": a.V, "N": a.N, "L0_d": a.L0_d,
                       "L0_q": a.L0_q, "nq": a.nq, "k": a.k, "postings": nnz,
                       "mean_postings_touched_per_query": float(touched.mean().item())},
-           "roofline": {"kernel": "sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel",
+           "roofline": {"kernel": ("cert_score_kernel" if idx.cert_stats()["searches"] else
+                                   ("sparse_block_kernel" if idx.block_stats()["block_calls"] else "sparse_score_kernel")),
                         "dense_column_terms": idx.block_stats()["dense_terms"],
                         "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None, "launches": int(n_l.value),

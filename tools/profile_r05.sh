@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-5 profile snapshot, ONE pass, run through gpurun from the repo root as the round's last GPU step:
+#   bash tools/profile_r05.sh        (writes gpurun_out/r05_prof; tools/profile_r05_collect.py copies the judged summaries into profiles/)
+# Every rocprofv3 call sits under its own `timeout`: a counter set the hardware cannot collect aborts the profiled process and leaves
+# rocprofv3 hanging until the box's limit (that cost 25 GPU-minutes once).  PMC passes are --kernel-trace only (gpurun refuses --pmc
+# together with the sys / hip / hsa trace domains).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05_prof
+rm -rf $O; mkdir -p $O
+cd $R
+# 1. the bench line itself (what the driver runs)
+python3 bench.py > $O/bench_line.json 2> $O/bench.log || echo "bench failed"
+cd /tmp && export TMPDIR=/tmp
+T="timeout -s KILL 600"
+# 2. kernel statistics of the headline step + the sparse leg
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-fast-mode --no-encode --no-config5 --no-robustness --no-shard-leg --no-drop-in --no-sparse-sweep --no-sparse-index --sparse-cpu-queries 4"
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -o bench -- $BENCH --steps 3 --warmup 1 > $O/bench_under_rocprof.json 2> $O/bench_stats.err
+# 3. the dense headline's traffic + MFMA counters (as in round 4)
+DENSE="$BENCH --no-sparse"
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $DENSE --steps 1 --warmup 0 > /dev/null 2> $O/pmc_fetch.err
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $DENSE --steps 1 --warmup 0 > /dev/null 2> $O/pmc_write.err
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- $DENSE --steps 1 --warmup 0 > /dev/null 2> $O/pmc_mfma.err
+# 4. the sparse scorer: kernel statistics, traffic, activity counters (2 searches per pass: warm-up + 1)
+SP="python3 $R/tools/quick_sparse_cert.py --exact 0 --check 0 --steps 1"
+T2="timeout -s KILL 150"
+$T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sparse_stats -o sp -- python3 $R/tools/quick_sparse_cert.py --exact 1 --check 0 --steps 2 > $O/sparse_under_rocprof.json 2> $O/sparse_stats.err
+$T2 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_sp_fetch -o p -- $SP > /dev/null 2> $O/pmc_sp_fetch.err
+$T2 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_sp_write -o p -- $SP > /dev/null 2> $O/pmc_sp_write.err
+i=0
+for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS_ATOMIC" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+           "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"; do
+  i=$((i+1))
+  $T2 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_sp$i -o p -- $SP > /dev/null 2> $O/pmc_sp$i.err || echo "sparse pmc pass $i failed: $set"
+done
+# 5. encode kernels (corpus + fp32-regime queries), as in round 4
+$T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/qenc_stats -o q -- python3 $R/tools/quick_query_encode.py 16 > $O/qenc.log 2> $O/qenc.err
+$T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc_stats -o e -- python3 $R/tools/quick_encode_budget.py 16384 > $O/enc.log 2> $O/enc.err
+cd $R
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null 2> $O/pmc_traffic.err
+python3 tools/pmc_traffic.py $O/pmc_sp_fetch $O/pmc_sp_write $O/pmc_sparse_traffic.json > /dev/null 2>> $O/pmc_traffic.err
+python3 tools/pmc_counters.py $O/pmc_mfma --out $O/pmc_mfma.json --match dense_split > /dev/null 2>> $O/pmc_traffic.err
+python3 tools/pmc_counters.py $O/pmc_sp? --out $O/pmc_sparse.json --match cert_score_kernel > /dev/null 2>> $O/pmc_traffic.err
+# 6. the GPU suite on the same box
+python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_suite.txt
+# keep the summaries, drop the bulky per-dispatch traces
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
+ls $O

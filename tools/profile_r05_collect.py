@@ -1,0 +1,54 @@
+"""Copies the judged summaries of gpurun_out/r05_prof (tools/profile_r05.sh) into profiles/ and ties the sparse traffic figure to the
+kernel source it was measured on (bench.py reads it back only for the same source and shape)."""
+import glob
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(R, "gpurun_out", "r05_prof")
+P = os.path.join(R, "profiles")
+
+
+def copy(src, dst):
+    f = glob.glob(os.path.join(O, src))
+    if f:
+        shutil.copy(f[0], os.path.join(P, dst))
+        print("copied", dst)
+    else:
+        print("missing", src, file=sys.stderr)
+
+
+copy("bench_line.json", "r05_bench_line.json")
+copy("bench_under_rocprof.json", "r05_bench_under_rocprof.json")
+copy("bench_stats/**/bench_kernel_stats.csv", "r05_bench_kernel_stats.csv") if glob.glob(os.path.join(O, "bench_stats/**/bench_kernel_stats.csv"), recursive=True) else None
+for src, dst in (("bench_stats", "r05_bench_kernel_stats.csv"), ("sparse_stats", "r05_sparse_kernel_stats.csv"), ("qenc_stats", "r05_query_encode_kernel_stats.csv"),
+                 ("enc_stats", "r05_encode_kernel_stats.csv")):
+    f = glob.glob(os.path.join(O, src, "**", "*kernel_stats.csv"), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(P, dst))
+        print("copied", dst)
+for src, dst in (("pmc_traffic.json", "r05_pmc_traffic.json"), ("pmc_mfma.json", "r05_pmc_mfma.json"), ("pmc_sparse.json", "r05_pmc_sparse.json"),
+                 ("gpu_suite.txt", "r05_gpu_suite.txt")):
+    copy(src, dst)
+# sparse traffic: per pass of 6 980 queries, tied to the kernel source
+try:
+    t = json.load(open(os.path.join(O, "pmc_sparse_traffic.json")))["kernels"]
+    k = [v for name, v in t.items() if name.startswith("cert_score_kernel")][0]
+    src = "scaling_retriever_amd/csrc/sparse_cert.hip"
+    doc = {"what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/quick_sparse_cert.py --exact 0 --check 0 --steps 1 "
+                   "(two searches of 6 980 queries), cert_score_kernel only",
+           "how": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernel's dispatches of one search (MI355X_MICROARCH.md: FETCH_SIZE "
+                  "reports half the bytes of wide coalesced reads on gfx950 and counts Infinity-Cache hits; most of this kernel's reads are 16-byte loads)",
+           "shape": {"V": 128256, "N": 8841823, "L0_d": 128, "L0_q": 32, "nq": 6980},
+           "passes_profiled": 2, "dispatches": k["dispatches"], "traffic_bytes_per_pass": int(k["traffic_bytes"] * k["dispatches"] / 2),
+           "fetch_kb_per_dispatch": k["FETCH_SIZE_KB"], "write_kb_per_dispatch": k["WRITE_SIZE_KB"],
+           "kernel_source": {"file": src, "sha256": hashlib.sha256(open(os.path.join(R, src), "rb").read()).hexdigest()},
+           "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=R, capture_output=True, text=True).stdout.strip()}
+    json.dump(doc, open(os.path.join(P, "r05_pmc_sparse_traffic.json"), "w"), indent=1)
+    print("wrote r05_pmc_sparse_traffic.json", doc["traffic_bytes_per_pass"])
+except Exception as e:
+    print("sparse traffic:", e, file=sys.stderr)
