@@ -1443,6 +1443,14 @@ def main():
                        "doc_encode_precision": "bf16 autocast regime", "score_precision": "exact fp32 (k-ordered fmaf chain)" + ("" if args.exact_kernel else ": certified fp16 upper-bound filter + exact re-score of 1-2k candidates per query, "
                                                                                "bit-identical to the exact kernel (parity field)"),
                        "ranks": ranks_info,
+                       # the figures of the other legs a reader looks for first, where a record that keeps only `config` still has them
+                       "drop_in_retrieval_qps": (drop_in or {}).get("retrieval_task_with_run_json", {}).get("queries_per_s") if drop_in else None,
+                       "drop_in_search_knn_qps": (drop_in or {}).get("search_knn", {}).get("queries_per_s") if drop_in else None,
+                       "sparse_qps": sparse["value"] if sparse else None,
+                       "sparse_qps_exact_kernels": (sparse.get("exact_kernels") or {}).get("queries_per_s") if sparse else None,
+                       "sparse_index_passages_per_s": (sparse.get("sparse_index") or {}).get("passages_per_s") if sparse else None,
+                       "sparse_index_build_postings_per_s": (sparse.get("index_build") or {}).get("postings_per_s") if sparse else None,
+                       "encode_passages_per_s": (encode or {}).get("value") if encode else None,
                        "parallelism": f"doc-shard x{world}" + (" (queries encoded 1/W per rank + all-gather of the 57 MB query matrix; "
                                                                        "1 RCCL gather of per-shard top-k; merge on rank 0)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "exact_kernel_mode": exact_mode, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,

@@ -44,7 +44,7 @@
 #define SC_TMAX 128                   // dense terms (MFMA K), at most: 8 k-steps of B fragments in registers, 8 KB of them in LDS
 #define SC_FWD_MAX 1024               // postings per doc the forward-index sort handles
 #ifndef SC_DIAG
-#define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups, 8 no LDS adds, 16 plain LDS read-modify-write
+#define SC_DIAG 0                     // timing-only variants (tools/micro/cert_diag.sh, wrong results): 1 no posting work, 2 no MFMA work, 4 no table lookups, 8 no LDS adds, 16 plain LDS read-modify-write, 32 no MFMA (operand loads stay), 64 no operand loads (MFMAs stay)
 #endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -689,9 +689,10 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                     const int i = mbi * KS + ksi;
                     if (!(SC_DIAG & 2)) {
                         __builtin_amdgcn_sched_barrier(0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq[ksi], acc, 0, 0, 0);
+                        if (!(SC_DIAG & 32)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i % DP], bq[ksi], acc, 0, 0, 0);
+                        else acc[0] += (float)af[i % DP][0];     // timing only: the load is still waited for
                         __builtin_amdgcn_sched_barrier(0);       // the ring's order is the point: hipcc otherwise re-packs the loads into one register and waits for each
-                        af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
+                        if (!(SC_DIAG & 64)) af[i % DP] = i + DP < NL ? *a_ptr(tile, i + DP) : *a_ptr(tnext, i + DP - NL);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

@@ -73,8 +73,12 @@ def test_dense_search_repeated_100_times_is_bit_identical():
     assert np.array_equal(first["fp32"][0][rows].cpu().numpy(), es)
 
 
-def test_sparse_search_repeated_50_times_is_bit_identical():
+@pytest.mark.parametrize("path", ["certified", "exact"])
+def test_sparse_search_repeated_50_times_is_bit_identical(path, monkeypatch):
+    """path: the certified two-stage scorer (the default at this size) or - dev switch - the exact kernels alone."""
     import os
+    if path == "exact":
+        monkeypatch.setenv("SR_SPARSE_CERT_SEARCH", "0")
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import synth
@@ -97,8 +101,11 @@ def test_sparse_search_repeated_50_times_is_bit_identical():
             assert not bad, f"search #{it}: queries {bad[:10]} differ from the first run"
         if it % 10 == 5:
             index.search(q_indptr[:9], q_cols[:8 * L0_q], q_vals[:8 * L0_q], 50, threshold=0.0)
-    st = index.block_stats()
-    assert st["dense_terms"] > 0 and st["block_calls"] > 0      # the query-block kernel served the batches
+    st, cs = index.block_stats(), index.cert_stats()
+    if path == "exact":
+        assert st["dense_terms"] > 0 and st["block_calls"] > 0 and cs["searches"] == 0      # the query-block kernel served the batches
+    else:
+        assert cs["present"] == 1 and cs["searches"] >= 50 and cs["redone_exact"] <= cs["queries"] // 100
     assert doc_ids.long().sum().item() == ids_sum and vals.double().sum().item() == vals_sum
     # the first run against the oracle's C port of numba_score_float + select_topk on a few queries
     h_indptr, h_ids, h_vals = indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy()
