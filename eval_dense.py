@@ -151,6 +151,8 @@ class DenseRetriever:
 class LocalFaissDenseRetriever(DenseRetriever):
     """eval_dense.py:108-135 with the flat index resident in HBM (DenseFlatIndexer over the HIP scorer)."""
 
+    RUN_PIECES = 3            # write_run: pieces of the query set (search of piece c + 1 beside the writing of piece c)
+
     def __init__(self, model, device, index):
         super().__init__(model, device)
         self.index = index
@@ -171,10 +173,37 @@ class LocalFaissDenseRetriever(DenseRetriever):
     def write_run(self, dataloader, top_docs, path):
         """get_top_docs + the run.json loop of eval_dense.py:225-241 in one go, without materialising a Python object per hit:
         encode, search, and sr_write_run_json over the result arrays.  Returns (number of queries, file size)."""
-        from scaling_retriever_amd.utils.run_file import write_run_json
+        from scaling_retriever_amd.utils.run_file import id_table, write_run_json
         query_reps, qids = generate_query_vecs(self.model, dataloader, self.device)
-        scores, positions = self.index.search_arrays(query_reps, top_docs)
-        return len(qids), write_run_json(path, qids, scores, positions, self.index.run_table())
+        nq = len(qids)
+        table = self.index.run_table()
+        n_pieces = self.RUN_PIECES if nq >= 1024 and table.distinct and id_table(qids).distinct else 1
+        if n_pieces == 1:
+            scores, positions = self.index.search_arrays(query_reps, top_docs)
+            return nq, write_run_json(path, qids, scores, positions, table)
+        # the query set in pieces: the GPU searches piece c + 1 (worker thread; the C call releases the GIL) while this thread formats
+        # and writes piece c - the exact results do not depend on how the queries are batched (pieces stay above 64 queries)
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        per = (nq + n_pieces - 1) // n_pieces
+        bounds = [(c0, min(nq, c0 + per)) for c0 in range(0, nq, per)]
+        dev = self.index.index.device
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+
+        def gpu(c):
+            with torch.cuda.device(dev):
+                torch.cuda.current_stream(dev).wait_event(ready)
+                return self.index.search_arrays(query_reps[bounds[c][0]:bounds[c][1]], top_docs)
+        size = 0
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(gpu, 0)
+            for c, (b0, b1) in enumerate(bounds):
+                scores, positions = fut.result()
+                if c + 1 < len(bounds):
+                    fut = pool.submit(gpu, c + 1)
+                size = write_run_json(path, qids[b0:b1], scores, positions, table, part=1 if c == 0 else (3 if c + 1 == len(bounds) else 2))
+        return nq, size
 
 
 def retrieval(args):

@@ -311,6 +311,13 @@ int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_sc
                       const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off, int64_t qid_width,
                       const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off, int64_t doc_width,
                       int64_t n_docs, int32_t n_threads, int64_t* bytes_written);
+/* The same file in pieces, so that the host writes piece c while the GPU searches piece c + 1 (eval_dense.py:225-241 writes after the whole
+ * search): part 1 = first piece (creates the file, leaves it open-ended), 2 = a middle piece, 3 = the last piece (closes the object).
+ * The finished file holds the bytes of one sr_write_run_json call over the concatenated pieces.  *bytes_written = size so far.      */
+int sr_write_run_json_part(const char* path, int32_t part, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
+                           const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
+                           int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
+                           int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written);
 /* Test hook: rounds of sr_write_run_json that were copied through the shared file mapping (rounds of >= 8 MB with more than
  * one thread) since the library was loaded; the other rounds are written with pwrite.                                       */
 int64_t sr_run_writer_mapped_rounds(void);

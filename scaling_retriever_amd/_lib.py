@@ -83,6 +83,8 @@ SIGNATURES = {
     "sr_run_writer_mapped_rounds": (c_int64, []),
     "sr_write_run_json": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_int64)]),
+    "sr_write_run_json_part": (c_int, [c_char_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, ctypes.POINTER(c_int64)]),
     "sr_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sr_gemm_f16_scaled": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sr_gemm_qkv_rope": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -124,17 +124,44 @@ static std::atomic<int64_t> g_mapped_rounds{0};
 // rounds of sr_write_run_json that went through the shared file mapping since the library was loaded (test hook)
 extern "C" int64_t sr_run_writer_mapped_rounds(void) { return g_mapped_rounds.load(); }
 
+static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
+                               const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
+                               int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
+                               int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written, int part);
+
 extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
                                  const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
                                  int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
                                  int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written) {
+    return write_run_json_impl(path, nq, k, h_scores, h_idx, h_counts, h_qid_i64, h_qid_bytes, h_qid_off, qid_width, h_doc_i64, h_doc_bytes,
+                               h_doc_off, doc_width, n_docs, n_threads, bytes_written, 0);
+}
+
+// The same file in pieces (the GPU searches the next piece of the query set while the host writes this one): part 1 = first piece
+// (creates the file, no closing brace), 2 = a middle piece (appends), 3 = the last piece (appends and closes).  The bytes of the finished
+// file are those of ONE sr_write_run_json call over the concatenated pieces.  *bytes_written = file size so far.
+extern "C" int sr_write_run_json_part(const char* path, int32_t part, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
+                                      const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
+                                      int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
+                                      int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written) {
+    SR_REQUIRE(part >= 1 && part <= 3, "sr_write_run_json_part: part must be 1 (first), 2 (middle) or 3 (last)");
+    return write_run_json_impl(path, nq, k, h_scores, h_idx, h_counts, h_qid_i64, h_qid_bytes, h_qid_off, qid_width, h_doc_i64, h_doc_bytes,
+                               h_doc_off, doc_width, n_docs, n_threads, bytes_written, part);
+}
+
+static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const float* h_scores, const int64_t* h_idx,
+                               const int32_t* h_counts, const int64_t* h_qid_i64, const char* h_qid_bytes, const int64_t* h_qid_off,
+                               int64_t qid_width, const int64_t* h_doc_i64, const char* h_doc_bytes, const int64_t* h_doc_off,
+                               int64_t doc_width, int64_t n_docs, int32_t n_threads, int64_t* bytes_written, int part) {
     SR_REQUIRE(path && nq >= 0 && k >= 0, "sr_write_run_json: bad argument");
     SR_REQUIRE(nq == 0 || k == 0 || (h_scores && h_idx), "sr_write_run_json: null result arrays");
     SR_REQUIRE(nq == 0 || h_qid_i64 || (h_qid_bytes && (h_qid_off || qid_width > 0)), "sr_write_run_json: no query ids");
     SR_REQUIRE(n_docs >= 0 && (n_docs == 0 || h_doc_i64 || (h_doc_bytes && (h_doc_off || doc_width > 0))),
                "sr_write_run_json: no document ids");
     const Keys qk{h_qid_i64, h_qid_bytes, h_qid_off, qid_width}, dk{h_doc_i64, h_doc_bytes, h_doc_off, doc_width};
-    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);      // O_RDWR: a shared writable mapping needs read access (EACCES with O_WRONLY)
+    const bool opens = part == 0 || part == 1, closes = part == 0 || part == 3;
+    // O_RDWR: a shared writable mapping needs read access (EACCES with O_WRONLY)
+    const int fd = open(path, opens ? (O_RDWR | O_CREAT | O_TRUNC) : O_RDWR, 0644);
     if (fd < 0) {
         sr_set_error("sr_write_run_json: cannot open %s: %s", path, strerror(errno));
         return SR_ERR_INVALID;
@@ -154,8 +181,14 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
     std::vector<int64_t> off((size_t)nt, 0);
     std::vector<size_t> skip((size_t)nt, 0);
     int64_t total = 1;                                        // the opening brace
-    bool ok = pwrite(fd, "{", 1, 0) == 1;
-    bool any_entry = false;
+    bool ok = true, any_entry = false;
+    if (opens) ok = pwrite(fd, "{", 1, 0) == 1;
+    else {                                                    // a continuation: behind what the earlier pieces wrote
+        const off_t end = lseek(fd, 0, SEEK_END);
+        ok = end >= 1;
+        total = (int64_t)end;
+        any_entry = end > 1;
+    }
     for (int64_t q0 = 0; q0 < nq && ok; q0 += slab * nt) {
         auto work = [&](int t) {
             const int64_t a = q0 + (int64_t)t * slab, b = a + slab < nq ? a + slab : nq;
@@ -250,8 +283,10 @@ extern "C" int sr_write_run_json(const char* path, int64_t nq, int64_t k, const 
         }
         for (int t = 0; t < nt; ++t) ok = ok && !io_bad[(size_t)t];
     }
-    ok = ok && pwrite(fd, "}", 1, (off_t)total) == 1;
-    total += 1;
+    if (closes) {
+        ok = ok && pwrite(fd, "}", 1, (off_t)total) == 1;
+        total += 1;
+    }
     ok = (close(fd) == 0) && ok;
     for (int t = 0; t < nt; ++t)
         if (bad[(size_t)t]) {

@@ -130,10 +130,12 @@ def id_table(keys):
     return keys if isinstance(keys, IdTable) else IdTable(keys)
 
 
-def write_run_json(path, qids, scores, positions, doc_table, counts=None, n_threads=0):
+def write_run_json(path, qids, scores, positions, doc_table, counts=None, n_threads=0, part=0):
     """Write {str(qid): {str(doc id): float(score)}} for scores fp32 [nq, k] / positions int64 [nq, k] (rows of `doc_table`; negative =
     padding) / counts [nq] (hits per row, optional).  Returns the file size.  Falls back to json.dump of the materialised dict
-    when keys repeat (a dict merges them; the array writer would not)."""
+    when keys repeat (a dict merges them; the array writer would not).
+    part: 0 = the whole file; 1 / 2 / 3 = first / middle / last piece of a file written piece by piece (sr_write_run_json_part: the
+    pieces' qids must be distinct across pieces too - the caller's concern - and the finished file equals one call over all rows)."""
     scores = np.ascontiguousarray(scores, dtype=np.float32)
     positions = np.ascontiguousarray(positions, dtype=np.int64)
     nq, k = scores.shape if scores.ndim == 2 else (0, 0)
@@ -143,6 +145,8 @@ def write_run_json(path, qids, scores, positions, doc_table, counts=None, n_thre
     if counts is not None:
         counts = np.ascontiguousarray(counts, dtype=np.int32)
     if not (qt.distinct and dt.distinct):
+        if part:
+            raise ValueError("write_run_json: a file written in pieces needs distinct query and document keys")
         with open(path, "w") as f:
             json.dump(RunResult(qt, scores, positions, dt, counts).to_dict(), f)
         import os
@@ -150,6 +154,12 @@ def write_run_json(path, qids, scores, positions, doc_table, counts=None, n_thre
     lib = _lib.load()
     qa, da = qt.c_args(), dt.c_args()
     nbytes = ctypes.c_int64(0)
+    if part:
+        _lib.check(lib.sr_write_run_json_part(str(path).encode(), int(part), nq, k, scores.ctypes.data, positions.ctypes.data,
+                                              counts.ctypes.data if counts is not None else None,
+                                              qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3], dt.n, int(n_threads), ctypes.byref(nbytes)),
+                   "sr_write_run_json_part")
+        return nbytes.value
     _lib.check(lib.sr_write_run_json(str(path).encode(), nq, k, scores.ctypes.data, positions.ctypes.data,
                                      counts.ctypes.data if counts is not None else None,
                                      qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3], dt.n, int(n_threads), ctypes.byref(nbytes)),

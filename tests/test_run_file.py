@@ -157,3 +157,24 @@ def test_empty_result(tmp_path):
     p = tmp_path / "run.json"
     write_run_json(p, [], np.zeros((0, 10), np.float32), np.zeros((0, 10), np.int64), np.arange(5))
     assert p.read_text() == "{}"
+
+
+@pytest.mark.parametrize("cuts", [(0, 700), (300, 301), (0, 0), (1000, 1000)])
+def test_file_written_in_pieces_equals_the_whole(tmp_path, cuts):
+    """sr_write_run_json_part: first / middle / last pieces (the host writes piece c while the GPU searches piece c + 1) give the bytes
+    of one call over all rows - also when a piece is empty or holds only queries without hits."""
+    rng = np.random.default_rng(11)
+    nq, k, N = 1000, 37, 5000
+    scores, positions = _case(rng, nq, k, N)
+    positions[:40] = -1                                         # the first 40 queries have no hit: the file's first entry comes later
+    qids = [str(10 * i + 3) for i in range(nq)]
+    docs = np.arange(N) * 3
+    whole, parts = tmp_path / "whole.json", tmp_path / "parts.json"
+    n = write_run_json(whole, qids, scores, positions, docs, n_threads=3)
+    a, b = cuts
+    bounds = [(0, a), (a, b), (b, nq)]
+    size = 0
+    for c, (r0, r1) in enumerate(bounds):
+        size = write_run_json(parts, qids[r0:r1], scores[r0:r1], positions[r0:r1], docs, n_threads=3, part=c + 1)
+    assert size == n and parts.read_bytes() == whole.read_bytes()
+    assert json.loads(parts.read_text()) == _reference_dict(qids, scores, positions, docs)
