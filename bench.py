@@ -509,7 +509,9 @@ def sparse_index_leg(args, device):
     first = next(iter(loader()))
     with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
         reps = model.encode(input_ids=first["input_ids"].to(device), attention_mask=first["attention_mask"].to(device))
-    shift = float(torch.topk(reps[:64], 128, dim=1).values[:, -1].float().mean().item())
+    # the constant that leaves 128 entries per passage ON AVERAGE over the first batch (rows differ in scale: a per-row 128-th largest
+    # value, averaged, left 390)
+    shift = float(torch.topk(reps.flatten(), 128 * reps.shape[0]).values[-1].item())
     del reps
     stub = _ThresholdedSparseDocs(model, shift)
     with contextlib.redirect_stdout(sys.stderr):

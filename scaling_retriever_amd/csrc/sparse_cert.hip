@@ -788,10 +788,10 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             if (tail == 0 || tail == 3) cert_add_posting(row, p4.z, wv);
             if (tail == 0) cert_add_posting(row, p4.w, wv);
         };
-        // E words: ecur = the pair holding the tile being STAGED, enext = the pair behind it (loaded a pair ahead)
-        uint2 ecur[4], enext[4];
+        // E words: ecur = the pair of tiles holding the tile that is staged next; the pair behind it is loaded right after its second
+        // tile was staged, a whole step (the adds of 4 items) before it is needed
+        uint2 ecur[4];
         load_group(tile0 >> 1, ecur);
-        load_group((tile0 >> 1) + 1, enext);
         if (tile0 & 1) {
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
@@ -896,10 +896,8 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 cert_overflow_windows(mark, tab_delta, tab_w, a.P, wrow, e_cons[0], e_cons[1], e_cons[2], e_cons[3], Ltot);
         };
         auto advance_queue = [&](int tile) {
-            if (tile & 1) {                                      // wave-uniform: the next pair becomes current, the one behind it is fetched
-#pragma unroll
-                for (int qi = 0; qi < 4; ++qi) ecur[qi] = enext[qi];
-                load_group((tile >> 1) + 2, enext);
+            if (tile & 1) {                                      // wave-uniform: the pair of tiles tile + 1, tile + 2
+                load_group((tile >> 1) + 1, ecur);
             } else {
 #pragma unroll
                 for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
@@ -1010,15 +1008,33 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
     if (tid == 0) n_kept = 0;
     __syncthreads();
     uint64_t* dst = a.cand_keys + q * a.cand_cap;
+    // the first 64 entries of the NEXT candidate's forward row are loaded while this one is intersected (a row is a ~1 KB gather)
+    auto row_of = [&](int c, int64_t& b, int64_t& e, int32_t& t, float& v) {
+        const int64_t doc = a.ap_ids[q * a.k_eff + (c < m ? c : m - 1)];
+        b = a.fwd_indptr[doc];
+        e = a.fwd_indptr[doc + 1];
+        const int64_t p = b + lane;
+        t = p < e ? a.fwd_term[p] : 0x7fffffff;
+        v = p < e ? a.fwd_val[p] : 0.f;
+    };
+    int64_t nb, ne;
+    int32_t nt;
+    float nv;
+    if (wave < m) row_of(wave, nb, ne, nt, nv);
     for (int c = wave; c < m; c += 4) {
         const int64_t doc = a.ap_ids[q * a.k_eff + c];
-        const int64_t b = a.fwd_indptr[doc], e = a.fwd_indptr[doc + 1];
+        const int64_t b = nb, e = ne;
+        int32_t t = nt;
+        float v = nv;
+        if (c + 4 < m) row_of(c + 4, nb, ne, nt, nv);
         float s = 0.f;
         for (int64_t p0 = b; p0 < e; p0 += 64) {
-            const int64_t p = p0 + lane;
-            const bool live = p < e;
-            const int32_t t = live ? a.fwd_term[p] : 0x7fffffff;
-            const float v = live ? a.fwd_val[p] : 0.f;
+            if (p0 > b) {
+                const int64_t p = p0 + lane;
+                t = p < e ? a.fwd_term[p] : 0x7fffffff;
+                v = p < e ? a.fwd_val[p] : 0.f;
+            }
+            const bool live = p0 + lane < e;
             int lo = 0;                       // lower bound of t among the query's terms (padded with INT_MAX to SC_MAXQT)
 #pragma unroll
             for (int step = SC_MAXQT / 2; step > 0; step >>= 1)

@@ -196,3 +196,31 @@ def test_search_begin_lower_bound_is_an_exact_score_j_documents_reach():
     s, i = idx.search_finish(Q, k, lower)          # one shard standing in for all: every document >= lower comes back exactly
     keep = es >= lower[:, None]
     assert bool(((s == es) | ~keep).all()) and bool(((i >= 0) | ~keep).all())
+
+
+def test_write_run_in_pipelined_pieces_equals_one_file(tiny, tmp_path):
+    """>= 1 024 queries: write_run searches in RUN_PIECES pieces (GPU on piece c + 1 while the host formats and writes piece c through
+    sr_write_run_json_part); the file holds the bytes of the one-piece run, which are json.dump's of the reference's loop."""
+    import eval_dense
+    from scaling_retriever_amd.indexer import DenseFlatIndexer
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiDense
+    cfg, w = tiny
+    H = cfg["hidden_size"]
+    rng = np.random.default_rng(18)
+    model = LlamaBiDense.from_weights(cfg, w).to("cuda").eval()
+    n_docs = 20_000
+    index = DenseFlatIndexer()
+    index.init_index(H)
+    index.index_data(rng.standard_normal((n_docs, H)).astype(np.float32), [f"P{5 * i}" for i in range(n_docs)])
+    retriever = eval_dense.LocalFaissDenseRetriever(model, index=index, device="cuda")
+    loader = _batches(np.random.default_rng(19), cfg["vocab_size"], [64] * 17 + [13], 2, 12)          # 1 101 queries
+    for i, b in enumerate(loader):
+        b["ids"] = [str(1000 * i + j) for j in range(len(b["ids"]))]
+    p3, p1 = tmp_path / "run3.json", tmp_path / "run1.json"
+    assert retriever.RUN_PIECES == 3
+    n_q, n3 = retriever.write_run(loader, 30, str(p3))
+    retriever.RUN_PIECES = 1
+    _, n1 = retriever.write_run(loader, 30, str(p1))
+    assert n_q == 1101 and n3 == n1 == p1.stat().st_size and p3.read_bytes() == p1.read_bytes()
+    run = json.loads(p3.read_text())
+    assert len(run) == 1101 and all(len(v) == 30 for v in run.values())
