@@ -234,10 +234,12 @@ __global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __res
 void sparse_cert_destroy(SparseCert* c) {
     if (!c) return;
     if (c->d_stamps) {          // diagnostic: mean cycles per tile step of the sampled waves
-        unsigned long long h[8] = {0};
+        unsigned long long h[16] = {0};
         if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] && h[6])
-            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f (of it slot reads + MFMA chain %.0f) barrier %.0f (%llu steps)\n",
-                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[7] / h[6], (double)h[5] / h[6], h[6]);
+            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f (of it slot reads + MFMA chain %.0f) barrier %.0f (%llu steps); "
+                            "step %.0f: last matrix wave at %.0f, last scatter wave at %.0f, scatter last in %.0f %% of the steps\n",
+                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[7] / h[6], (double)h[5] / h[6], h[6],
+                    (double)h[11] / h[6], (double)h[8] / h[6], (double)h[9] / h[6], 100.0 * (double)h[10] / h[6]);
         (void)hipFree(c->d_stamps);
     }
     void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
@@ -301,10 +303,7 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         int n_heavy = (int)std::min<size_t>(heavy.size(), (size_t)t_max);
         c->T = std::max(16, (n_heavy + 15) / 16 * 16);
         c->KS = c->T / 16;
-        if (c->KS != 1 && c->KS != 2 && c->KS != 4 && c->KS != 8) {     // instantiated k-step counts
-            c->KS = c->KS < 4 ? 4 : 8;
-            c->T = c->KS * 16;
-        }
+        if (c->KS == 3) { c->KS = 4; c->T = 64; }                         // instantiated k-step counts: 1, 2, 4 .. 8
         std::vector<int32_t> h_slot((size_t)V, -1), h_terms((size_t)std::max(1, n_heavy));
         for (int i = 0; i < n_heavy; ++i) {
             h_slot[(size_t)heavy[(size_t)i].second] = i;
@@ -542,6 +541,9 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
     return v;
 }
 
+#ifndef SC_STAMPS
+#define SC_STAMPS 0                   // 1: the per-role cycle stamps (dev switch SR_CERT_STAMPS) are compiled in; they cost registers, so the product build leaves them out
+#endif
 #ifndef SC_DP
 #define SC_DP 8                       // A fragments in flight per matrix wave
 #endif
@@ -619,6 +621,12 @@ __device__ __noinline__ void cert_overflow_windows(unsigned short* mark, const u
     }
 }
 
+constexpr int sc_ring_depth(int nl) {
+    int d = nl < SC_DP ? nl : SC_DP;
+    while (nl % d) --d;
+    return d;
+}
+
 template <int KS>
 __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     extern __shared__ uint32_t slots[];                          // 2 x [SC_QB][SC_PITCH_W] | B fragments | mark buffers
@@ -638,6 +646,8 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     // the query block's MFMA B fragments (k-step s: 64 lanes x 8 halves), read back per k-step: they would cost 4 KS VGPRs
     f16x8* const bl = reinterpret_cast<f16x8*>(slots + 2 * SC_SLOT_WORDS);
     if (tid < KS * 64) bl[tid] = a.bfrag[(int64_t)qb * KS * 64 + tid];
+    const bool st_wg = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0;            // dev switch: this workgroup's waves report their barrier arrivals
+    unsigned long long* const t_end = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(bl + KS * 64) + 8 * SC_WAVE_LDS);
     __syncthreads();
     // The two roles work on DIFFERENT tiles: in step t the scatter waves add the rare postings of tile t into LDS tile t & 1 while
     // the matrix waves multiply tile t - 1, add LDS tile (t - 1) & 1 to it, filter and clear it.  One barrier per step.
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         // The A fragments of a tile are a sequence of NL = 4 KS loads (block, k-step); DP of them are in flight
         // in a ring of registers at any time, across tile boundaries too - the matrix pipe never waits for a fresh round trip.
         constexpr int NL = 4 * KS;
-        constexpr int DP = NL < SC_DP ? NL : SC_DP;
+        constexpr int DP = sc_ring_depth(NL);                    // the ring runs across tile boundaries: its depth divides NL
         // fragment i = (block, k-step) of the wave's tile slice lies i KB behind the slice's start: wave-uniform base (SGPRs) + 16 lane + immediate.
         // (Measured and dropped, both at the same time per tile step: a per-workgroup rotation of the fragment order, against 32 workgroups
         // of an XCD reading the same lines of a tile at the same time; an L2 warm-up of the tile three steps ahead by LDS-DMA loads.)
@@ -673,8 +683,9 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bq[ks] = bl[ks * 64 + lane];
         __syncthreads();                                         // step tile0: the scatter waves fill LDS tile tile0 & 1
-        const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
+        const bool st_on = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
         unsigned long long st_w = 0, st_b = 0, st_n = 0, st_m = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
+        unsigned long long st_mm = 0, st_ms = 0, st_sl = 0, st_step = 0, st_0 = st_t;   // per step: when the last matrix / scatter wave reached the barrier
         for (int tile = tile0; tile < tile1; ++tile) {
             const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
             uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
@@ -742,10 +753,20 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 }
             }
             if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_w += now - st_t; st_t = now; }
+            if (st_wg && lane == 0) t_end[wave] = __builtin_readcyclecounter();
             __syncthreads();                                     // step tile + 1
-            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
+            if (st_on) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                unsigned long long mm = 0, ms = 0;
+                for (int w = 0; w < 8; ++w) { mm = t_end[w] > mm ? t_end[w] : mm; ms = t_end[8 + w] > ms ? t_end[8 + w] : ms; }
+                st_mm += mm - st_0; st_ms += ms - st_0; st_sl += ms > mm ? 1 : 0; st_step += now - st_0; st_0 = now;
+                st_b += now - st_t; st_t = now; ++st_n;
+            }
         }
-        if (st_on && lane == 0) { atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); atomicAdd(&a.stamps[7], st_m); }
+        if (st_on && lane == 0) {
+            atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); atomicAdd(&a.stamps[7], st_m);
+            atomicAdd(&a.stamps[8], st_mm); atomicAdd(&a.stamps[9], st_ms); atomicAdd(&a.stamps[10], st_sl); atomicAdd(&a.stamps[11], st_step);
+        }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
         // What a (query, tile) item adds: per rare term the run of its postings inside the tile.  Table E gives the run in ONE word per
@@ -905,7 +926,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         };
         stage_all(tile0);
         advance_queue(tile0);
-        const bool st_on = a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 8;
+        const bool st_on = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 8;
         unsigned long long st_c = 0, st_s = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
             consume_all(slots + (tile & 1) * SC_SLOT_WORDS);     // the loads were issued a step ago
@@ -913,6 +934,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             stage_all(tile + 1);
             advance_queue(tile + 1);
             if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_s += now - st_t; st_t = now; }
+            if (st_wg && lane == 0) t_end[wave] = __builtin_readcyclecounter();
             __syncthreads();                                     // step tile + 1
             if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
@@ -1069,7 +1091,7 @@ static int cert_realloc(T*& p, size_t n) {
 template <int KS>
 static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
     static DeviceOnce lds_set;
-    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_WAVE_LDS);
+    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_WAVE_LDS + (a.stamps ? 128 : 0));
     if (bool* slot = lds_set.pending()) {
         SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         *slot = true;
@@ -1135,20 +1157,22 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     a.cand_keys = c->ws.cand_keys; a.cand_count = c->ws.cand_count; a.cand_cap = c->ws.cand_cap; a.overflow = c->overflow;
     a.n_qblocks = n_qblocks;
     a.dump = c->want_dump ? c->dump : nullptr;
-    if (sr_dev_getenv("SR_CERT_STAMPS") && !c->d_stamps) {
-        SR_CHECK_HIP(hipMalloc((void**)&c->d_stamps, 8 * 8));
-        SR_CHECK_HIP(hipMemsetAsync(c->d_stamps, 0, 8 * 8, s));
+    if (SC_STAMPS && sr_dev_getenv("SR_CERT_STAMPS") && !c->d_stamps) {
+        SR_CHECK_HIP(hipMalloc((void**)&c->d_stamps, 16 * 8));
+        SR_CHECK_HIP(hipMemsetAsync(c->d_stamps, 0, 16 * 8, s));
     }
     a.stamps = c->d_stamps;
     a.dump_stride = dump_stride;
     int64_t step = 1;
+    int64_t tpw_max = 16;                  // tiles a workgroup walks: amortises its prologue; the chunk's operand (256 KB per tile at T = 128) should stay in its XCD's L2
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_TPW")) tpw_max = std::max(1, atoi(e));
     for (int64_t t0 = 0; t0 < c->n_tiles;) {
         int64_t nt = step < 512 ? step : 512;
         if (t0 + nt > c->n_tiles) nt = c->n_tiles - t0;
         a.tile_begin = (int)t0;
         a.n_tiles_launch = (int)nt;
         int64_t tpw = nt * n_qblocks / 1024;           // enough workgroups to fill the chip, then longer walks per workgroup
-        tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+        tpw = tpw < 1 ? 1 : (tpw > tpw_max ? tpw_max : tpw);
         a.tiles_per_wg = (int)tpw;
         const int64_t n_chunks = ceil_div64(nt, tpw);
         const unsigned grid = (unsigned)(ceil_div64(n_chunks, 8) * 8 * n_qblocks);
@@ -1158,6 +1182,9 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
             case 1: rc = cert_launch_score<1>(a, grid, s); break;
             case 2: rc = cert_launch_score<2>(a, grid, s); break;
             case 4: rc = cert_launch_score<4>(a, grid, s); break;
+            case 5: rc = cert_launch_score<5>(a, grid, s); break;
+            case 6: rc = cert_launch_score<6>(a, grid, s); break;
+            case 7: rc = cert_launch_score<7>(a, grid, s); break;
             case 8: rc = cert_launch_score<8>(a, grid, s); break;
             default: sr_set_error("sparse_cert_search: %d k-steps are not instantiated", c->KS); rc = SR_ERR_INVALID; break;
         }

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Regenerates the measurement table of DESIGN.md section 6 from a bench line, so that the document cannot drift from the numbers:
-python tools/design_table.py profiles/r04_bench_line.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
+python tools/design_table.py profiles/r05_bench_line.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_bench_line.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_line.json")
 r = json.load(open(src))
 rf, bd = r["roofline"], r["breakdown"]
 rows = []
@@ -22,7 +22,7 @@ row("queries/s end to end at the reference's precision: fp32-regime query encode
 row("dominant kernel `dense_split_kernel<true>` (the certified filter's upper-bound pass, fp16 MFMA)",
     f"{rf['achieved']:.0f} TFLOP/s = **{rf['frac']:.3f} of the 16-bit MFMA peak**; {rf['avg_launch_ms']:.4f} ms per launch by HIP events, {rf['launches'] // r['steps']} launches per search = "
     f"{100 * rf['kernel_share_of_step']:.0f} % of the step; {rf['queries_certified']} queries certified, {rf['queries_redone_by_exact_kernel']} re-done; "
-    f"traffic beyond L2 per launch: {(rf['traffic'] or 0) / 1e9:.2f} GB (`profiles/r04_pmc_traffic.json`)")
+    f"traffic beyond L2 per launch: {(rf['traffic'] or 0) / 1e9:.2f} GB (`profiles/r05_pmc_traffic.json`)")
 em = r.get("exact_kernel_mode") or {}
 if em:
     row("the same step through the exact fp32 MFMA kernel (`exact_kernel_mode`: the data-independent floor)",
@@ -65,15 +65,22 @@ for sb in r.get("small_batch") or []:
     row(f"small-batch dense score, nq = {sb['nq']} (HBM-bound, `dense_stream_kernel`)", f"{sb['achieved'] / 1e3:.2f} TB/s = {sb['frac']:.2f} of the 8 TB/s spec ({sb['ms_per_search']} ms per pass)")
 sp = r.get("sparse")
 if sp:
-    b = sp["bounds"]
-    row("sparse scoring, full MSMARCO shape (configs[2])", f"**{sp['value']:.0f} queries/s** ({sp['ms_per_pass']} ms per pass, kernel {sp['roofline']['kernel_ms_per_pass']} ms); {sp['parity']}; "
-        f"HBM floor {sp['roofline']['hbm_floor_ms_per_pass']} ms (frac {sp['roofline']['frac']}): not HBM-bound")
-    row("... what the kernel does, counted on the device", f"dense-column multiply-adds {b['valu_dense_columns']['ops_per_pass']:.3g} lane-ops: VALU floor {b['valu_dense_columns']['floor_ms_per_pass']} ms; "
-        f"bytes loaded {b['l2_bytes_loaded']['bytes_per_pass']:.3g} (columns {b['l2_bytes_loaded']['of_which_dense_columns']:.3g}): L2 floor {b['l2_bytes_loaded']['floor_ms_per_pass']} ms; "
-        f"scattered postings {b['lds_scatter']['rmw_per_pass']:.3g}: LDS floor {b['lds_scatter']['floor_ms_per_pass']} ms; sum of floors {b['sum_of_floors_ms']} ms, kernel / floors = {b['kernel_over_sum_of_floors']}")
-    if sp["roofline"].get("traffic"):
-        row("... HBM / fabric traffic of the sparse scorer", f"{sp['roofline']['traffic'] / 1e9:.0f} GB beyond L2 per pass against {sp['roofline']['unique_index_bytes_per_pass'] / 1e9:.1f} GB of unique posting bytes "
-            f"(`profiles/r04_pmc_sparse_traffic.json`)")
+    b, rf2, ex = sp["bounds"], sp["roofline"], sp.get("exact_kernels") or {}
+    row("sparse scoring, full MSMARCO shape (configs[2])", f"**{sp['value']:.0f} queries/s** ({sp['ms_per_pass']} ms per pass: `cert_score_kernel` {rf2['kernel_ms_per_pass']} ms in {rf2['launches']} launches, "
+        f"the other kernels {rf2.get('other_kernels_ms_per_pass')} ms; {sp['path']['queries_redone_by_the_exact_kernels_per_pass']} queries re-done by the exact kernels); {sp['parity']}; "
+        + (f"the exact kernels alone: {ex['queries_per_s']:.0f} queries/s (kernels {ex['kernel_ms_per_pass']} ms), same bits: {ex['same_bits_as_the_product_path']}" if ex else ""))
+    m, l2, ld = b["mfma_heavy_terms"], b["l2_matrix_operand"], b["lds_rare_postings"]
+    row("... what the scorer does, counted on the device", f"heavy terms on the matrix pipe {m['flop_per_pass']:.3g} flop: MFMA floor {m['floor_ms_per_pass']} ms; matrix operand out of L2 {l2['bytes_per_pass']:.3g} B: "
+        f"L2 floor {l2['floor_ms_per_pass']} ms; rare postings {ld['adds_per_pass']:.3g} LDS adds: LDS floor {ld['floor_ms_per_pass']} ms; sum of floors {b['sum_of_floors_ms']} ms, "
+        f"kernel / floors = **{b['kernel_over_sum_of_floors']}**")
+    row("... HBM side of the sparse scorer", f"unique posting bytes per pass {rf2['unique_index_bytes_per_pass'] / 1e9:.1f} GB (all 6 980 queries in one batch; {rf2['unique_index_bytes_per_pass_in_batches_of_1024'] / 1e9:.1f} GB in "
+        f"batches of 1 024 as round 4 ran them): HBM floor {rf2['hbm_floor_ms_per_pass']} ms, frac {rf2['frac']}"
+        + (f"; traffic beyond L2 per pass {rf2['traffic'] / 1e9:.0f} GB (`profiles/r05_pmc_sparse_traffic.json`)" if rf2.get("traffic") else ""))
+    ib = sp.get("index_build")
+    if ib:
+        row("CSR-by-term build (`sr_sparse_csr_build`), full MSMARCO shape", f"**{ib['postings_per_s'] / 1e9:.1f} G postings/s** ({ib['seconds'] * 1e3:.0f} ms for {sp['config']['postings']} postings, "
+            f"{ib['roofline']['achieved']:.0f} GB/s of algorithmic bytes = {ib['roofline']['frac']:.3f} of HBM); bit-identical to the source index: {ib['bit_identical_to_the_source_index']}; "
+            f"forward index by doc: {ib['forward_index_by_doc']['seconds'] * 1e3:.0f} ms")
     if sp.get("drop_in"):
         d2 = sp["drop_in"]
         row("drop-in: `SparseRetrieval.retrieve` incl. `run.json` + `q_stats.json` (`indexer.py:530-540`)",
@@ -82,16 +89,21 @@ if sp:
     if sw:
         cells = "; ".join(f"{x['index']} {x['L0_d']}/{x['L0_q']}: {x['queries_per_s'] / 1e3:.1f} k" for x in sw["rows"])
         row("sparse sweep (index L0_d/L0_q: queries/s; 64 queries per cell bit-exact vs the C oracle)", cells)
+    si = sp.get("sparse_index")
+    if si:
+        row("drop-in: `SparseIndexer.index` (encode + sparse head + compaction + CSR build)", f"**{si['passages_per_s']:.0f} passages/s** ({si['seconds']} s, L0_d {si['L0_d']}, {si['postings']} postings) = "
+            f"{si['roofline']['achieved']:.0f} TFLOP/s = {si['roofline']['frac']:.3f} of bf16 MFMA peak over the wall time; MSMARCO extrapolation {si['msmarco_extrapolation_minutes']} min")
     cb = sp["cpu_baseline"]
     row("sparse CPU baseline", f"{cb['value']} queries/s with the reference's 32 threads (4 × 8); best shape on the host: {cb['best_shape_on_this_host']['value']} with {cb['best_shape_on_this_host']['threads']} threads")
 cb = r.get("cpu_baseline")
 if cb:
-    row("dense CPU baseline (faiss's algorithm: BLAS sgemm blocks + a heap per query)", f"{cb['value']} queries/s on {cb.get('host_cpu')} ({cb['cores']} hardware threads, {cb.get('threads')} used: the best sgemm rate measured, "
-        f"{cb.get('sgemm_gflops')} GFLOP/s; sgemm {cb.get('sgemm_s')} s + heaps {cb.get('heap_s')} s on the sample)")
-table = "\n".join([f"| r04, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
+    al = cb.get("all_hardware_threads")
+    row("dense CPU baseline (faiss's algorithm: BLAS sgemm blocks + a heap per query)", f"**{cb['value']} queries/s** with {cb['cores']} threads on {cb.get('host_cpu')} (median of 3 runs, sgemm at {cb.get('sgemm_gflops')} GFLOP/s)"
+        + (f"; with all {al['threads']} hardware threads: {al['value']} queries/s (runs {al['seconds']} s)" if al else ""))
+table = "\n".join([f"| r05, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-B, E = "<!-- BEGIN r04 table (tools/design_table.py) -->", "<!-- END r04 table -->"
+B, E = "<!-- BEGIN r05 table (tools/design_table.py) -->", "<!-- END r05 table -->"
 if B in s:
     s = s[:s.index(B) + len(B)] + "\n" + table + "\n" + s[s.index(E):]
     open(p, "w").write(s)
