@@ -160,6 +160,11 @@ struct TopkWS {
 int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s);
 // merge candidates into the running top-k (per query), update tau, clear candidates
 int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s);
+// the same, and where a select runs also d_tau2[q] := the score of the k2-th best key of the union (k2 < k; 0 / nullptr: off); d_tau2 is never lowered
+// by the caller's protocol: a query whose compaction only appends keeps its previous value
+// select_over in [k, 2 k]: the running set is cut back to k (and tau, tau2 refreshed) once it holds more keys than this - 2 k fills the
+// slots before it pays for a select, k selects in every call that brought a candidate
+int topk_compact2(TopkWS& ws, int64_t nq, int k, int k2, float* d_tau2, int select_over, hipStream_t s);
 // sort the running top-k descending and write [nq, k] outputs (+ optional counts)
 int topk_finalize(TopkWS& ws, int64_t nq, int k, float pad_score, float* d_out_scores,
                   int64_t* d_out_ids, int32_t* d_out_counts, hipStream_t s);

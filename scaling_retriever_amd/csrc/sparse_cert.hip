@@ -77,6 +77,7 @@ struct SparseCert {
     int32_t* n_rare = nullptr;        // [nq_pad]
     int32_t* n_qt = nullptr;          // [nq_pad]
     int32_t* n_drop = nullptr;        // [nq_pad] rare terms left out of stage 1 (weight below fp16's normal range)
+    float* tau2 = nullptr;            // [nq_pad] k-th best key so far (topk_compact2), 0 until a select has run: the band below it is the filter threshold
     uint8_t* elig = nullptr;          // [nq_pad]
     uint8_t* overflow = nullptr;      // [nq_pad]
     int32_t* m_count = nullptr;       // [nq_pad] candidates to re-score
@@ -234,16 +235,29 @@ __global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __res
 void sparse_cert_destroy(SparseCert* c) {
     if (!c) return;
     if (c->d_stamps) {          // diagnostic: mean cycles per tile step of the sampled waves
-        unsigned long long h[16] = {0};
-        if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] && h[6])
-            fprintf(stderr, "[cert stamps] scatter wave: add %.0f stage %.0f barrier %.0f cycles per step (%llu steps); matrix wave: work %.0f (of it slot reads + MFMA chain %.0f) barrier %.0f (%llu steps); "
-                            "step %.0f: last matrix wave at %.0f, last scatter wave at %.0f, scatter last in %.0f %% of the steps\n",
-                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3], (double)h[4] / h[6], (double)h[7] / h[6], (double)h[5] / h[6], h[6],
-                    (double)h[11] / h[6], (double)h[8] / h[6], (double)h[9] / h[6], 100.0 * (double)h[10] / h[6]);
+        unsigned long long h[80] = {0};
+        if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0]) {
+            const double n = (double)h[0];
+            fprintf(stderr, "[cert stamps] %llu sampled tile steps of %.0f cycles: last matrix wave at the barrier after %.0f, last scatter wave after %.0f (scatter last in %.0f %% of the steps); first blocks of wave 1 with a candidate: %.0f %%; single candidates per step %.1f, steps over the %d LDS words %.1f %%\n",
+                    h[0], (double)h[1] / n, (double)h[2] / n, (double)h[3] / n, 100.0 * (double)h[4] / n, 100.0 * (double)h[5] / n);
+            fprintf(stderr, "[cert stamps]   matrix waves  : barrier arrival");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", (double)h[16 + w] / n);
+            fprintf(stderr, " | end of the last MFMA chain");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", (double)h[32 + w] / n);
+            fprintf(stderr, " | keys of the first block done");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", (double)h[48 + w] / n);
+            fprintf(stderr, " | end of the first filter");
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", (double)h[64 + w] / n);
+            fprintf(stderr, "\n[cert stamps]   scatter waves : barrier arrival");
+            for (int w = 8; w < 16; ++w) fprintf(stderr, " %.0f", (double)h[16 + w] / n);
+            fprintf(stderr, " | end of the adds");
+            for (int w = 8; w < 16; ++w) fprintf(stderr, " %.0f", (double)h[32 + w] / n);
+            fprintf(stderr, "\n");
+        }
         (void)hipFree(c->d_stamps);
     }
     void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
-                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
+                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->tau2, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws.release();
@@ -486,6 +500,19 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------- score kernel ---
+// The cut on stage-1 keys that follows from K = the k-th best key (of all docs, or of the docs seen so far): a doc whose key lies under it
+// cannot be among the k best reference scores (the bound of DESIGN.md 4.6).  Monotone in K, so the cut from the k-th best key SO FAR
+// is a valid filter threshold while the scan runs, and it is what cert_select_kernel applies to the final list.  < 1: no cut.
+__device__ __forceinline__ double cert_cut_from_kth(double Kk, int T, int n_rare, int n_qt, int n_drop) {
+    // relative error of the MFMA part: two fp16 roundings (2^-11 each, and their product), fp32 accumulation over T terms, the
+    // scaling multiply; gamma: the reference's fp32 chain against real arithmetic
+    const double dd = 2.0 * 4.8828125e-4 + 2.4e-7 + (double)T * 2.4e-7 + 1.0e-5;
+    const double gamma = ((double)n_qt + 2.0) * 6.0e-8 * 1.01;
+    const double lb = (Kk - 1.2 - 1.01 * (double)n_rare) / (1.0 + dd);           // lower bound of the k-th true_fix
+    // a doc's true_fix is at most (key + 1.2) / (1 - dd) + 2.03 per rare term that stage 1 left out
+    return floor((lb * (1.0 - gamma) / (1.0 + gamma) - 2.03 * (double)n_drop) * (1.0 - dd) - 1.2) - 1.0;
+}
+
 struct CertArgs {
     const f16x8* d16;
     const uint32_t* P;
@@ -498,6 +525,11 @@ struct CertArgs {
     const float* rare_w;
     const float* cq;
     const float* tau;        // (k + band)-th best key so far, -inf until that many are held
+    const float* tau2;       // k-th best key so far (0: not known yet); with n_rare / n_qt / n_drop / T it gives the band cut, usually the tighter threshold
+    const int32_t* n_rare;
+    const int32_t* n_qt;
+    const int32_t* n_drop;
+    int T;
     int64_t nq;
     uint64_t* cand_keys;
     int* cand_count;
@@ -505,6 +537,7 @@ struct CertArgs {
     uint8_t* overflow;
     int tile_begin, n_tiles_launch, tiles_per_wg, n_qblocks;
     uint16_t* dump;          // debug: [nq_pad][dump_stride] keys
+    int stamps_from;              // SR_CERT_STAMPS=<first tile>: only launches that begin at this tile or later are sampled
     unsigned long long* stamps;   // dev switch SR_CERT_STAMPS: [8] cycle sums per phase of sampled waves
     int64_t dump_stride;
 };
@@ -551,6 +584,8 @@ __device__ __forceinline__ int sc_scan_max(int v) {             // values >= 0
 #define SC_QUADS (SC_ITERS * 64)      // quads staged per wave and tile; also the 16-bit entries of a wave's mark buffer
 #define SC_WAVE_LDS (SC_QUADS * 2 + 256 * 4 + 256 * 2)   // bytes per scatter wave: marks, delta table, weight table
 #define SC_SLOT_WORDS (SC_QB * SC_PITCH_W)
+#define SC_BREGION 8192               // bytes: the query block's B fragments until they sit in registers (1 KB per k-step)
+#define SC_TAIL_LDS (8 * SC_WAVE_LDS)  // the scatter waves' buffers
 
 // The quads of a scatter wave's 4 items beyond the SC_QUADS staged ones: further windows of SC_QUADS through the same flat walk, loads
 // and adds back to back (one memory round trip per 2 048 postings).  Not inlined: the kernel's register allocation is sized for the
@@ -621,6 +656,12 @@ __device__ __noinline__ void cert_overflow_windows(unsigned short* mark, const u
     }
 }
 
+#if SC_STAMPS
+#define SC_STAMP(ph) do { if (st_wg && lane == 0) t_ph[(ph) * 16 + wave] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define SC_STAMP(ph) do { } while (0)
+#endif
+
 constexpr int sc_ring_depth(int nl) {
     int d = nl < SC_DP ? nl : SC_DP;
     while (nl % d) --d;
@@ -646,8 +687,10 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
     // the query block's MFMA B fragments (k-step s: 64 lanes x 8 halves), read back per k-step: they would cost 4 KS VGPRs
     f16x8* const bl = reinterpret_cast<f16x8*>(slots + 2 * SC_SLOT_WORDS);
     if (tid < KS * 64) bl[tid] = a.bfrag[(int64_t)qb * KS * 64 + tid];
-    const bool st_wg = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0;            // dev switch: this workgroup's waves report their barrier arrivals
-    unsigned long long* const t_end = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(bl + KS * 64) + 8 * SC_WAVE_LDS);
+    // dev switch SR_CERT_STAMPS (compiled in with -DSC_STAMPS=1): every wave of a sampled workgroup leaves the time of its phase ends in LDS (one lane, one
+    // 32-bit write each); matrix wave 0 adds them up in global memory after the step's barrier - nothing is carried in registers across the loop
+    const bool st_wg = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0 && a.tile_begin >= a.stamps_from;
+    volatile uint32_t* const t_ph = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<char*>(bl) + SC_BREGION + SC_TAIL_LDS);   // [4 phases][16 waves]
     __syncthreads();
     // The two roles work on DIFFERENT tiles: in step t the scatter waves add the rare postings of tile t into LDS tile t & 1 while
     // the matrix waves multiply tile t - 1, add LDS tile (t - 1) & 1 to it, filter and clear it.  One barrier per step.
@@ -657,7 +700,11 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         const int qn = lane & 31, h = lane >> 5;
         const int64_t q = (int64_t)qb * SC_QB + qn;
         const float cq = a.cq[q];
-        const float tq = q < a.nq ? a.tau[q] : INFINITY;
+        float tq = q < a.nq ? a.tau[q] : INFINITY;
+        if (q < a.nq && a.tau2[q] > 0.f) {
+            const double cb = cert_cut_from_kth((double)a.tau2[q], a.T, a.n_rare[q], a.n_qt[q], a.n_drop[q]);
+            if (cb >= 1.0 && (float)cb > tq) tq = (float)cb;
+        }
         int cut = 1;                                             // keys of 0 are never candidates
         if (tq > 1.f) cut = tq >= 65536.f ? 65536 : (int)ceilf(tq);
         const uint32_t cutm1 = (uint32_t)(cut - 1);
@@ -683,9 +730,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bq[ks] = bl[ks * 64 + lane];
         __syncthreads();                                         // step tile0: the scatter waves fill LDS tile tile0 & 1
-        const bool st_on = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
-        unsigned long long st_w = 0, st_b = 0, st_n = 0, st_m = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
-        unsigned long long st_mm = 0, st_ms = 0, st_sl = 0, st_step = 0, st_0 = st_t;   // per step: when the last matrix / scatter wave reached the barrier
+        uint32_t st_0 = st_wg ? (uint32_t)__builtin_readcyclecounter() : 0u;      // start of the step (matrix wave 0's barrier exit)
         for (int tile = tile0; tile < tile1; ++tile) {
             const int tnext = tile + 1 < tile1 ? tile + 1 : tile;    // past the end: re-reads this tile (no branch around the loads)
             uint32_t* const buf = slots + (tile & 1) * SC_SLOT_WORDS;
@@ -707,7 +752,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_m += now - st_t; st_w += now - st_t; st_t = now; }
+                if (mbi == 3) SC_STAMP(1);                       // end of the step's last MFMA chain
                 // accumulators -> 16-bit fixed point, two docs per word: register pair (2 g, 2 g + 1) = rows 8 (g / 2) + 4 h + 2 (g % 2) + {0, 1};
                 // + the LDS tile's fixed-point sums of the rare terms
                 uint2 sv[4];
@@ -736,7 +781,12 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                         *reinterpret_cast<uint32_t*>(a.dump + q * a.dump_stride + doc) = key[g];
                     }
                 }
-                if (any != 0) {                                  // rare once the threshold has risen: a few lanes per tile
+                if (mbi == 0) {
+                    SC_STAMP(2);                                 // first block: keys done (LDS sums read and cleared), before the candidates
+                    if (SC_STAMPS && st_wg && wave == 1 && __builtin_amdgcn_ballot_w64(any != 0) != 0 && lane == 0) atomicAdd(&a.stamps[5], 1ull);
+                }
+                if (SC_DIAG & 128) any = 0;                      // timing only: no candidates
+                if (any != 0) {                                  // one block in two at the MSMARCO shape once the threshold has risen (46 % in the launches from tile 2 000 on)
                     int cnt = 0;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) cnt += ((key[g] & 0xffffu) > cutm1 ? 1 : 0) + ((key[g] >> 16) > cutm1 ? 1 : 0);
@@ -751,21 +801,24 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                         if (hi > cutm1) { if (pos < a.cand_cap) dst[pos] = sr_make_key((float)hi, doc + 1u); ++pos; }
                     }
                 }
+                if (mbi == 0) SC_STAMP(3);                       // end of the first block's filter
             }
-            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_w += now - st_t; st_t = now; }
-            if (st_wg && lane == 0) t_end[wave] = __builtin_readcyclecounter();
+            SC_STAMP(0);
             __syncthreads();                                     // step tile + 1
-            if (st_on) {
-                const unsigned long long now = __builtin_readcyclecounter();
-                unsigned long long mm = 0, ms = 0;
-                for (int w = 0; w < 8; ++w) { mm = t_end[w] > mm ? t_end[w] : mm; ms = t_end[8 + w] > ms ? t_end[8 + w] : ms; }
-                st_mm += mm - st_0; st_ms += ms - st_0; st_sl += ms > mm ? 1 : 0; st_step += now - st_0; st_0 = now;
-                st_b += now - st_t; st_t = now; ++st_n;
+            if (st_wg && wave == 0) {
+                const uint32_t now = (uint32_t)__builtin_readcyclecounter();
+                uint32_t d = t_ph[lane] - st_0;            // lane 16 p + w: phase p of wave w, cycles since the step began
+                if ((int32_t)d < 0) d = 0u;                                   // a workgroup's last step: the scatter waves have no tile left (their figures come out low by 1 / steps per workgroup)
+                atomicAdd(&a.stamps[16 + lane], (unsigned long long)d);
+                uint32_t mx = lane < 16 ? d : 0u;                             // barrier arrival of the slowest wave per role
+                for (int o = 1; o < 8; o <<= 1) { const uint32_t oth = (uint32_t)__shfl_xor((int)mx, o); mx = oth > mx ? oth : mx; }
+                const uint32_t mm = (uint32_t)__shfl((int)mx, 0), ms = (uint32_t)__shfl((int)mx, 8);
+                if (lane == 0) {
+                    atomicAdd(&a.stamps[0], 1ull); atomicAdd(&a.stamps[1], (unsigned long long)(now - st_0));
+                    atomicAdd(&a.stamps[2], (unsigned long long)mm); atomicAdd(&a.stamps[3], (unsigned long long)ms); atomicAdd(&a.stamps[4], ms > mm ? 1ull : 0ull);
+                }
+                st_0 = now;
             }
-        }
-        if (st_on && lane == 0) {
-            atomicAdd(&a.stamps[4], st_w); atomicAdd(&a.stamps[5], st_b); atomicAdd(&a.stamps[6], st_n); atomicAdd(&a.stamps[7], st_m);
-            atomicAdd(&a.stamps[8], st_mm); atomicAdd(&a.stamps[9], st_ms); atomicAdd(&a.stamps[10], st_sl); atomicAdd(&a.stamps[11], st_step);
         }
     } else {
         // ---------------- scatter waves: queries 4 sw .. 4 sw + 3 of the block, lane j = rare term j ----------------
@@ -781,7 +834,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         // entry 0): the number of vector-memory instructions per stage is a constant, so the compiler can wait for an item's loads with
         // a counted vmcnt that leaves everything issued after them in flight.
         const int sw = wave - 8;
-        unsigned short* const mark = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(bl + KS * 64) + sw * SC_WAVE_LDS);
+        unsigned short* const mark = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(bl) + SC_BREGION + sw * SC_WAVE_LDS);
         int32_t term[4];
         uint32_t cur[4];            // running start (index into P) of every rare term's next run, at the tile being staged
 #pragma unroll
@@ -926,19 +979,14 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         };
         stage_all(tile0);
         advance_queue(tile0);
-        const bool st_on = SC_STAMPS && a.stamps != nullptr && (blockIdx.x & 63) == 0 && wave == 8;
-        unsigned long long st_c = 0, st_s = 0, st_b = 0, st_n = 0, st_t = st_on ? __builtin_readcyclecounter() : 0;
         for (int tile = tile0; tile < tile1; ++tile) {
             consume_all(slots + (tile & 1) * SC_SLOT_WORDS);     // the loads were issued a step ago
-            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_c += now - st_t; st_t = now; }
+            SC_STAMP(1);                                         // end of the adds
             stage_all(tile + 1);
             advance_queue(tile + 1);
-            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_s += now - st_t; st_t = now; }
-            if (st_wg && lane == 0) t_end[wave] = __builtin_readcyclecounter();
+            SC_STAMP(0);
             __syncthreads();                                     // step tile + 1
-            if (st_on) { const unsigned long long now = __builtin_readcyclecounter(); st_b += now - st_t; st_t = now; ++st_n; }
         }
-        if (st_on && lane == 0) { atomicAdd(&a.stamps[0], st_c); atomicAdd(&a.stamps[1], st_s); atomicAdd(&a.stamps[2], st_b); atomicAdd(&a.stamps[3], st_n); }
         __syncthreads();                                         // the matrix waves' last step
     }
 }
@@ -967,14 +1015,7 @@ __global__ void cert_select_kernel(CertSelectArgs a) {
     const int cnt = a.ap_counts[q];
     const float* sc = a.ap_scores + q * a.k_eff;
     if (good && cnt >= a.k) {
-        // relative error of the MFMA part: two fp16 roundings (2^-11 each, and their product), fp32 accumulation over T terms, the
-        // scaling multiply; gamma: the reference's fp32 chain against real arithmetic
-        const double dd = 2.0 * 4.8828125e-4 + 2.4e-7 + (double)a.T * 2.4e-7 + 1.0e-5;
-        const double gamma = ((double)a.n_qt[q] + 2.0) * 6.0e-8 * 1.01;
-        const double Kk = (double)sc[a.k - 1];
-        const double lb = (Kk - 1.2 - 1.01 * (double)a.n_rare[q]) / (1.0 + dd);           // lower bound of the k-th true_fix
-        // a doc's true_fix is at most (key + 1.2) / (1 - dd) + 2.03 per rare term that stage 1 left out
-        const double cutd = floor((lb * (1.0 - gamma) / (1.0 + gamma) - 2.03 * (double)a.n_drop[q]) * (1.0 - dd) - 1.2) - 1.0;
+        const double cutd = cert_cut_from_kth((double)sc[a.k - 1], a.T, a.n_rare[q], a.n_qt[q], a.n_drop[q]);
         if (cutd >= 1.0) {
             const float cutf = (float)cutd;
             // the list is complete down to its last key: certified if it is not truncated, or if the truncation lies below the cut
@@ -1091,7 +1132,8 @@ static int cert_realloc(T*& p, size_t n) {
 template <int KS>
 static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
     static DeviceOnce lds_set;
-    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + 1024 * KS + 8 * SC_WAVE_LDS + (a.stamps ? 128 : 0));
+    static_assert(1024 * KS <= SC_BREGION, "B fragments");
+    const int lds = (int)(sizeof(uint32_t) * 2 * SC_SLOT_WORDS + SC_BREGION + SC_TAIL_LDS + (a.stamps ? 256 : 0));
     if (bool* slot = lds_set.pending()) {
         SR_CHECK_HIP(hipFuncSetAttribute((const void*)cert_score_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         *slot = true;
@@ -1117,6 +1159,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         SR_TRY(cert_realloc(c->n_rare, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->n_qt, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->n_drop, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->tau2, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->elig, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->overflow, (size_t)nq_pad));
         SR_TRY(cert_realloc(c->m_count, (size_t)nq_pad));
@@ -1154,17 +1197,26 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     a.P = c->P; a.S = c->S; a.s_stride = c->n_tiles + 1; a.E = c->E; a.e_stride = c->e_stride;
     a.bfrag = reinterpret_cast<const f16x8*>(c->bfrag);
     a.rare_term = c->rare_term; a.rare_w = c->rare_w; a.cq = c->cq; a.tau = c->ws.tau; a.nq = nq;
+    a.tau2 = c->tau2; a.n_rare = c->n_rare; a.n_qt = c->n_qt; a.n_drop = c->n_drop; a.T = c->T;
+    SR_CHECK_HIP(hipMemsetAsync(c->tau2, 0, sizeof(float) * (size_t)nq_pad, s));
     a.cand_keys = c->ws.cand_keys; a.cand_count = c->ws.cand_count; a.cand_cap = c->ws.cand_cap; a.overflow = c->overflow;
     a.n_qblocks = n_qblocks;
     a.dump = c->want_dump ? c->dump : nullptr;
     if (SC_STAMPS && sr_dev_getenv("SR_CERT_STAMPS") && !c->d_stamps) {
-        SR_CHECK_HIP(hipMalloc((void**)&c->d_stamps, 16 * 8));
-        SR_CHECK_HIP(hipMemsetAsync(c->d_stamps, 0, 16 * 8, s));
+        SR_CHECK_HIP(hipMalloc((void**)&c->d_stamps, 80 * 8));
+        SR_CHECK_HIP(hipMemsetAsync(c->d_stamps, 0, 80 * 8, s));
     }
     a.stamps = c->d_stamps;
+    a.stamps_from = 0;
+    if (SC_STAMPS) { if (const char* e = sr_dev_getenv("SR_CERT_STAMPS")) a.stamps_from = atoi(e); }
     a.dump_stride = dump_stride;
-    int64_t step = 1;
-    int64_t tpw_max = 16;                  // tiles a workgroup walks: amortises its prologue; the chunk's operand (256 KB per tile at T = 128) should stay in its XCD's L2
+    int64_t step = k_eff / SC_DT + 1;      // the first launch covers just over k + band docs (no threshold exists before that many keys are held), then doubling
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_STEP0")) step = std::max(1, atoi(e));
+    bool band_filter = true;               // dev switch SR_SPARSE_CERT_BAND=0: filter with the (k + band)-th best key only
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_BAND")) band_filter = atoi(e) != 0;
+    int sel_over = 2 * k_eff;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_SELOVER")) sel_over = (int)(atof(e) * k_eff);
+    int64_t tpw_max = 32;                  // tiles a workgroup walks: amortises its prologue; the chunk's operand (256 KB per tile at T = 128) should stay in its XCD's L2
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_TPW")) tpw_max = std::max(1, atoi(e));
     for (int64_t t0 = 0; t0 < c->n_tiles;) {
         int64_t nt = step < 512 ? step : 512;
@@ -1190,7 +1242,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         }
         idx->prof.end(s, 0, 0);
         SR_TRY(rc);
-        SR_TRY(topk_compact(c->ws, nq_pad, k_eff, s));
+        SR_TRY(topk_compact2(c->ws, nq_pad, k_eff, band_filter ? k : 0, c->tau2, sel_over, s));
         t0 += nt;
         step *= 2;
     }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __r
 #define TOPK_SEL_R 28        // keys per thread the select keeps in registers (unions of up to 7168 keys; 120 VGPRs = 4 workgroups per CU)
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
-                                                           int* __restrict__ cand_count, int k, int64_t cand_cap) {
+                                                           int* __restrict__ cand_count, int k, int64_t cand_cap,
+                                                           int k2, float* __restrict__ tau2, int select_over) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int* hist = reinterpret_cast<int*>(smem_raw);          // [256]
     int* scan = hist + 256;                                 // [256]
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
 
     // append only: below k keys there is nothing to cut; with k or more already held tau is finite and every candidate
     // beats it, so the set stays a superset of the top-k until its 2k slots overflow
-    if (n <= k || (nr >= k && n <= cap)) {
+    if (n <= k || (nr >= k && n <= select_over)) {      // select_over = 2 k unless the caller wants fresher thresholds (topk_compact2)
         for (int i = tid; i < nc; i += 256) run[nr + i] = cand[i];
         if (n == k) {
             // tau = smallest kept score
@@ -201,8 +202,42 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict_
         // no barrier here: the next pass rewrites hist after these reads of it (two barriers back), scan[] two barriers and
         // ctrl[] three barriers further on
     }
-#undef TOPK_HIST_ADD
     const uint64_t T = prefix;  // the k-th largest key (keys are unique)
+    // Optional second rank k2 < k (sparse_cert.hip: the k2-th best SCORE so far gives a tighter, still valid, filter threshold than the k-th
+    // best key): four more passes over the score half of the keys, from the registers only (a larger union leaves tau2 as it was - a lower
+    // bound of the k2-th best score stays one).
+    if (k2 > 0 && in_regs) {
+        uint64_t prefix2 = 0;
+        int remaining2 = k2;
+        for (int pass = 7; pass >= 4; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TOPK_SEL_R; ++j)
+                if (tid + 256 * j < n && (pass == 7 || (kreg[j] >> (shift + 8)) == prefix2)) TOPK_HIST_ADD(kreg[j]);
+            __syncthreads();
+            const int c = hist[tid];
+            int s2 = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(s2, off);
+                if ((tid & 63) + off < 64) s2 += o;
+            }
+            if ((tid & 63) == 0) scan[tid >> 6] = s2;
+            __syncthreads();
+            for (int w = (tid >> 6) + 1; w < 4; ++w) s2 += scan[w];
+            const int above = s2 - c;
+            if (s2 >= remaining2 && above < remaining2) {
+                ctrl[0] = tid;
+                ctrl[1] = remaining2 - above;
+            }
+            __syncthreads();
+            prefix2 = (prefix2 << 8) | (uint64_t)ctrl[0];
+            remaining2 = ctrl[1];
+        }
+        if (tid == 0) tau2[q] = sr_key_score(prefix2 << 32);
+    }
+#undef TOPK_HIST_ADD
 
     if (tid == 0) {
         ctrl[2] = 0;
@@ -418,7 +453,10 @@ int topk_reset(TopkWS& ws, int64_t nq, hipStream_t s) {
 
 // NOTE: kernels index run_keys with stride 2 * k (k = the logical k of this search, at most the allocated ws.k) and
 // cand_keys with stride ws.cand_cap.
-int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
+int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) { return topk_compact2(ws, nq, k, 0, nullptr, 2 * k, s); }
+
+int topk_compact2(TopkWS& ws, int64_t nq, int k, int k2, float* d_tau2, int select_over, hipStream_t s) {
+    select_over = select_over < k ? k : (select_over > 2 * k ? 2 * k : select_over);
     if (nq == 0) return SR_OK;
     const size_t lds = sizeof(int) * (256 + 256 + 8) + sizeof(uint32_t) * 2 * (size_t)k;
     if (ws.seg_n > 0) {
@@ -427,7 +465,7 @@ int topk_compact(TopkWS& ws, int64_t nq, int k, hipStream_t s) {
         SR_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
-                       ws.cand_keys, ws.cand_count, k, ws.cand_cap);
+                       ws.cand_keys, ws.cand_count, k, ws.cand_cap, k2, d_tau2, select_over);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }

@@ -16,7 +16,7 @@ else
   cd "$ROOT"
   for d in $2; do
     echo "== SC_DIAG=$d"
-    SR_CERT_STAMPS=1 SR_HIP_LIB="$ROOT/build_var/libsr_cert_$d.so" python tools/quick_sparse_cert.py --exact 0 --check 0 --steps 2 2>&1 | grep -v amdgpu.ids | python -c "
+    SR_CERT_STAMPS=${STAMPS_FROM:-1} SR_HIP_LIB="$ROOT/build_var/libsr_cert_$d.so" python tools/quick_sparse_cert.py --exact 0 --check 0 --steps 2 2>&1 | grep -v amdgpu.ids | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'): print(json.loads(l)['certified'])
