@@ -177,8 +177,9 @@ int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, in
 int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8);
 /* Test hook for the error bound: enable = 1 / 0 switches the recording of the stage-1 keys of every (query, doc) pair on /
  * off; enable = 2 copies the last search's keys to h_keys uint16 [nq_pad][n_tiles * 1024] (nq_pad = nq rounded up to 32)
- * and the per-query constants to h_consts fp32 [nq_pad][5] = {c_q (0: query outside the fast path), s_q, rare terms in
- * stage 1, query terms, rare terms left out of stage 1 (weight below fp16's normal range)}; *vscale, *T = the index-side
+ * and the per-query constants to h_consts fp32 [nq_pad][6] = {c_q (0: query outside the fast path), s_q, rare terms in
+ * stage 1, query terms, rare terms left out of stage 1 (weight below fp16's normal range), the k-th best key the scan's
+ * last top-k select saw (0: none ran) - the cut below it is the scan's filter threshold}; *vscale, *T = the index-side
  * constants.  With true_fix = 65535 * s_q * (real-arithmetic score) every key obeys
  * true_fix (1 - dd) - 1.2 - 2.03 * left out <= key <= true_fix (1 + dd) + 1.2 + 1.01 * rare terms.                          */
 int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_keys, int64_t keys_capacity,

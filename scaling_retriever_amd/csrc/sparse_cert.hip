@@ -1313,12 +1313,15 @@ extern "C" int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint
     SR_CHECK_HIP(hipMemcpy(nr.data(), c->n_rare, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     SR_CHECK_HIP(hipMemcpy(nt.data(), c->n_qt, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     SR_CHECK_HIP(hipMemcpy(nd.data(), c->n_drop, sizeof(int32_t) * (size_t)nq_pad, hipMemcpyDeviceToHost));
+    std::vector<float> t2((size_t)nq_pad);
+    SR_CHECK_HIP(hipMemcpy(t2.data(), c->tau2, sizeof(float) * (size_t)nq_pad, hipMemcpyDeviceToHost));
     for (int64_t q = 0; q < nq_pad; ++q) {
-        h_consts[5 * q] = cqv[(size_t)q];
-        h_consts[5 * q + 1] = sqv[(size_t)q];
-        h_consts[5 * q + 2] = (float)nr[(size_t)q];
-        h_consts[5 * q + 3] = (float)nt[(size_t)q];
-        h_consts[5 * q + 4] = (float)nd[(size_t)q];
+        h_consts[6 * q] = cqv[(size_t)q];
+        h_consts[6 * q + 1] = sqv[(size_t)q];
+        h_consts[6 * q + 2] = (float)nr[(size_t)q];
+        h_consts[6 * q + 3] = (float)nt[(size_t)q];
+        h_consts[6 * q + 4] = (float)nd[(size_t)q];
+        h_consts[6 * q + 5] = t2[(size_t)q];
     }
     if (vscale) *vscale = c->vscale;
     if (T) *T = c->T;

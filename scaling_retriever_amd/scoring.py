@@ -281,12 +281,12 @@ class SparseIndexHIP:
                        "sr_sparse_index_cert_debug")
 
     def cert_recorded_keys(self, nq):
-        """(keys uint16 [nq_pad, n_tiles * 1024], consts fp32 [nq_pad, 5] = (c_q, s_q, rare terms, query terms, rare terms left out), vscale, T) of the
-        last search (after cert_record_keys(True))."""
+        """(keys uint16 [nq_pad, n_tiles * 1024], consts fp32 [nq_pad, 6] = (c_q, s_q, rare terms, query terms, rare terms left out, the k-th best
+        key the last top-k select of the scan saw: 0 if none ran), vscale, T) of the last search (after cert_record_keys(True))."""
         nq_pad = (nq + 31) // 32 * 32
         stride = self.cert_stats()["doc_tiles"] * 1024
         keys = np.empty((nq_pad, stride), dtype=np.uint16)
-        consts = np.empty((nq_pad, 5), dtype=np.float32)
+        consts = np.empty((nq_pad, 6), dtype=np.float32)
         vs, T = ctypes.c_float(0), ctypes.c_int32(0)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sr_sparse_index_cert_debug(self._h, 2, keys.ctypes.data_as(ctypes.c_void_p), keys.size,

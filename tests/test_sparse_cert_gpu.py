@@ -91,7 +91,7 @@ def test_stage1_keys_obey_the_bound_for_every_query_doc_pair(forced):
     dd = 2.0 * 2.0 ** -11 + 2.4e-7 + T * 2.4e-7 + 1.0e-5
     checked = 0
     for q in range(nq):
-        cq, sq, n_rare, n_qt, n_drop = consts[q]
+        cq, sq, n_rare, n_qt, n_drop = consts[q, :5]
         if cq == 0:
             continue
         tf = 65535.0 * float(sq) * true[q]
@@ -291,3 +291,32 @@ def test_tiny_rare_weights_are_left_out_of_stage_one_and_still_exact(forced):
     idx.cert_record_keys(False)
     assert (consts[:32, 4] > 0).sum() >= 16          # most queries had a term left out ...
     assert idx.cert_stats()["redone_exact"] <= 2      # ... and were certified all the same
+
+
+@pytest.mark.parametrize("sel_over", ["2.0", "1.0"])
+def test_band_filter_threshold_is_valid_and_changes_no_row(forced, monkeypatch, sel_over):
+    """While the scan runs, docs are filtered by the cut that follows from the k-th best key SO FAR (second rank of the top-k select,
+    topk_compact2): it must never exceed the k-th best key of the whole collection, and rows must equal the oracle's and those of a scan
+    that filters with the (k + band)-th best key only.  sel_over = 1.0: a select (and a fresh threshold) in every launch."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(77)
+    V, N, nq, k = 2500, 230000, 40, 60                     # 225 tiles: launches of 2, 4, ... 128 tiles; k + band = 1 084 keys held
+    indptr, ids, vals = _zipf_index(rng, V, N, 24)
+    qi, qc, qv = _zipf_queries(rng, V, nq, 20)
+    monkeypatch.setenv("SR_DEV_SWITCHES", "1")
+    monkeypatch.setenv("SR_SPARSE_CERT_SELOVER", sel_over)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    idx.cert_record_keys(True)
+    s1, i1, c1 = _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+    keys, consts, _, _ = idx.cert_recorded_keys(nq)
+    idx.cert_record_keys(False)
+    assert idx.cert_stats()["redone_exact"] == 0
+    seen = 0
+    for q in range(nq):
+        kth_all = np.sort(keys[q, :N])[-k]
+        assert consts[q, 5] <= kth_all, (q, consts[q, 5], kth_all)
+        seen += consts[q, 5] > 0
+    assert seen >= nq // 2                                  # the second rank was found for most queries (a select ran)
+    monkeypatch.setenv("SR_SPARSE_CERT_BAND", "0")
+    s0, i0, c0 = idx.search(qi, qc, qv, k)
+    assert np.array_equal(s0.cpu().numpy(), s1) and np.array_equal(i0.cpu().numpy(), i1) and np.array_equal(c0.cpu().numpy(), c1)
