@@ -506,13 +506,22 @@ def sparse_index_leg(args, device):
     def loader():
         return TokenBudgetCollectionLoader(tokenized=chunks, max_length=192, max_tokens=args.token_budget // 2, max_seqs=512,
                                            window=32768, pad_token_id=V - 1, padding_side="left")
-    first = next(iter(loader()))
+    # The constant that leaves 128 entries per passage on average.  The loader's batches hold passages of similar length, and a rep's
+    # scale grows with the number of tokens under its max: one batch calibrates its own length only (first batch: L0_d 316-390 over the
+    # whole run) - so every 16th batch of the first length-bucketing window is encoded and the constant bisected over all of them.
+    import itertools
+    sample = []
     with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
-        reps = model.encode(input_ids=first["input_ids"].to(device), attention_mask=first["attention_mask"].to(device))
-    # the constant that leaves 128 entries per passage ON AVERAGE over the first batch (rows differ in scale: a per-row 128-th largest
-    # value, averaged, left 390)
-    shift = float(torch.topk(reps.flatten(), 128 * reps.shape[0]).values[-1].item())
-    del reps
+        for b in itertools.islice(loader(), 0, 160, 16):
+            sample.append(model.encode(input_ids=b["input_ids"].to(device), attention_mask=b["attention_mask"].to(device)).float())
+    rows_s = sum(int(r.shape[0]) for r in sample)
+    lo, hi = 0.0, max(float(r.max().item()) for r in sample)
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        cnt = sum(int((r > mid).sum().item()) for r in sample)
+        lo, hi = (mid, hi) if cnt > 128 * rows_s else (lo, mid)
+    shift = hi
+    del sample
     stub = _ThresholdedSparseDocs(model, shift)
     with contextlib.redirect_stdout(sys.stderr):
         SparseIndexer(stub, None, device, compute_stats=True, dim_voc=V).index(
@@ -695,6 +704,7 @@ def drop_in_dense_leg(args, cfg, model, index, device, n_local):
                                   "id_mapping_alone_ms = the 7 M references by themselves (the numpy take + tolist per row it replaces beside it)"},
            "get_top_docs": {"ms": round(t_top * 1e3, 1), "queries_per_s": round(nq / t_top, 1)},
            "retrieval_task_with_run_json": {"ms": round(t_run * 1e3, 1), "queries_per_s": round(nq / t_run, 1), "run_json_bytes": int(nbytes),
+                                            "timeline_of_the_last_call": retriever.last_run_timeline,
                                             "note": "generate_query_vecs + search + sr_write_run_json (the bytes json.dump of the reference's nested "
                                                     "dict gives, tests/test_run_file.py): what eval_dense.py --task_name retrieval does after the index is resident"}}
     assert same_bits, "coalesced query encode differs from the per-batch calls"
@@ -1060,7 +1070,7 @@ def main():
     # run inside this process), used only when measured on the same problem shape; the file names the commit it was taken at
     split_traffic, split_traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
             pmc2 = json.load(f)
         shape2 = pmc2["dense_split_launch"]
         import hashlib
@@ -1069,7 +1079,7 @@ def main():
         if (same_kernel and shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
                 and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
             split_traffic = [v for kname, v in pmc2["kernels"].items() if kname.startswith("dense_split_kernel") and "<false>" not in kname][0]["traffic_bytes"]
-            split_traffic_src = "profiles/r04_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
+            split_traffic_src = "profiles/r05_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
     except Exception:
         split_traffic = None
     if filtered:

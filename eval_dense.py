@@ -151,6 +151,7 @@ class DenseRetriever:
 class LocalFaissDenseRetriever(DenseRetriever):
     """eval_dense.py:108-135 with the flat index resident in HBM (DenseFlatIndexer over the HIP scorer)."""
 
+    last_run_timeline = None  # write_run: wall-clock stages of the last call (bench.py reports them)
     RUN_PIECES = 3            # write_run: pieces of the query set (search of piece c + 1 beside the writing of piece c)
 
     def __init__(self, model, device, index):
@@ -173,9 +174,12 @@ class LocalFaissDenseRetriever(DenseRetriever):
     def write_run(self, dataloader, top_docs, path):
         """get_top_docs + the run.json loop of eval_dense.py:225-241 in one go, without materialising a Python object per hit:
         encode, search, and sr_write_run_json over the result arrays.  Returns (number of queries, file size)."""
+        import time
         from scaling_retriever_amd.utils.run_file import id_table, write_run_json
+        t_start = time.perf_counter()
         query_reps, qids = generate_query_vecs(self.model, dataloader, self.device)
         nq = len(qids)
+        tl = self.last_run_timeline = {"generate_query_vecs_returned_ms": round((time.perf_counter() - t_start) * 1e3, 1), "pieces": []}
         table = self.index.run_table()
         n_pieces = self.RUN_PIECES if nq >= 1024 and table.distinct and id_table(qids).distinct else 1
         if n_pieces == 1:
@@ -185,8 +189,10 @@ class LocalFaissDenseRetriever(DenseRetriever):
         # and writes piece c - the exact results do not depend on how the queries are batched (pieces stay above 64 queries)
         import torch
         from concurrent.futures import ThreadPoolExecutor
-        per = (nq + n_pieces - 1) // n_pieces
-        bounds = [(c0, min(nq, c0 + per)) for c0 in range(0, nq, per)]
+        # pieces of whole 256-query tiles (the scorer pads a query set to tiles: 3 x 2 327 queries are 30 of them, 6 980 are 28)
+        tiles = (nq + 255) // 256
+        cuts = [min(nq, 256 * ((tiles * c + n_pieces - 1) // n_pieces)) for c in range(n_pieces + 1)]
+        bounds = [(cuts[c], cuts[c + 1]) for c in range(n_pieces) if cuts[c + 1] > cuts[c]]
         dev = self.index.index.device
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
@@ -199,10 +205,14 @@ class LocalFaissDenseRetriever(DenseRetriever):
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(gpu, 0)
             for c, (b0, b1) in enumerate(bounds):
+                t0 = time.perf_counter()
                 scores, positions = fut.result()
+                t1 = time.perf_counter()
                 if c + 1 < len(bounds):
                     fut = pool.submit(gpu, c + 1)
                 size = write_run_json(path, qids[b0:b1], scores, positions, table, part=1 if c == 0 else (3 if c + 1 == len(bounds) else 2))
+                tl["pieces"].append({"queries": b1 - b0, "waited_for_the_search_ms": round((t1 - t0) * 1e3, 1),
+                                     "formatted_and_written_ms": round((time.perf_counter() - t1) * 1e3, 1)})
         return nq, size
 
 

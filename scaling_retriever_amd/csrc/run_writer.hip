@@ -20,6 +20,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -189,7 +190,12 @@ static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const fl
         total = (int64_t)end;
         any_entry = end > 1;
     }
+    const bool timing = getenv("SR_RUN_WRITER_TIMING") != nullptr;      // per-phase wall times on stderr
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_fmt = 0, t_copy = 0, t_alloc = 0;
+    const double t_begin = now_ms();
     for (int64_t q0 = 0; q0 < nq && ok; q0 += slab * nt) {
+        const double t_r0 = now_ms();
         auto work = [&](int t) {
             const int64_t a = q0 + (int64_t)t * slab, b = a + slab < nq ? a + slab : nq;
             std::string& s = bufs[(size_t)t];
@@ -243,6 +249,8 @@ static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const fl
             work(0);
             for (auto& x : th) x.join();
         }
+        const double t_r1 = now_ms();
+        t_fmt += t_r1 - t_r0;
         for (int t = 0; t < nt; ++t) {
             const std::string& s = bufs[(size_t)t];
             skip[(size_t)t] = (!s.empty() && !any_entry) ? 2 : 0;          // the file's first entry has no separator in front
@@ -255,7 +263,10 @@ static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const fl
         // (posix_fallocate: a full disk is an error code here, not a SIGBUS in a thread); any failure falls back to pwrite.
         const int64_t round_begin = off[0], round_bytes = total - off[0];
         bool mapped = false;
-        if (round_bytes >= (8 << 20) && nt > 1 && posix_fallocate(fd, 0, (off_t)total) == 0) {
+        const bool reserved = round_bytes >= (8 << 20) && nt > 1 && posix_fallocate(fd, 0, (off_t)total) == 0;
+        const double t_r2 = now_ms();
+        t_alloc += t_r2 - t_r1;
+        if (reserved) {
             const int64_t page = (int64_t)sysconf(_SC_PAGESIZE);
             const int64_t map_begin = round_begin / page * page;
             void* m = mmap(nullptr, (size_t)(total - map_begin), PROT_WRITE, MAP_SHARED, fd, (off_t)map_begin);
@@ -282,7 +293,11 @@ static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const fl
             for (auto& x : th) x.join();
         }
         for (int t = 0; t < nt; ++t) ok = ok && !io_bad[(size_t)t];
+        t_copy += now_ms() - t_r2;
     }
+    if (timing)
+        fprintf(stderr, "[run writer] %lld queries, %d threads, slabs of %lld: format %.1f ms, reserve %.1f ms, copy into the file %.1f ms, total %.1f ms\n",
+                (long long)nq, nt, (long long)slab, t_fmt, t_alloc, t_copy, now_ms() - t_begin);
     if (closes) {
         ok = ok && pwrite(fd, "}", 1, (off_t)total) == 1;
         total += 1;

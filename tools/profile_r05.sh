@@ -8,8 +8,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05_prof
 rm -rf $O; mkdir -p $O
 cd $R
-# 1. the bench line itself (what the driver runs)
-python3 bench.py > $O/bench_line.json 2> $O/bench.log || echo "bench failed"
 cd /tmp && export TMPDIR=/tmp
 T="timeout -s KILL 600"
 # 2. kernel statistics of the headline step + the sparse leg
@@ -42,7 +40,11 @@ python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /de
 python3 tools/pmc_traffic.py $O/pmc_sp_fetch $O/pmc_sp_write $O/pmc_sparse_traffic.json > /dev/null 2>> $O/pmc_traffic.err
 python3 tools/pmc_counters.py $O/pmc_mfma --out $O/pmc_mfma.json --match dense_split > /dev/null 2>> $O/pmc_traffic.err
 python3 tools/pmc_counters.py $O/pmc_sp? --out $O/pmc_sparse.json --match cert_score_kernel > /dev/null 2>> $O/pmc_traffic.err
-# 6. the GPU suite on the same box
+# 6. the bench line itself (what the driver runs), AFTER the counter passes: its sparse leg reads profiles/r05_pmc_sparse_traffic.json, which
+#    the collector ties to the sha256 of the kernel source that was profiled above
+python3 tools/profile_r05_collect.py > $O/collect_on_box.log 2>&1
+python3 bench.py > $O/bench_line.json 2> $O/bench.log || echo "bench failed"
+# 7. the GPU suite on the same box
 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_suite.txt
 # keep the summaries, drop the bulky per-dispatch traces
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete

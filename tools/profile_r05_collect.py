@@ -34,6 +34,22 @@ for src, dst in (("bench_stats", "r05_bench_kernel_stats.csv"), ("sparse_stats",
 for src, dst in (("pmc_traffic.json", "r05_pmc_traffic.json"), ("pmc_mfma.json", "r05_pmc_mfma.json"), ("pmc_sparse.json", "r05_pmc_sparse.json"),
                  ("gpu_suite.txt", "r05_gpu_suite.txt")):
     copy(src, dst)
+# dense traffic: what bench.py needs beside the per-kernel figures to know that the file matches the kernel and the shape it runs
+try:
+    pj = os.path.join(P, "r05_pmc_traffic.json")
+    d = json.load(open(pj))
+    srcf = "scaling_retriever_amd/csrc/dense_split.hip"
+    d["note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the reduced bench command of tools/profile_r05.sh, "
+                 "folded by tools/pmc_traffic.py; KB per dispatch averaged over the kernel's dispatches. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                 "(MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read and counts Infinity-Cache hits).")
+    d["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=R, capture_output=True, text=True).stdout.strip() or "(snapshot without .git)"
+    d["dense_split_launch"] = {"n_docs": 8841823, "nq": 6980, "dim": 2048, "launches_per_search": 272, "algorithmic_bytes": 161997585,
+                               "algorithmic_note": "one fp16 plane of the launch's docs + their (x, y) + one fp16 plane of the queries, each once"}
+    d["kernel_source"] = {"file": srcf, "sha256": hashlib.sha256(open(os.path.join(R, srcf), "rb").read()).hexdigest()}
+    json.dump(d, open(pj, "w"), indent=1)
+    print("annotated r05_pmc_traffic.json")
+except Exception as e:
+    print("dense traffic:", e, file=sys.stderr)
 # sparse traffic: per pass of 6 980 queries, tied to the kernel source
 try:
     t = json.load(open(os.path.join(O, "pmc_sparse_traffic.json")))["kernels"]
