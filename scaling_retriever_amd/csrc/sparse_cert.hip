@@ -50,6 +50,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 struct SparseCert {
@@ -700,6 +701,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         const int qn = lane & 31, h = lane >> 5;
         const int64_t q = (int64_t)qb * SC_QB + qn;
         const float cq = a.cq[q];
+        const f32x2 cq2 = {cq, cq};
         float tq = q < a.nq ? a.tau[q] : INFINITY;
         if (q < a.nq && a.tau2[q] > 0.f) {
             const double cb = cert_cut_from_kth((double)a.tau2[q], a.T, a.n_rare[q], a.n_qt[q], a.n_drop[q]);
@@ -767,8 +769,9 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 uint32_t any = 0;
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
-                    const u16x2 k0 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G] * cq, acc[4 * G + 1] * cq) + __builtin_bit_cast(u16x2, sv[G].x);
-                    const u16x2 k1 = __builtin_amdgcn_cvt_pknorm_u16(acc[4 * G + 2] * cq, acc[4 * G + 3] * cq) + __builtin_bit_cast(u16x2, sv[G].y);
+                    const f32x2 a0 = f32x2{acc[4 * G], acc[4 * G + 1]} * cq2, a1 = f32x2{acc[4 * G + 2], acc[4 * G + 3]} * cq2;   // v_pk_mul_f32
+                    const u16x2 k0 = __builtin_amdgcn_cvt_pknorm_u16(a0[0], a0[1]) + __builtin_bit_cast(u16x2, sv[G].x);
+                    const u16x2 k1 = __builtin_amdgcn_cvt_pknorm_u16(a1[0], a1[1]) + __builtin_bit_cast(u16x2, sv[G].y);
                     key[2 * G] = __builtin_bit_cast(uint32_t, k0);
                     key[2 * G + 1] = __builtin_bit_cast(uint32_t, k1);
                     any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(k0, __builtin_bit_cast(u16x2, cutm1x2)));
@@ -929,11 +932,18 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
             tail2 = 0u;
 #pragma unroll
             for (int it = 0; it < SC_ITERS / 4; ++it) rid8[it] = 0u;
+            // running maximum over the 512 positions: eight INDEPENDENT in-wave scans (the compiler interleaves their DPP steps), the carry
+            // from one 64-lane step into the next applied afterwards (max-scan(max(x, c)) = max(max-scan(x), c) for a wave-uniform c)
+            int sm[SC_ITERS];
 #pragma unroll
             for (int it = 0; it < SC_ITERS; ++it) {
                 tail2 |= (uint32_t)(rid[it] >> 9) << (2 * it);
-                const int v = sc_scan_max(max(rid[it] & 0x1ff, carry));
-                carry = __builtin_amdgcn_readlane(v, 63);
+                sm[it] = sc_scan_max(rid[it] & 0x1ff);
+            }
+#pragma unroll
+            for (int it = 0; it < SC_ITERS; ++it) {
+                const int v = max(sm[it], carry);
+                carry = max(carry, __builtin_amdgcn_readlane(sm[it], 63));
                 rid[it] = (v - 1) & 255;
                 rid8[it / 4] |= (uint32_t)rid[it] << (8 * (it % 4));
             }
