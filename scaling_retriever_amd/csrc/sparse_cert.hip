@@ -1226,6 +1226,10 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_BAND")) band_filter = atoi(e) != 0;
     int sel_over = 2 * k_eff;
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_SELOVER")) sel_over = (int)(atof(e) * k_eff);
+    // while the launches still double, every compaction selects: a launch then appends k + band candidates per query whatever its size, and a
+    // threshold one launch old lets twice as many through (-0.9 ms per pass at the MSMARCO shape; dev switch SR_SPARSE_CERT_SELEARLY=0)
+    bool sel_early = true;
+    if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_SELEARLY")) sel_early = atoi(e) != 0;
     int64_t tpw_max = 32;                  // tiles a workgroup walks: amortises its prologue; the chunk's operand (256 KB per tile at T = 128) should stay in its XCD's L2
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_TPW")) tpw_max = std::max(1, atoi(e));
     for (int64_t t0 = 0; t0 < c->n_tiles;) {
@@ -1252,7 +1256,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         }
         idx->prof.end(s, 0, 0);
         SR_TRY(rc);
-        SR_TRY(topk_compact2(c->ws, nq_pad, k_eff, band_filter ? k : 0, c->tau2, sel_over, s));
+        SR_TRY(topk_compact2(c->ws, nq_pad, k_eff, band_filter ? k : 0, c->tau2, (sel_early && nt < 512) ? k_eff : sel_over, s));
         t0 += nt;
         step *= 2;
     }
