@@ -152,7 +152,8 @@ class LocalFaissDenseRetriever(DenseRetriever):
     """eval_dense.py:108-135 with the flat index resident in HBM (DenseFlatIndexer over the HIP scorer)."""
 
     last_run_timeline = None  # write_run: wall-clock stages of the last call (bench.py reports them)
-    RUN_PIECES = 3            # write_run: pieces of the query set (search of piece c + 1 beside the writing of piece c)
+    RUN_PIECES = 4            # write_run: pieces of the query set (search of piece c + 1 beside the writing of piece c)
+    RUN_PIECE_SHARES = (9, 8, 7, 4)
 
     def __init__(self, model, device, index):
         super().__init__(model, device)
@@ -189,10 +190,17 @@ class LocalFaissDenseRetriever(DenseRetriever):
         # and writes piece c - the exact results do not depend on how the queries are batched (pieces stay above 64 queries)
         import torch
         from concurrent.futures import ThreadPoolExecutor
-        # pieces of whole 256-query tiles (the scorer pads a query set to tiles: 3 x 2 327 queries are 30 of them, 6 980 are 28)
+        # pieces of whole 256-query tiles (the scorer pads a query set to tiles: 3 x 2 327 queries are 30 of them, 6 980 are 28), shrinking
+        # towards the end: the writing of piece c hides under the search of piece c + 1 while it is no longer than that search, and only the
+        # last piece's writing (75 MB into the page cache took 38-88 ms for 2 116 queries over runs) stays on the critical path
         tiles = (nq + 255) // 256
-        cuts = [min(nq, 256 * ((tiles * c + n_pieces - 1) // n_pieces)) for c in range(n_pieces + 1)]
-        bounds = [(cuts[c], cuts[c + 1]) for c in range(n_pieces) if cuts[c + 1] > cuts[c]]
+        shares = self.RUN_PIECE_SHARES[:n_pieces]
+        acc, cuts = 0.0, [0]
+        for w in shares[:-1]:
+            acc += w / sum(shares)
+            cuts.append(min(nq, 256 * max(cuts[-1] // 256 + 1, round(tiles * acc))))
+        cuts = [c_ for c_ in cuts if nq - c_ > 64] + [nq]         # no piece of 64 queries or fewer: those take the small-batch kernel (other summation order)
+        bounds = [(cuts[c], cuts[c + 1]) for c in range(len(cuts) - 1) if cuts[c + 1] > cuts[c]]
         dev = self.index.index.device
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))

@@ -173,7 +173,8 @@ int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, in
  * kernels.  Queries it cannot certify (a negative or unordered query, more than 64 rare terms, a band of undecided keys
  * wider than 1024, fewer than k docs with a non-zero key) are re-done by the exact kernels inside the same call.
  * out8: [0] 1 if this index has the scorer, [1] heavy terms on the matrix pipe, [2] searches it ran, [3] queries it was
- * given, [4] queries re-done by the exact kernels, [5] doc tiles of 1024, [6..7] 0.                                        */
+ * given, [4] queries re-done by the exact kernels, [5] doc tiles of 1024, [6] candidates whose exact chain the certified
+ * path ran (rounded up to 16 per query), [7] 0.                                                                            */
 int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8);
 /* Test hook for the error bound: enable = 1 / 0 switches the recording of the stage-1 keys of every (query, doc) pair on /
  * off; enable = 2 copies the last search's keys to h_keys uint16 [nq_pad][n_tiles * 1024] (nq_pad = nq rounded up to 32)

@@ -66,8 +66,7 @@ struct SparseCert {
                                       // posting, 0xffff0000 | length = two or more postings (in P from the running start on)
     int e_stride = 0;                 // n_tiles rounded up to 4, + 4: 16-byte rows, a 16-byte read never leaves its row
     int64_t* fwd_indptr = nullptr;    // doc-major forward index, terms ascending inside a doc
-    int32_t* fwd_term = nullptr;
-    float* fwd_val = nullptr;
+    uint64_t* fwd_tv = nullptr;       // [nnz] term << 32 | value bits: one 16-byte load per lane brings two postings of a row
     // per-call plan (grown on demand)
     int64_t nq_cap = 0;
     _Float16* bfrag = nullptr;        // [nq_pad / 32][KS][64][8]: MFMA B fragments (k = dense slot, col = query)
@@ -84,9 +83,7 @@ struct SparseCert {
     int32_t* m_count = nullptr;       // [nq_pad] candidates to re-score
     int* d_n_uncert = nullptr;
     int64_t ap_cap = 0;               // approximate top lists [nq][k_eff]
-    float* ap_scores = nullptr;
     int64_t* ap_ids = nullptr;
-    int32_t* ap_counts = nullptr;
     TopkWS ws;
     // statistics (sr_sparse_index_cert_stats)
     int64_t n_calls = 0, n_queries = 0, n_uncert = 0, n_rescored = 0;
@@ -184,20 +181,18 @@ __global__ void cert_i32_to_i64_kernel(const int32_t* __restrict__ in, int64_t n
 }
 __global__ __launch_bounds__(256) void cert_fwd_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc_ids,
                                                             const float* __restrict__ vals, const int64_t* __restrict__ fwd_indptr,
-                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ fwd_term,
-                                                            float* __restrict__ fwd_val) {
+                                                            int32_t* __restrict__ cursor, uint64_t* __restrict__ fwd_tv) {
     const int64_t t = blockIdx.y;
     const int64_t b = indptr[t], e = indptr[t + 1];
     for (int64_t p = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (int64_t)gridDim.x * blockDim.x) {
         const int32_t d = doc_ids[p];
         const int64_t pos = fwd_indptr[d] + atomicAdd(&cursor[d], 1);
-        fwd_term[pos] = (int32_t)t;
-        fwd_val[pos] = vals[p];
+        fwd_tv[pos] = ((uint64_t)(uint32_t)t << 32) | (uint64_t)__float_as_uint(vals[p]);
     }
 }
 // one wave per doc: bitonic sort of its (term, value) pairs by term in LDS; flags |= 2 for a doc with more than SC_FWD_MAX postings
-__global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __restrict__ fwd_indptr, int64_t n_docs, int32_t* __restrict__ fwd_term,
-                                                            float* __restrict__ fwd_val, int* __restrict__ flags) {
+__global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __restrict__ fwd_indptr, int64_t n_docs, uint64_t* __restrict__ fwd_tv,
+                                                            int* __restrict__ flags) {
     __shared__ uint64_t keys_all[4][SC_FWD_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t d = (int64_t)blockIdx.x * 4 + wave;
@@ -213,7 +208,7 @@ __global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __res
     int P = 64;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += 64)
-        keys[i] = i < n ? (((uint64_t)(uint32_t)fwd_term[b + i] << 32) | (uint64_t)__float_as_uint(fwd_val[b + i])) : ~0ull;
+        keys[i] = i < n ? fwd_tv[b + i] : ~0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int size = 2; size <= P; size <<= 1)
         for (int j = size >> 1; j > 0; j >>= 1) {
@@ -227,10 +222,7 @@ __global__ __launch_bounds__(256) void cert_fwd_sort_kernel(const int64_t* __res
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-    for (int i = lane; i < n; i += 64) {
-        fwd_term[b + i] = (int32_t)(keys[i] >> 32);
-        fwd_val[b + i] = __uint_as_float((uint32_t)(keys[i] & 0xffffffffu));
-    }
+    for (int i = lane; i < n; i += 64) fwd_tv[b + i] = keys[i];
 }
 
 void sparse_cert_destroy(SparseCert* c) {
@@ -239,7 +231,7 @@ void sparse_cert_destroy(SparseCert* c) {
         unsigned long long h[80] = {0};
         if (hipMemcpy(h, c->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0]) {
             const double n = (double)h[0];
-            fprintf(stderr, "[cert stamps] %llu sampled tile steps of %.0f cycles: last matrix wave at the barrier after %.0f, last scatter wave after %.0f (scatter last in %.0f %% of the steps); first blocks of wave 1 with a candidate: %.0f %%; single candidates per step %.1f, steps over the %d LDS words %.1f %%\n",
+            fprintf(stderr, "[cert stamps] %llu sampled tile steps of %.0f cycles: last matrix wave at the barrier after %.0f, last scatter wave after %.0f (scatter last in %.0f %% of the steps); first blocks of wave 1 with a candidate: %.0f %%\n",
                     h[0], (double)h[1] / n, (double)h[2] / n, (double)h[3] / n, 100.0 * (double)h[4] / n, 100.0 * (double)h[5] / n);
             fprintf(stderr, "[cert stamps]   matrix waves  : barrier arrival");
             for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", (double)h[16 + w] / n);
@@ -257,8 +249,8 @@ void sparse_cert_destroy(SparseCert* c) {
         }
         (void)hipFree(c->d_stamps);
     }
-    void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_term, c->fwd_val, c->bfrag, c->rare_term, c->rare_w,
-                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->tau2, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_scores, c->ap_ids, c->ap_counts, c->dump};
+    void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_tv, c->bfrag, c->rare_term, c->rare_w,
+                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->tau2, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_ids, c->dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws.release();
@@ -337,8 +329,7 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
             hipMalloc((void**)&c->P, sizeof(uint32_t) * ((size_t)nnz + 4)) != hipSuccess || hipMalloc((void**)&c->S, s_words * 4) != hipSuccess ||
             hipMalloc((void**)&c->E, e_words * 4) != hipSuccess ||
             hipMalloc((void**)&c->fwd_indptr, sizeof(int64_t) * (size_t)(N + 1)) != hipSuccess ||
-            hipMalloc((void**)&c->fwd_term, sizeof(int32_t) * (size_t)nnz) != hipSuccess ||
-            hipMalloc((void**)&c->fwd_val, sizeof(float) * (size_t)nnz) != hipSuccess ||
+            hipMalloc((void**)&c->fwd_tv, sizeof(uint64_t) * ((size_t)nnz + 2)) != hipSuccess ||
             hipMalloc((void**)&d_terms, sizeof(int32_t) * h_terms.size()) != hipSuccess ||
             hipMalloc((void**)&d_cnt, sizeof(int32_t) * (size_t)N) != hipSuccess || hipMalloc((void**)&d_cnt64, sizeof(int64_t) * (size_t)N) != hipSuccess) {
             (void)hipGetLastError();
@@ -363,8 +354,8 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         if (sr_device_exclusive_scan_i64(d_cnt64, c->fwd_indptr, N, s) != SR_OK) break;
         if (hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)N, s) != hipSuccess) break;
         hipLaunchKernelGGL(cert_fwd_fill_kernel, dim3(64, (unsigned)V), dim3(256), 0, s, idx->indptr, idx->doc_ids, idx->vals, c->fwd_indptr, d_cnt,
-                           c->fwd_term, c->fwd_val);
-        hipLaunchKernelGGL(cert_fwd_sort_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, s, c->fwd_indptr, N, c->fwd_term, c->fwd_val, d_flags);
+                           c->fwd_tv);
+        hipLaunchKernelGGL(cert_fwd_sort_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, s, c->fwd_indptr, N, c->fwd_tv, d_flags);
         if (hipGetLastError() != hipSuccess) break;
         if (hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
         rc = SR_OK;
@@ -1002,10 +993,15 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- certificate kernel ---
-// One thread per query, over the approximate top list (keys descending): the candidates that need the exact chain, or "uncertified".
+// One workgroup per query over its UNSORTED running set (up to 2 (k + band) keys: the best k + band at the last select and everything
+// appended since): the k-th best key by two 256-bin histogram passes over the 16-bit key values, the cut that follows from it, and the
+// docs whose key reaches the cut, in any order - the re-score does not care, and sorting 8 192 keys per query for this took 0.8 ms.
+// The set holds every doc whose key lies above max(tau, cut(tau2)): tau = the (k + band)-th best key at the last select (keys under
+// it were cut away then), cut(tau2) <= the final cut (monotone).  So it is complete down to the final cut iff tau < cut.
 struct CertSelectArgs {
-    const float* ap_scores;
-    const int32_t* ap_counts;
+    const uint64_t* run_keys;
+    const int* run_count;
+    const float* tau;
     int64_t nq;
     int k, k_eff, T;
     const uint8_t* elig;
@@ -1013,35 +1009,78 @@ struct CertSelectArgs {
     const int32_t* n_rare;
     const int32_t* n_qt;
     const int32_t* n_drop;
+    int64_t* ap_ids;          // [nq][2 k_eff] candidates' doc indices
     int32_t* m_count;
     uint8_t* uncert;
     int* n_uncert;
 };
-__global__ void cert_select_kernel(CertSelectArgs a) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= a.nq) return;
-    int m = 0;
-    bool good = a.elig[q] && !a.overflow[q];
-    const int cnt = a.ap_counts[q];
-    const float* sc = a.ap_scores + q * a.k_eff;
-    if (good && cnt >= a.k) {
-        const double cutd = cert_cut_from_kth((double)sc[a.k - 1], a.T, a.n_rare[q], a.n_qt[q], a.n_drop[q]);
-        if (cutd >= 1.0) {
-            const float cutf = (float)cutd;
-            // the list is complete down to its last key: certified if it is not truncated, or if the truncation lies below the cut
-            if (cnt < a.k_eff || sc[a.k_eff - 1] < cutf) {
-                int lo = a.k, hi = cnt;                  // first index with key < cut (keys descend)
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sc[mid] >= cutf) lo = mid + 1; else hi = mid;
-                }
-                m = lo;
-            } else good = false;
-        } else good = false;
-    } else good = false;
-    a.m_count[q] = good ? m : 0;
-    a.uncert[q] = good ? 0 : 1;
-    if (!good) atomicAdd(a.n_uncert, 1);
+#define SC_SEL_R 32          // keys per thread: 2 (k + band) <= 2 SR_MAX_TOPK = 8 192
+__global__ __launch_bounds__(256) void cert_select_kernel(CertSelectArgs a) {
+    __shared__ int hist[256];
+    __shared__ int scan[4];
+    __shared__ int ctrl[4];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int cap = 2 * a.k_eff;
+    const int n = a.run_count[q] < cap ? a.run_count[q] : cap;
+    const uint64_t* run = a.run_keys + q * cap;
+    bool good = a.elig[q] && !a.overflow[q] && n >= a.k;       // fewer than k docs with a non-zero key: the exact kernels decide
+    if (!good) {
+        if (tid == 0) { a.m_count[q] = 0; a.uncert[q] = 1; atomicAdd(a.n_uncert, 1); }
+        return;
+    }
+    uint32_t v[SC_SEL_R];                                       // key values, integers in [1, 65 535]
+#pragma unroll
+    for (int j = 0; j < SC_SEL_R; ++j) {
+        const int i = tid + 256 * j;
+        v[j] = i < n ? (uint32_t)sr_key_score(run[i]) : 0u;
+    }
+    // rank `rem` from the top among the values whose high byte is `hi` (pass 1: all values, by high byte)
+    auto select_byte = [&](int pass, uint32_t hi, int rem, int& bin, int& rem_out) {
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SC_SEL_R; ++j)
+            if (tid + 256 * j < n && (pass == 0 || (v[j] >> 8) == hi)) atomicAdd(&hist[pass == 0 ? (v[j] >> 8) : (v[j] & 255u)], 1);
+        __syncthreads();
+        const int c = hist[tid];
+        int sfx = c;                                             // sum over bins >= tid
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(sfx, off);
+            if ((tid & 63) + off < 64) sfx += o;
+        }
+        if ((tid & 63) == 0) scan[tid >> 6] = sfx;
+        __syncthreads();
+        for (int w = (tid >> 6) + 1; w < 4; ++w) sfx += scan[w];
+        const int above = sfx - c;
+        if (sfx >= rem && above < rem) { ctrl[0] = tid; ctrl[1] = rem - above; }
+        __syncthreads();
+        bin = ctrl[0];
+        rem_out = ctrl[1];
+        __syncthreads();
+    };
+    int b_hi, b_lo, rem;
+    select_byte(0, 0u, a.k, b_hi, rem);
+    select_byte(1, (uint32_t)b_hi, rem, b_lo, rem);
+    const double cutd = cert_cut_from_kth((double)(b_hi * 256 + b_lo), a.T, a.n_rare[q], a.n_qt[q], a.n_drop[q]);
+    good = cutd >= 1.0 && a.tau[q] < (float)cutd;
+    if (tid == 0) ctrl[2] = 0;
+    __syncthreads();
+    if (good) {
+        const uint32_t cut = (uint32_t)cutd;
+#pragma unroll
+        for (int j = 0; j < SC_SEL_R; ++j) {
+            const int i = tid + 256 * j;
+            if (i < n && v[j] >= cut) a.ap_ids[q * cap + atomicAdd(&ctrl[2], 1)] = (int64_t)(uint32_t)(~(uint32_t)run[i]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.m_count[q] = good ? ctrl[2] : 0;
+        a.uncert[q] = good ? 0 : 1;
+        if (!good) atomicAdd(a.n_uncert, 1);
+        else atomicAdd(a.n_uncert + 1, (ctrl[2] + 15) >> 4);       // statistics
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- exact re-score ---
@@ -1052,11 +1091,10 @@ struct CertRescoreArgs {
     const int32_t* q_cols;
     const float* q_vals;
     const int64_t* fwd_indptr;
-    const int32_t* fwd_term;
-    const float* fwd_val;
+    const uint64_t* fwd_tv;
     const int64_t* ap_ids;
     const int32_t* m_count;
-    int k_eff;
+    int ap_stride;
     float threshold;
     uint32_t id_base, id_stride;
     uint64_t* cand_keys;
@@ -1065,8 +1103,10 @@ struct CertRescoreArgs {
 };
 __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
 #pragma clang fp contract(off)
-    __shared__ int32_t qc[SC_MAXQT];
-    __shared__ float qv[SC_MAXQT];
+    // the query's terms in an open-addressed table (1 024 slots for at most 256 terms, linear probing): a doc term finds its partner in
+    // ~1.1 LDS reads; a binary search over the sorted terms took 8 dependent ones per doc term and was most of this kernel's time
+    __shared__ int32_t hk[1024];
+    __shared__ float hv[1024];
     __shared__ int n_kept;
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1074,56 +1114,109 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
     if (m == 0) return;                       // cand_count[q] stays 0 (topk_reset)
     const int64_t tb = a.q_indptr[q];
     const int nqt = (int)(a.q_indptr[q + 1] - tb);
-    for (int i = tid; i < SC_MAXQT; i += 256) {
-        qc[i] = i < nqt ? a.q_cols[tb + i] : 0x7fffffff;
-        qv[i] = i < nqt ? a.q_vals[tb + i] : 0.f;
-    }
+    for (int i = tid; i < 1024; i += 256) hk[i] = -1;
     if (tid == 0) n_kept = 0;
     __syncthreads();
+    for (int i = tid; i < nqt; i += 256) {                       // nqt <= SC_MAXQT, terms distinct (cert_plan_kernel's eligibility)
+        const int32_t t = a.q_cols[tb + i];
+        if (t < 0) continue;                                     // matches no doc term (and -1 marks an empty slot)
+        uint32_t h = ((uint32_t)t * 2654435761u) >> 22;
+        while (atomicCAS(&hk[h], -1, t) != -1) h = (h + 1u) & 1023u;
+        hv[h] = a.q_vals[tb + i];
+    }
+    __syncthreads();
     uint64_t* dst = a.cand_keys + q * a.cand_cap;
-    // the first 64 entries of the NEXT candidate's forward row are loaded while this one is intersected (a row is a ~1 KB gather)
-    auto row_of = [&](int c, int64_t& b, int64_t& e, int32_t& t, float& v) {
-        const int64_t doc = a.ap_ids[q * a.k_eff + (c < m ? c : m - 1)];
-        b = a.fwd_indptr[doc];
-        e = a.fwd_indptr[doc + 1];
-        const int64_t p = b + lane;
-        t = p < e ? a.fwd_term[p] : 0x7fffffff;
-        v = p < e ? a.fwd_val[p] : 0.f;
+    // One wave per candidate.  What the kernel's time is made of (timing-only builds, 7.7 M candidates per pass): the row gathers alone
+    // 1.5 ms (5.4 TB/s); the intersection alone, every load served from cache, 3.4 ms - and of that nearly all is the ORDERED sum: the
+    // products must be added one after the other in term order (the reference's fp32 chain), a scalar loop iteration per match (15-20
+    // per top candidate) with 63 lanes idle.  Tried and dropped: one LANE per candidate (64 chains side by side, but 64 rows per load
+    // instruction: 7.7 ms).  Kept: doc indices and row bounds of 64 candidates gathered at once (lane j = candidate j of the batch); the
+    // first 256 postings of the next TWO candidates' rows in flight, 16 bytes = two postings per lane, no load and no register touched
+    // at issue time on the common path (the compiler then waits with a counted vmcnt); the query's terms in a hash table instead of a
+    // binary search; a branch-free body of the ordered sum.
+    auto rl64 = [&](int64_t x, int j) -> int64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), j);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
     };
-    int64_t nb, ne;
-    int32_t nt;
-    float nv;
-    if (wave < m) row_of(wave, nb, ne, nt, nv);
-    for (int c = wave; c < m; c += 4) {
-        const int64_t doc = a.ap_ids[q * a.k_eff + c];
-        const int64_t b = nb, e = ne;
-        int32_t t = nt;
-        float v = nv;
-        if (c + 4 < m) row_of(c + 4, nb, ne, nt, nv);
-        float s = 0.f;
-        for (int64_t p0 = b; p0 < e; p0 += 64) {
-            if (p0 > b) {
-                const int64_t p = p0 + lane;
-                t = p < e ? a.fwd_term[p] : 0x7fffffff;
-                v = p < e ? a.fwd_val[p] : 0.f;
+    for (int c0 = wave; c0 < m; c0 += 256) {
+        const int cj = c0 + 4 * lane;                 // the wave's candidates: wave, wave + 4, ...
+        int64_t b_l = 0, e_l = 0;
+        uint32_t doc_l = 0u;
+        if (cj < m) {
+            const int64_t d = a.ap_ids[q * a.ap_stride + cj];
+            doc_l = (uint32_t)d;
+            b_l = a.fwd_indptr[d];
+            e_l = a.fwd_indptr[d + 1];
+        }
+        const int nb = (m - c0 + 3) / 4 < 64 ? (m - c0 + 3) / 4 : 64;
+        // a chunk = 128 postings of a row, two per lane; idle lanes read the table's start (the load is unconditional), and what lies beyond
+        // the row is masked where the chunk is USED - touching the registers here would wait for the load on the spot
+        auto load_chunk = [&](int64_t p0, int64_t e) -> u32x4_u {
+            const int64_t p = p0 + 2 * lane;
+            if (SC_DIAG & 1024) return *reinterpret_cast<const u32x4_u*>(a.fwd_tv + 2 * lane);      // timing only: every row is the table's start (cache hits)
+            return *reinterpret_cast<const u32x4_u*>(a.fwd_tv + (p < e ? p : 0));
+        };
+        u32x4_u rr[2][2];                             // [row in flight][chunk]: (value bits, term) x 2 per lane
+        auto fetch = [&](int j, u32x4_u (&r)[2]) {
+            const int jj = j < nb ? j : nb - 1;       // past the batch: re-reads its last row
+            const int64_t b = rl64(b_l, jj), e = rl64(e_l, jj);
+            r[0] = load_chunk(b, e);
+            r[1] = load_chunk(b + 128, e);
+        };
+        auto add_chunk = [&](const u32x4_u& r, int64_t p0, int64_t e, float& s) {
+            const int64_t p = p0 + 2 * lane;
+            const uint32_t t0 = r.y, t1 = r.w;
+            bool d0 = !(p < e), d1 = !(p + 1 < e), m0 = false, m1 = false;
+            uint32_t h0 = (t0 * 2654435761u) >> 22, h1 = (t1 * 2654435761u) >> 22;
+            while (!(d0 && d1)) {                      // both postings of a lane probe in one loop: their LDS reads go out together
+                const int32_t k0 = hk[h0], k1 = hk[h1];
+                if (!d0) {
+                    if (k0 == (int32_t)t0) { m0 = true; d0 = true; }
+                    else if (k0 == -1) d0 = true;
+                    else h0 = (h0 + 1u) & 1023u;
+                }
+                if (!d1) {
+                    if (k1 == (int32_t)t1) { m1 = true; d1 = true; }
+                    else if (k1 == -1) d1 = true;
+                    else h1 = (h1 + 1u) & 1023u;
+                }
             }
-            const bool live = p0 + lane < e;
-            int lo = 0;                       // lower bound of t among the query's terms (padded with INT_MAX to SC_MAXQT)
-#pragma unroll
-            for (int step = SC_MAXQT / 2; step > 0; step >>= 1)
-                if (qc[lo + step - 1] < t) lo += step;
-            const bool match = live && lo < nqt && qc[lo] == t;
-            const float prod = match ? qv[lo] * v : 0.f;
-            uint64_t mm = __ballot(match);
-            while (mm) {
+            const float w0 = hv[h0], w1 = hv[h1];
+            // a posting without a partner contributes +0.0f: s + 0.0f == s bit for bit (s is a sum of non-negative products, never -0)
+            const float prod0 = m0 ? w0 * __uint_as_float(r.x) : 0.f, prod1 = m1 ? w1 * __uint_as_float(r.z) : 0.f;
+            uint64_t mm = __ballot(m0 || m1);
+            while (mm) {                               // ascending terms: lane by lane, a lane's first posting before its second
                 const int i = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod), i));
+                s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod0), i));
+                s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod1), i));
             }
-        }
-        if (lane == 0 && s > a.threshold) {
-            const int pos = atomicAdd(&n_kept, 1);
-            dst[pos] = sr_make_key(s, a.id_base + (uint32_t)doc * a.id_stride);
+        };
+        auto intersect = [&](int j, const u32x4_u (&cr)[2]) {
+            const int64_t b = rl64(b_l, j), e = rl64(e_l, j);
+            const uint32_t doc = (uint32_t)__builtin_amdgcn_readlane((int)doc_l, j);
+            float s = 0.f;
+            add_chunk(cr[0], b, e, s);
+            if (e - b > 128) add_chunk(cr[1], b + 128, e, s);    // wave-uniform, no load inside
+            for (int64_t p0 = b + 256; p0 < e; p0 += 128) {      // rows beyond 256 postings: their own, rare loop
+                const u32x4_u r = load_chunk(p0, e);
+                add_chunk(r, p0, e, s);
+            }
+            if (lane == 0 && s > a.threshold) {
+                const int pos = atomicAdd(&n_kept, 1);
+                dst[pos] = sr_make_key(s, a.id_base + doc * a.id_stride);
+            }
+        };
+        fetch(0, rr[0]);
+        fetch(1, rr[1]);
+        for (int j = 0; j < nb; j += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4_u cr[2] = {rr[h][0], rr[h][1]};
+                fetch(j + h + 2, rr[h]);               // unconditional (clamped): a constant number of loads per step
+                if (j + h < nb && !(SC_DIAG & 512)) intersect(j + h, cr);  // wave-uniform (bit 512, timing only: rows loaded, nothing intersected)
+                if ((SC_DIAG & 512) && cr[0].x == 0x12345u && cr[1].y == 0x54321u) n_kept = 1;       // keeps the loads alive
+            }
         }
     }
     __syncthreads();
@@ -1176,12 +1269,10 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         c->nq_cap = nq_pad;
     }
     if (nq_pad * k_eff > c->ap_cap) {
-        SR_TRY(cert_realloc(c->ap_scores, (size_t)nq_pad * (size_t)k_eff));
-        SR_TRY(cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)k_eff));
-        SR_TRY(cert_realloc(c->ap_counts, (size_t)nq_pad));
+        SR_TRY(cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)(2 * k_eff)));
         c->ap_cap = nq_pad * k_eff;
     }
-    if (!c->d_n_uncert) SR_CHECK_HIP(hipMalloc((void**)&c->d_n_uncert, sizeof(int)));
+    if (!c->d_n_uncert) SR_CHECK_HIP(hipMalloc((void**)&c->d_n_uncert, 2 * sizeof(int)));      // [0] uncertified queries, [1] candidates re-scored (in units of 16)
     const int64_t dump_stride = (int64_t)c->n_tiles * SC_DT;
     if (c->want_dump && c->dump_nq < nq_pad) {
         SR_TRY(cert_realloc(c->dump, (size_t)nq_pad * (size_t)dump_stride));
@@ -1191,7 +1282,7 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
 
     // plan
     SR_CHECK_HIP(hipMemsetAsync(c->bfrag, 0, sizeof(_Float16) * (size_t)nq_pad * (size_t)c->T, s));
-    SR_CHECK_HIP(hipMemsetAsync(c->d_n_uncert, 0, sizeof(int), s));
+    SR_CHECK_HIP(hipMemsetAsync(c->d_n_uncert, 0, 2 * sizeof(int), s));
     CertPlanArgs pa;
     pa.q_indptr = d_q_indptr; pa.q_cols = d_q_cols; pa.q_vals = d_q_vals; pa.nq = nq; pa.n_terms = idx->n_terms;
     pa.indptr = idx->indptr; pa.dslot = c->dslot; pa.vmax = c->vmax; pa.KS = c->KS; pa.vscale = c->vscale;
@@ -1260,29 +1351,31 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
         t0 += nt;
         step *= 2;
     }
-    SR_TRY(topk_finalize(c->ws, nq_pad, k_eff, 0.f, c->ap_scores, c->ap_ids, c->ap_counts, s));
 
     // stage 2: certificate, exact re-score of the candidates, exact top-k of those
     CertSelectArgs sa;
-    sa.ap_scores = c->ap_scores; sa.ap_counts = c->ap_counts; sa.nq = nq; sa.k = k; sa.k_eff = k_eff; sa.T = c->T;
+    sa.run_keys = c->ws.run_keys; sa.run_count = c->ws.run_count; sa.tau = c->ws.tau; sa.ap_ids = c->ap_ids;
+    sa.nq = nq; sa.k = k; sa.k_eff = k_eff; sa.T = c->T;
     sa.elig = c->elig; sa.overflow = c->overflow; sa.n_rare = c->n_rare; sa.n_qt = c->n_qt; sa.n_drop = c->n_drop; sa.m_count = c->m_count;
     sa.uncert = d_uncert; sa.n_uncert = c->d_n_uncert;
-    hipLaunchKernelGGL(cert_select_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(cert_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, sa);
     SR_CHECK_LAUNCH();
     SR_TRY(topk_reset(c->ws, nq_pad, s));
     CertRescoreArgs ra;
     ra.q_indptr = d_q_indptr; ra.q_cols = d_q_cols; ra.q_vals = d_q_vals;
-    ra.fwd_indptr = c->fwd_indptr; ra.fwd_term = c->fwd_term; ra.fwd_val = c->fwd_val;
-    ra.ap_ids = c->ap_ids; ra.m_count = c->m_count; ra.k_eff = k_eff; ra.threshold = threshold;
+    ra.fwd_indptr = c->fwd_indptr; ra.fwd_tv = c->fwd_tv;
+    ra.ap_ids = c->ap_ids; ra.m_count = c->m_count; ra.ap_stride = 2 * k_eff; ra.threshold = threshold;
     ra.id_base = (uint32_t)id_base; ra.id_stride = (uint32_t)id_stride;
     ra.cand_keys = c->ws.cand_keys; ra.cand_count = c->ws.cand_count; ra.cand_cap = c->ws.cand_cap;
     hipLaunchKernelGGL(cert_rescore_kernel, dim3((unsigned)nq), dim3(256), 0, s, ra);
     SR_CHECK_LAUNCH();
     SR_TRY(topk_compact(c->ws, nq, k, s));
     SR_TRY(topk_finalize(c->ws, nq, k, 0.f, d_out_scores, d_out_ids, d_out_counts, s));
-    int h_un = 0;
-    SR_CHECK_HIP(hipMemcpyAsync(&h_un, c->d_n_uncert, sizeof(int), hipMemcpyDeviceToHost, s));
+    int h_un2[2] = {0, 0};
+    SR_CHECK_HIP(hipMemcpyAsync(h_un2, c->d_n_uncert, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     SR_CHECK_HIP(hipStreamSynchronize(s));
+    const int h_un = h_un2[0];
+    c->n_rescored += 16ll * h_un2[1];
     *n_uncert = h_un;
     ++c->n_calls;
     c->n_queries += nq;
@@ -1297,7 +1390,7 @@ extern "C" int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8) {
     std::lock_guard<std::mutex> lock(idx->mu);
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     if (SparseCert* c = idx->cert) {
-        out8[0] = 1; out8[1] = c->T; out8[2] = c->n_calls; out8[3] = c->n_queries; out8[4] = c->n_uncert; out8[5] = c->n_tiles;
+        out8[0] = 1; out8[1] = c->T; out8[2] = c->n_calls; out8[3] = c->n_queries; out8[4] = c->n_uncert; out8[5] = c->n_tiles; out8[6] = c->n_rescored;
     }
     return SR_OK;
 }

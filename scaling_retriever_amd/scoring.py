@@ -268,10 +268,11 @@ class SparseIndexHIP:
         return {"dense_terms": a.value, "block_calls": b.value, "fallback_calls": c.value}
 
     def cert_stats(self):
-        """Certified two-stage scorer (csrc/sparse_cert.hip): {"present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles"}."""
+        """Certified two-stage scorer (csrc/sparse_cert.hip): {"present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles",
+        "candidates_rescored" (exact chains run by the certified path, rounded up to 16 per query)}."""
         out = (ctypes.c_int64 * 8)()
         _lib.check(self.lib.sr_sparse_index_cert_stats(self._h, out), "sr_sparse_index_cert_stats")
-        keys = ("present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles")
+        keys = ("present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles", "candidates_rescored")
         return {k_: int(v) for k_, v in zip(keys, out)}
 
     def cert_record_keys(self, enable):

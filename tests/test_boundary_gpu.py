@@ -217,7 +217,7 @@ def test_write_run_in_pipelined_pieces_equals_one_file(tiny, tmp_path):
     for i, b in enumerate(loader):
         b["ids"] = [str(1000 * i + j) for j in range(len(b["ids"]))]
     p3, p1 = tmp_path / "run3.json", tmp_path / "run1.json"
-    assert retriever.RUN_PIECES == 3
+    assert retriever.RUN_PIECES == 4
     n_q, n3 = retriever.write_run(loader, 30, str(p3))
     retriever.RUN_PIECES = 1
     _, n1 = retriever.write_run(loader, 30, str(p1))
