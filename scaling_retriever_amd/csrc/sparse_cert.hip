@@ -1108,6 +1108,12 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
     __shared__ int32_t hk[1024];
     __shared__ float hv[1024];
     __shared__ int n_kept;
+    // queries of at most 64 terms (a row then has at most 64 matching postings): a row's products are compacted into LDS in term order
+    // and 16 rows are summed side by side, lane r adding up row r - the ordered sum costs a lane-parallel loop per 16 rows instead of
+    // a scalar loop iteration per match
+    __shared__ float pl[4][16][65];
+    __shared__ int pcnt[4][16];
+    __shared__ uint32_t pdoc[4][16];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = a.m_count[q];
@@ -1126,6 +1132,7 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
     }
     __syncthreads();
     uint64_t* dst = a.cand_keys + q * a.cand_cap;
+    const bool lists = nqt <= 64 && !(SC_DIAG & 2048);       // bit 2048: the scalar loop for every query (A/B)
     // One wave per candidate.  What the kernel's time is made of (timing-only builds, 7.7 M candidates per pass): the row gathers alone
     // 1.5 ms (5.4 TB/s); the intersection alone, every load served from cache, 3.4 ms - and of that nearly all is the ORDERED sum: the
     // products must be added one after the other in term order (the reference's fp32 chain), a scalar loop iteration per match (15-20
@@ -1192,6 +1199,59 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
                 s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod1), i));
             }
         };
+        // the same probe, the products written to their place in the row's list instead of being added
+        auto list_chunk = [&](const u32x4_u& r, int64_t p0, int64_t e, int row, int& base) {
+            const int64_t p = p0 + 2 * lane;
+            const uint32_t t0 = r.y, t1 = r.w;
+            bool d0 = !(p < e), d1 = !(p + 1 < e), m0 = false, m1 = false;
+            uint32_t h0 = (t0 * 2654435761u) >> 22, h1 = (t1 * 2654435761u) >> 22;
+            while (!(d0 && d1)) {
+                const int32_t k0 = hk[h0], k1 = hk[h1];
+                if (!d0) {
+                    if (k0 == (int32_t)t0) { m0 = true; d0 = true; }
+                    else if (k0 == -1) d0 = true;
+                    else h0 = (h0 + 1u) & 1023u;
+                }
+                if (!d1) {
+                    if (k1 == (int32_t)t1) { m1 = true; d1 = true; }
+                    else if (k1 == -1) d1 = true;
+                    else h1 = (h1 + 1u) & 1023u;
+                }
+            }
+            const uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+            if ((b0 | b1) == 0ull) return;
+            const float w0 = hv[h0], w1 = hv[h1];
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                              (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+            if (m0) pl[wave][row][base + below] = w0 * __uint_as_float(r.x);
+            if (m1) pl[wave][row][base + below + (m0 ? 1 : 0)] = w1 * __uint_as_float(r.z);
+            base += __popcll(b0) + __popcll(b1);
+        };
+        auto list_row = [&](int j, const u32x4_u (&cr)[2]) {
+            const int64_t b = rl64(b_l, j), e = rl64(e_l, j);
+            const int row = j & 15;
+            int base = 0;
+            list_chunk(cr[0], b, e, row, base);
+            if (e - b > 128) list_chunk(cr[1], b + 128, e, row, base);
+            for (int64_t p0 = b + 256; p0 < e; p0 += 128) {
+                const u32x4_u r = load_chunk(p0, e);
+                list_chunk(r, p0, e, row, base);
+            }
+            if (lane == 0) { pcnt[wave][row] = base; pdoc[wave][row] = (uint32_t)__builtin_amdgcn_readlane((int)doc_l, j); }
+        };
+        auto sum_rows = [&](int rows) {                 // lane r: row r's products, one after the other
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < rows) {
+                const int n = pcnt[wave][lane];
+                float s = 0.f;
+                for (int i = 0; i < n; ++i) s = s + pl[wave][lane][i];
+                if (s > a.threshold) {
+                    const int pos = atomicAdd(&n_kept, 1);
+                    dst[pos] = sr_make_key(s, a.id_base + pdoc[wave][lane] * a.id_stride);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
         auto intersect = [&](int j, const u32x4_u (&cr)[2]) {
             const int64_t b = rl64(b_l, j), e = rl64(e_l, j);
             const uint32_t doc = (uint32_t)__builtin_amdgcn_readlane((int)doc_l, j);
@@ -1214,7 +1274,12 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
             for (int h = 0; h < 2; ++h) {
                 const u32x4_u cr[2] = {rr[h][0], rr[h][1]};
                 fetch(j + h + 2, rr[h]);               // unconditional (clamped): a constant number of loads per step
-                if (j + h < nb && !(SC_DIAG & 512)) intersect(j + h, cr);  // wave-uniform (bit 512, timing only: rows loaded, nothing intersected)
+                if (j + h < nb && !(SC_DIAG & 512)) {     // wave-uniform (bit 512, timing only: rows loaded, nothing intersected)
+                    if (lists) {
+                        list_row(j + h, cr);
+                        if (((j + h) & 15) == 15 || j + h == nb - 1) sum_rows(((j + h) & 15) + 1);
+                    } else intersect(j + h, cr);
+                }
                 if ((SC_DIAG & 512) && cr[0].x == 0x12345u && cr[1].y == 0x54321u) n_kept = 1;       // keeps the loads alive
             }
         }

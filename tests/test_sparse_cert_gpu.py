@@ -320,3 +320,25 @@ def test_band_filter_threshold_is_valid_and_changes_no_row(forced, monkeypatch, 
     monkeypatch.setenv("SR_SPARSE_CERT_BAND", "0")
     s0, i0, c0 = idx.search(qi, qc, qv, k)
     assert np.array_equal(s0.cpu().numpy(), s1) and np.array_equal(i0.cpu().numpy(), i1) and np.array_equal(c0.cpu().numpy(), c1)
+
+
+def test_long_queries_take_the_scalar_ordered_sum(forced):
+    """More than 64 query terms (at most 64 of them rare, or the query is not on the fast path at all): the re-score adds a row's products
+    in its scalar loop instead of the 64-entry LDS lists; rows must still be the oracle's."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(91)
+    V, N, nq = 1500, 70000, 24
+    indptr, ids, vals = _zipf_index(rng, V, N, 60)
+    qi, qc, qv = [0], [], []
+    for q in range(nq):
+        heavy = rng.choice(120, size=70 + q % 20, replace=False)              # the longest lists: on the matrix pipe
+        rare = 200 + rng.choice(V - 200, size=20 + q % 30, replace=False)
+        cols = np.sort(np.concatenate([heavy, rare])).astype(np.int32)
+        qc.append(cols)
+        qv.append(np.log1p(rng.uniform(0, 20, size=len(cols))).astype(np.float32))
+        qi.append(qi[-1] + len(cols))
+    qi, qc, qv = np.array(qi, np.int64), np.concatenate(qc), np.concatenate(qv)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, 100)
+    st = idx.cert_stats()
+    assert st["searches"] == 1 and st["redone_exact"] <= nq // 4 and st["candidates_rescored"] > 0
