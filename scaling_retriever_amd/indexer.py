@@ -27,7 +27,7 @@ from tqdm import tqdm
 from . import _lib
 from .scoring import DenseIndexHIP, SparseIndexHIP, sparse_csr_build, sparse_csr_expand_terms
 from .utils.inverted_index import IndexDictOfArray
-from .utils.run_file import IdTable, RunResult, to_host
+from .utils.run_file import IdTable, RunResult, id_table, to_host, write_run_json
 from .utils.utils import get_rank, get_world_size, is_first_worker, to_list
 
 logger = logging.getLogger()
@@ -715,9 +715,44 @@ class SparseRetrieval:
         res.dump(os.path.join(self.out_dir, "run.json"))        # sr_write_run_json: the bytes json.dump(res) writes
 
     def retrieve(self, q_loader, topk, threshold=0.):
-        sparse_query_vecs, qids = self._generate_query_vecs(q_loader)
-        res, stats = self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
-        self._write_outputs(res, stats)
+        """indexer.py:530-540.  Query groups of QUERY_GROUP_ROWS rows go through encode -> search one after the other while a worker
+        thread writes the previous group's piece of run.json (sr_write_run_json_part): formatting and the page-cache copy of a Dev-sized
+        file take as long as the encode, and nothing in them needs the GPU.  A query's rows do not depend on the batch it is searched in
+        (certified or exact: the same bits), and the file is the one-call file byte for byte (tests/test_boundary_gpu.py)."""
+        groups = list(batch_groups(q_loader, self.QUERY_GROUP_ROWS))
+        group_qids = [[x for batch in g for x in (batch["ids"] if isinstance(batch["ids"], list) else to_list(batch["ids"]))] for g in groups]
+        qids = [x for g in group_qids for x in g]
+        table = self.doc_id_table()
+        if len(groups) < 2 or not (id_table(qids).distinct and id_table(table).distinct):
+            sparse_query_vecs, qids = self._generate_query_vecs([batch for g in groups for batch in g])
+            res, stats = self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
+            self._write_outputs(res, stats)
+            return res
+        from concurrent.futures import ThreadPoolExecutor
+        os.makedirs(self.out_dir, exist_ok=True)
+        path = os.path.join(self.out_dir, "run.json")
+        pieces, nnz, writes = [], 0, []
+        with ThreadPoolExecutor(max_workers=1) as writer:              # one worker: the pieces reach the file in order
+            for gi, group in enumerate(groups):
+                with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:390-391
+                    reps = encode_group(self.model, group, self.device)
+                q = QueryCSR(*sparse_reps_to_csr(reps))
+                del reps
+                nnz += int(q.cols.numel())
+                scores, ids, counts = self.hip_index.search(q.row_ptr, q.cols, q.vals, topk, threshold=threshold)
+                piece = (to_host(scores), to_host(ids), to_host(counts))
+                pieces.append(piece)
+                part = 1 if gi == 0 else (3 if gi + 1 == len(groups) else 2)
+                writes.append(writer.submit(write_run_json, path, group_qids[gi], piece[0], piece[1], table, piece[2], 0, part))
+            for w in writes:
+                w.result()
+        res = RunResult(qids, np.concatenate([p_[0] for p_ in pieces]), np.concatenate([p_[1] for p_ in pieces]), table,
+                        np.concatenate([p_[2] for p_ in pieces]))
+        if self.compute_stats:
+            stats = defaultdict(float)
+            stats["L0_q"] = float(nnz) / len(qids) if qids else 0.0
+            with open(os.path.join(self.out_dir, "q_stats.json"), "w") as handler:
+                json.dump(stats, handler)
         return res
 
 

@@ -177,24 +177,29 @@ class RunResult(Mapping):
         self.scores = np.ascontiguousarray(scores, dtype=np.float32)
         self.positions = np.ascontiguousarray(positions, dtype=np.int64)
         self.counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.int32)
-        k = self.scores.shape[1] if self.scores.ndim == 2 else 0
-        valid = self.positions >= 0
+        self._row_of = None                     # built on first access: a caller that only wanted the files pays nothing for the mapping
+
+    def _keep(self, r):
+        keep = self.positions[r] >= 0
         if self.counts is not None:
-            valid &= np.arange(k)[None, :] < self.counts[:, None]
-        self._valid = valid
-        self._has_hit = valid.any(1) if valid.size else np.zeros(len(self.scores), dtype=bool)
-        self._row_of = None
+            keep &= np.arange(keep.shape[0]) < self.counts[r]
+        return keep
 
     def _rows(self):
         if self._row_of is None:
+            k = self.scores.shape[1] if self.scores.ndim == 2 else 0
+            valid = self.positions >= 0
+            if self.counts is not None:
+                valid &= np.arange(k)[None, :] < self.counts[:, None]
+            has_hit = valid.any(1) if valid.size else np.zeros(len(self.scores), dtype=bool)
             rows = {}
-            for r in np.nonzero(self._has_hit)[0].tolist():
+            for r in np.nonzero(has_hit)[0].tolist():
                 rows.setdefault(self.qids.key(r), []).append(r)
             self._row_of = rows
         return self._row_of
 
     def _row_dict(self, r):
-        keep = self._valid[r]
+        keep = self._keep(r)
         return dict(zip(self.docs.keys_of(self.positions[r][keep]), self.scores[r][keep].astype(np.float64).tolist()))
 
     def __getitem__(self, qid):

@@ -179,3 +179,29 @@ def test_sharded_dense_retriever_single_process_fake_world():
         si.append(i)
     ms, mi = topk_merge(torch.stack(ss), torch.stack(si))
     assert torch.equal(mi, fi) and torch.equal(ms, fs)
+
+
+def test_sparse_retrieve_in_pipelined_groups_equals_one_group(tiny, tmp_path, monkeypatch):
+    """SparseRetrieval.retrieve takes the query groups one after the other (encode -> search) while a worker thread writes the previous
+    group's piece of run.json: same mapping, same file bytes and same q_stats.json as the one-group path."""
+    from scaling_retriever_amd.indexer import SparseIndexer, SparseRetrieval
+    from scaling_retriever_amd.modeling.llm_encoder import LlamaBiSparse
+    cfg, w = tiny
+    V = cfg["vocab_size"]
+    rng = np.random.default_rng(5)
+    docs, queries = _corpus(rng, 300, V, 1, 6), _corpus(rng, 37, V, 1, 3)
+    pids, qids = [f"p{i}" for i in range(len(docs))], [f"q{7 * i}" for i in range(len(queries))]
+    model = LlamaBiSparse.from_weights(cfg, w, precision="bf16").to("cuda").eval()
+    index_dir = str(tmp_path / "index")
+    SparseIndexer(model, index_dir=index_dir, compute_stats=True, dim_voc=model.vocab_size, device="cuda").index(
+        FakeLoader(docs, pids, batch_size=16, pad_id=V - 1))
+    outs = []
+    for name, rows in (("one", 2048), ("many", 8)):           # 37 queries in loader batches of 4: one group / five groups of 8 rows
+        monkeypatch.setattr(SparseRetrieval, "QUERY_GROUP_ROWS", rows)
+        retr = SparseRetrieval(config={"index_dir": index_dir, "out_dir": str(tmp_path / name)}, model=model, compute_stats=True,
+                               dim_voc=model.vocab_size, device="cuda")
+        res = retr.retrieve(FakeLoader(queries, qids, batch_size=4, pad_id=V - 1), topk=20, threshold=0.0)
+        outs.append((res.to_dict(), (tmp_path / name / "run.json").read_bytes(), json.load(open(tmp_path / name / "q_stats.json"))))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 30
+    assert outs[0][1] == outs[1][1]
+    assert outs[0][2]["L0_q"] == pytest.approx(outs[1][2]["L0_q"], rel=1e-6)
