@@ -174,53 +174,55 @@ class LocalFaissDenseRetriever(DenseRetriever):
 
     def write_run(self, dataloader, top_docs, path):
         """get_top_docs + the run.json loop of eval_dense.py:225-241 in one go, without materialising a Python object per hit:
-        encode, search, and sr_write_run_json over the result arrays.  Returns (number of queries, file size)."""
+        encode, search, and sr_write_run_json over the result arrays.  Returns (number of queries, file size).
+        A large query set goes through in pieces: this thread drives the GPU (encode piece c, search piece c) while a worker thread formats
+        and writes piece c - 1 (the C call releases the GIL).  Exact results do not depend on how the queries are batched (pieces stay above
+        64 queries) and the file is the one-call file byte for byte."""
         import time
+        from concurrent.futures import ThreadPoolExecutor
         from scaling_retriever_amd.utils.run_file import id_table, write_run_json
         t_start = time.perf_counter()
-        query_reps, qids = generate_query_vecs(self.model, dataloader, self.device)
-        nq = len(qids)
-        tl = self.last_run_timeline = {"generate_query_vecs_returned_ms": round((time.perf_counter() - t_start) * 1e3, 1), "pieces": []}
+        batches = list(dataloader)
+        sizes = [len(b["ids"]) for b in batches]
+        nq = sum(sizes)
+        all_qids = [x for b in batches for x in b["ids"]]
         table = self.index.run_table()
-        n_pieces = self.RUN_PIECES if nq >= 1024 and table.distinct and id_table(qids).distinct else 1
+        n_pieces = self.RUN_PIECES if nq >= 1024 and table.distinct and id_table(all_qids).distinct else 1
+        tl = self.last_run_timeline = {"pieces": []}
         if n_pieces == 1:
+            query_reps, qids = generate_query_vecs(self.model, batches, self.device)
             scores, positions = self.index.search_arrays(query_reps, top_docs)
             return nq, write_run_json(path, qids, scores, positions, table)
-        # the query set in pieces: the GPU searches piece c + 1 (worker thread; the C call releases the GIL) while this thread formats
-        # and writes piece c - the exact results do not depend on how the queries are batched (pieces stay above 64 queries)
-        import torch
-        from concurrent.futures import ThreadPoolExecutor
-        # pieces of whole 256-query tiles (the scorer pads a query set to tiles: 3 x 2 327 queries are 30 of them, 6 980 are 28), shrinking
-        # towards the end: the writing of piece c hides under the search of piece c + 1 while it is no longer than that search, and only the
-        # last piece's writing (75 MB into the page cache took 38-88 ms for 2 116 queries over runs) stays on the critical path
+        # piece boundaries: whole loader batches, as close as they come to whole 256-query tiles (the scorer pads a query set to tiles:
+        # 3 x 2 327 queries are 30 of them, 6 980 are 28), shrinking towards the end - only the LAST piece's writing stays on the critical
+        # path (60-75 MB into the page cache took 18-90 ms over runs)
         tiles = (nq + 255) // 256
-        shares = self.RUN_PIECE_SHARES[:n_pieces]
-        acc, cuts = 0.0, [0]
+        shares, acc, targets = self.RUN_PIECE_SHARES[:n_pieces], 0.0, []
         for w in shares[:-1]:
             acc += w / sum(shares)
-            cuts.append(min(nq, 256 * max(cuts[-1] // 256 + 1, round(tiles * acc))))
-        cuts = [c_ for c_ in cuts if nq - c_ > 64] + [nq]         # no piece of 64 queries or fewer: those take the small-batch kernel (other summation order)
-        bounds = [(cuts[c], cuts[c + 1]) for c in range(len(cuts) - 1) if cuts[c + 1] > cuts[c]]
-        dev = self.index.index.device
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))
-
-        def gpu(c):
-            with torch.cuda.device(dev):
-                torch.cuda.current_stream(dev).wait_event(ready)
-                return self.index.search_arrays(query_reps[bounds[c][0]:bounds[c][1]], top_docs)
-        size = 0
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(gpu, 0)
-            for c, (b0, b1) in enumerate(bounds):
+            targets.append(min(nq, 256 * max(1, round(tiles * acc))))
+        cum, cuts = 0, [0]
+        for bi, n in enumerate(sizes):
+            cum += n
+            if len(cuts) - 1 < len(targets) and cum >= targets[len(cuts) - 1] and nq - cum > 64 and cum - sum(sizes[:cuts[-1]]) > 64:
+                cuts.append(bi + 1)
+        cuts.append(len(batches))
+        pieces = [batches[cuts[c]:cuts[c + 1]] for c in range(len(cuts) - 1) if cuts[c + 1] > cuts[c]]
+        size, writes = 0, []
+        with ThreadPoolExecutor(max_workers=1) as writer:              # one worker: the pieces reach the file in order
+            for c, piece in enumerate(pieces):
                 t0 = time.perf_counter()
-                scores, positions = fut.result()
+                reps, qids = generate_query_vecs(self.model, piece, self.device)
+                scores, positions = self.index.search_arrays(reps, top_docs)
                 t1 = time.perf_counter()
-                if c + 1 < len(bounds):
-                    fut = pool.submit(gpu, c + 1)
-                size = write_run_json(path, qids[b0:b1], scores, positions, table, part=1 if c == 0 else (3 if c + 1 == len(bounds) else 2))
-                tl["pieces"].append({"queries": b1 - b0, "waited_for_the_search_ms": round((t1 - t0) * 1e3, 1),
-                                     "formatted_and_written_ms": round((time.perf_counter() - t1) * 1e3, 1)})
+                part = 1 if c == 0 else (3 if c + 1 == len(pieces) else 2)
+                writes.append(writer.submit(write_run_json, path, qids, scores, positions, table, None, 0, part))
+                tl["pieces"].append({"queries": len(qids), "encode_and_search_ms": round((t1 - t0) * 1e3, 1)})
+            t2 = time.perf_counter()
+            for w in writes:
+                size = w.result()
+            tl["waited_for_the_writer_after_the_last_search_ms"] = round((time.perf_counter() - t2) * 1e3, 1)
+        tl["total_ms"] = round((time.perf_counter() - t_start) * 1e3, 1)
         return nq, size
 
 
