@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void topk_gather_segments_kernel(uint64_t* __r
 
 // ---------------------------------------------------------------- compact ---
 // One workgroup (256 threads) per query.  run_keys has 2k slots per query.
-#define TOPK_SEL_R 28        // keys per thread the select keeps in registers (unions of up to 7168 keys; 120 VGPRs = 4 workgroups per CU)
+// TOPK_SEL_R = keys per thread the select keeps in registers: 28 (unions of up to 7 168 keys; 120 VGPRs = 4 workgroups per CU) by default,
+// 20 (5 120 keys) for callers whose unions are known to be smaller (the certified sparse scorer: at most 2 (k + 1 024) keys + a launch's survivors)
+template <int TOPK_SEL_R>
 __global__ __launch_bounds__(256) void topk_compact_kernel(uint64_t* __restrict__ run_keys, int* __restrict__ run_count,
                                                            float* __restrict__ tau, uint64_t* __restrict__ cand_keys,
                                                            int* __restrict__ cand_count, int k, int64_t cand_cap,
@@ -464,8 +466,12 @@ int topk_compact2(TopkWS& ws, int64_t nq, int k, int k2, float* d_tau2, int sele
                            ws.cand_cap, ws.seg_cnt, ws.seg_n, ws.seg_off, nq);
         SR_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
-                       ws.cand_keys, ws.cand_count, k, ws.cand_cap, k2, d_tau2, select_over);
+    if (k2 > 0 && 2 * k + 1024 <= 256 * 20)
+        hipLaunchKernelGGL(topk_compact_kernel<20>, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
+                           ws.cand_keys, ws.cand_count, k, ws.cand_cap, k2, d_tau2, select_over);
+    else
+        hipLaunchKernelGGL(topk_compact_kernel<28>, dim3((unsigned)nq), dim3(256), lds, s, ws.run_keys, ws.run_count, ws.tau,
+                           ws.cand_keys, ws.cand_count, k, ws.cand_cap, k2, d_tau2, select_over);
     SR_CHECK_LAUNCH();
     return SR_OK;
 }
