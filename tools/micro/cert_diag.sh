@@ -1,6 +1,11 @@
 #!/bin/bash
 # Timing-only variants of cert_score_kernel (never shipped; wrong results): which role sets the tile time?
 #   SC_DIAG bit 1: scatter waves add no postings   bit 2: matrix waves load / multiply nothing   bit 4: no table lookups
+#           bit 8: no LDS adds   16: plain read-modify-write instead of the LDS atomic   32: loads but no MFMA   64: MFMA but no loads
+#           bit 128: no candidates (queries then go to the exact kernels: read the cert kernel's own time from the stamps or a trace)
+#           bit 512: re-score loads its rows but intersects nothing   1024: re-score reads every row from the table's start (cache hits)
+#           bit 2048: re-score adds with its scalar loop for every query
+#   third argument: extra compiler flags, e.g. "-DSC_STAMPS=1 -Wno-inline-asm" for the per-role cycle stamps (SR_CERT_STAMPS=<first tile>)
 # Build HERE (hipcc cross-compiles): bash tools/micro/cert_diag.sh build "0 1 2 3 5 7" ; run on the GPU box: bash tools/micro/cert_diag.sh run "0 1 2 3 5 7"
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
