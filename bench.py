@@ -504,7 +504,7 @@ def sparse_index_leg(args, device):
     chunks, lens = synth_token_chunks(n_pass, 4.25, 0.35, 8, 192, V, 5, (0, n_pass))
 
     def loader():
-        return TokenBudgetCollectionLoader(tokenized=chunks, max_length=192, max_tokens=args.token_budget // 2, max_seqs=512,
+        return TokenBudgetCollectionLoader(tokenized=chunks, max_length=192, max_tokens=args.token_budget, max_seqs=1024,
                                            window=32768, pad_token_id=V - 1, padding_side="left")
     # The constant that leaves 128 entries per passage on average.  The loader's batches hold passages of similar length, and a rep's
     # scale grows with the number of tokens under its max: one batch calibrates its own length only (first batch: L0_d 316-390 over the
@@ -525,7 +525,7 @@ def sparse_index_leg(args, device):
     stub = _ThresholdedSparseDocs(model, shift)
     with contextlib.redirect_stdout(sys.stderr):
         SparseIndexer(stub, None, device, compute_stats=True, dim_voc=V).index(
-            TokenBudgetCollectionLoader(tokenized=chunks[:1], max_length=192, max_tokens=args.token_budget // 2, max_seqs=512,
+            TokenBudgetCollectionLoader(tokenized=chunks[:1], max_length=192, max_tokens=args.token_budget, max_seqs=1024,
                                         pad_token_id=V - 1, padding_side="left"))                     # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
