@@ -59,6 +59,55 @@ def test_sparse_search_random_shapes(seed, V, N, density, nq, nterms, k, thresho
     index.close()
 
 
+@settings(max_examples=60, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(20, 400), st.integers(1, 9000), st.floats(0.002, 0.25), st.integers(1, 70),
+       st.integers(1, 40), st.sampled_from([1, 7, 100, 1000, 3000]), st.sampled_from([0.0, 0.7]), st.booleans())
+def test_certified_sparse_scorer_random_shapes(monkeypatch_module, seed, V, N, density, nq, nterms, k, threshold, zeros):
+    """The certified two-stage scorer forced on (it is sized for collections of >= 64 tiles): collections of one ragged tile up to nine,
+    term laws with and without lists that cover every doc, queries with zero-valued terms, k above the collection size, a positive
+    threshold - every row must be the oracle's, whichever of its paths (certified, handed back to the exact kernels) served it."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(seed)
+    dens = np.minimum(1.0, density * 8.0 / np.arange(1, V + 1) ** 0.7)            # a few heavy terms, a long tail
+    lists = [np.sort(rng.choice(N, size=rng.binomial(N, d_), replace=False)).astype(np.int32) for d_ in dens]
+    indptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+    doc_ids = np.concatenate(lists).astype(np.int32)
+    if len(doc_ids) == 0:
+        return
+    vals = np.log1p(rng.random(len(doc_ids)) * 20).astype(np.float32)
+    nterms = min(nterms, V)
+    cols = np.concatenate([np.sort(rng.choice(V, size=nterms, replace=False)) for _ in range(nq)]).astype(np.int32)
+    qv = np.log1p(rng.random(nq * nterms) * 20).astype(np.float32)
+    if zeros:
+        qv[rng.random(len(qv)) < 0.2] = 0.0
+    q_indptr = np.arange(0, nq * nterms + 1, nterms, dtype=np.int64)
+    index = SparseIndexHIP(torch.from_numpy(indptr).cuda(), torch.from_numpy(doc_ids).cuda(), torch.from_numpy(vals).cuda(), N)
+    s, i, c = index.search(torch.from_numpy(q_indptr).cuda(), torch.from_numpy(cols).cuda(), torch.from_numpy(qv).cuda(), k, threshold=threshold)
+    oi, os_, oc = SC.sparse_retrieve_c(indptr, doc_ids, vals, q_indptr, cols, qv, k, threshold, N, q_threads=2)
+    s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
+    assert np.array_equal(c, oc)
+    for q in range(nq):
+        assert np.array_equal(i[q, :c[q]], oi[q, :c[q]]) and np.array_equal(s[q, :c[q]], os_[q, :c[q]]), q
+    st_ = index.cert_stats()
+    assert st_["present"] == 1 and (st_["searches"] == 1 or k + 1024 > 4096)
+    index.close()
+
+
+@pytest.fixture(scope="module")
+def monkeypatch_module():
+    """SR_SPARSE_CERT=1 (dev switch) for the whole module's forced-scorer tests: hypothesis re-enters the test function many times, and a
+    function-scoped monkeypatch may not be combined with @given."""
+    import os
+    old = {k_: os.environ.get(k_) for k_ in ("SR_SPARSE_CERT", "SR_DEV_SWITCHES")}
+    os.environ["SR_SPARSE_CERT"], os.environ["SR_DEV_SWITCHES"] = "1", "1"
+    yield
+    for k_, v in old.items():
+        if v is None:
+            os.environ.pop(k_, None)
+        else:
+            os.environ[k_] = v
+
+
 @pytest.fixture(scope="module")
 def tiny_models(golden_dir):
     import json
