@@ -277,7 +277,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #define KL_DSR(DST, BASE, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "n"(OFF))
 // KL_DMA writes m0 (the LDS destination of the DMA) and says so in its clobber list: the compiler may use m0 itself anywhere around the asm
 // (an LDS-DMA builtin, s_movrel, sendmsg) and will not carry a value in it across this statement.  The loads it issues are NOT tracked by the
-// compiler's vmcnt / lgkmcnt bookkeeping: every wait for them in the four-wave loop is written by hand (KL_WAIT_*), and nothing outside the asm
+// compiler's vmcnt / lgkmcnt bookkeeping: every wait for them in the four-wave loop is written by hand (the `s_waitcnt vmcnt(16)` / `lgkmcnt(0)` + `s_barrier` asm at the KL_B1_AT / KL_B2_AT slots), and nothing outside the asm
 // blocks reads the LDS bytes they fill before such a wait + barrier.
 #define KL_DMA(SRD, VOFF, KOFF, M0B, M0OFF)                                                                         \
         asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(KOFF), "s"(M0B), "n"(M0OFF) : "memory", "scc", "m0")
