@@ -73,6 +73,99 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def _finite(o):
+    """Non-finite floats become null: the contract line is strict JSON (no NaN / Infinity tokens)."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+CONTRACT_LINE_MAX = 4096
+
+
+def contract_line(res):
+    """The ONE stdout line the driver parses: the contract fields, `roofline` and `cpu_baseline` of the headline, and a few scalars
+    per leg.  Everything else (`res`: notes, sweeps, timelines) goes to stderr and to gpurun_out/bench_detail.json."""
+    r, c = res.get("roofline") or {}, res.get("cpu_baseline") or {}
+    cfg = res["config"]
+    sp, enc, c5, di = res.get("sparse") or {}, res.get("encode") or {}, res.get("config5_8b") or {}, res.get("drop_in") or {}
+    sweep = _get(sp, "sparse_sweep", "rows") or []
+    line = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": f"Lion-DS-1B dense, BASELINE configs[{1 if res['n_gpus'] == 1 else 3}]: {cfg['n_queries']} Dev queries encoded "
+                                  f"(HIP LlamaBiDense 1B dims, {cfg['layers']} layers, fp32 regime) + exact fp32 top-{cfg['topk']} over "
+                                  f"{cfg['n_docs']} x {cfg['hidden']} embeddings resident in HBM",
+                      "n_docs": cfg["n_docs"], "n_queries": cfg["n_queries"], "hidden": cfg["hidden"], "topk": cfg["topk"],
+                      "layers": cfg["layers"], "parallelism": f"doc-shard x{res['n_gpus']}", "ranks": cfg.get("ranks")}
+    line["roofline"] = {"kernel": (r.get("kernel") or "").split(" (")[0], "bound": r.get("bound"), "achieved": r.get("achieved"),
+                        "peak": r.get("peak"), "unit": "TFLOP/s", "frac": r.get("frac"), "traffic": r.get("traffic"),
+                        "launches": r.get("launches"), "avg_launch_ms": r.get("avg_launch_ms"), "flop_per_launch": r.get("flop_per_launch"),
+                        "kernel_share_of_step": r.get("kernel_share_of_step")} if r else None
+    line["cpu_baseline"] = {"value": c.get("value"), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+                            "threads": c.get("cores"), "host_cpu": c.get("host_cpu"),
+                            "sample": (c.get("sample_short") or (c.get("sample") or "")[:160])} if c else None
+    line["parity"] = "bit-identical to the exact fp32 kernel, all queries" if res.get("parity") and "bit-identical" in res["parity"] else res.get("parity")
+    line["breakdown"] = {"query_encode_ms": _get(res, "breakdown", "query_encode_ms"), "search_ms": _get(res, "breakdown", "search_ms"),
+                         "query_encode_frac": (round(_get(res, "breakdown", "query_encode_mfma_TFLOPs") / PEAK_BF16_MFMA_TF, 4)
+                                               if _get(res, "breakdown", "query_encode_mfma_TFLOPs") else None)}
+    line["exact_kernel"] = {"qps": _get(res, "exact_kernel_mode", "value"), "frac_fp32_mfma": _get(res, "exact_kernel_mode", "roofline", "frac")}
+    line["drop_in"] = {"retrieval_qps": _get(di, "retrieval_task_with_run_json", "queries_per_s"), "search_knn_qps": _get(di, "search_knn", "queries_per_s")}
+    line["encode"] = {"passages_per_s": enc.get("value"), "frac": _get(enc, "roofline", "frac"), "sample_passages": enc.get("sample_passages"),
+                      "padded_128_passages_per_s": _get(enc, "padded_batch_128_mode", "passages_per_s")} if enc else None
+    line["sparse"] = {"qps": sp.get("value"), "ms_per_pass": sp.get("ms_per_pass"), "kernel": _get(sp, "roofline", "kernel"),
+                      "bound": _get(sp, "roofline", "bound"), "achieved_GBps": _get(sp, "roofline", "achieved"),
+                      "frac": _get(sp, "roofline", "frac"), "traffic": _get(sp, "roofline", "traffic"),
+                      "kernel_ms_per_pass": _get(sp, "roofline", "kernel_ms_per_pass"),
+                      "kernel_over_sum_of_floors": _get(sp, "bounds", "kernel_over_sum_of_floors"),
+                      "redone_exact": _get(sp, "path", "queries_redone_by_the_exact_kernels_per_pass"),
+                      "exact_kernels_qps": _get(sp, "exact_kernels", "queries_per_s"),
+                      "oracle_bit_exact_queries": sp.get("oracle_bit_exact_queries"),
+                      "cpu_qps": _get(sp, "cpu_baseline", "value"), "cpu_cores": _get(sp, "cpu_baseline", "cores"),
+                      "retrieve_qps": _get(sp, "drop_in", "retrieve", "queries_per_s"),
+                      "index_build_postings_per_s": _get(sp, "index_build", "postings_per_s"),
+                      "index_build_frac": _get(sp, "index_build", "roofline", "frac"),
+                      "index_passages_per_s": _get(sp, "sparse_index", "passages_per_s"),
+                      "index_frac": _get(sp, "sparse_index", "roofline", "frac"),
+                      "index_sample_passages": _get(sp, "sparse_index", "sample_passages"),
+                      "sweep": {"cells": len(sweep), "min_qps": min((x["queries_per_s"] for x in sweep), default=None),
+                                "max_L0_q": max((x["L0_q"] for x in sweep), default=None),
+                                "redone_exact": sum(x["queries_redone_by_the_exact_kernels"] for x in sweep),
+                                "all_bit_exact": all(x.get("queries_bit_exact_vs_oracle", 0) >= 64 for x in sweep)} if sweep else None} if sp else None
+    line["config5_8b"] = {"encode_passages_per_s": _get(c5, "encode", "value"), "encode_frac": _get(c5, "encode", "roofline", "frac"),
+                          "score_shard_qps": _get(c5, "score_shard_filtered", "queries_per_s")} if c5 else None
+    line["small_batch"] = [{"nq": x["nq"], "frac_hbm": x["frac"]} for x in (res.get("small_batch") or [])] or None
+    line["detail"] = "gpurun_out/bench_detail.json"
+    text = json.dumps(_finite(line), allow_nan=False, separators=(",", ":"))
+    assert len(text) < CONTRACT_LINE_MAX and "Infinity" not in text and "NaN" not in text, len(text)
+    return text
+
+
+def emit(res):
+    """Full record -> stderr + side file; the compact contract line -> the LAST line of stdout."""
+    full = json.dumps(_finite(res), allow_nan=False)
+    log("[bench detail]", full)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        log("[bench detail] side file not written:", e)
+    sys.stdout.flush()
+    print(contract_line(res), flush=True)
+
+
 def random_weights(cfg, device, seed):
     """Random-init weights of the named architecture, generated on the device in bf16 (no checkpoints offline)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -406,6 +499,7 @@ def sparse_leg(args, device):
     for q in range(check):
         assert gc[q] == oc[q], (q, gc[q], oc[q])
         assert np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), q
+    out["oracle_bit_exact_queries"] = int(check)
     out["parity"] = f"{check} queries bit-exact (ids and fp32 scores) vs the oracle's C port of numba_score_float + select_topk at full size"
     best = max(runs, key=lambda r: r["qps"])
     out["cpu_baseline"] = {"value": round(runs[0]["qps"], 3), "unit": "queries/s", "cores": 32, "kind": "port",
@@ -544,7 +638,7 @@ def sparse_index_leg(args, device):
     out = {"workload": f"SparseIndexer.index: {n_pass} synthetic passages (mean {tokens / n_pass:.1f} tokens) at Lion-SP-1B dims, token-budget loader, real HIP "
                        f"encoder + sparse head, reps thresholded to L0_d ~ 128 (random weights give no realistic sparsity), sr_sparse_compact per batch, "
                        f"sr_sparse_csr_build at the end, index kept on the device",
-           "passages_per_s": round(n_pass / t, 1), "seconds": round(t, 2), "tokens_per_s": round(tokens / t, 1), "L0_d": round(nnz / n_pass, 1),
+           "passages_per_s": round(n_pass / t, 1), "sample_passages": int(n_pass), "seconds": round(t, 2), "tokens_per_s": round(tokens / t, 1), "L0_d": round(nnz / n_pass, 1),
            "postings": nnz, "stats": {k_: round(float(v_), 2) for k_, v_ in res.get("stats", {}).items()},
            "roofline": {"kernel": "gemm_bf16_kernel (encoder body + lm_head with the segmented-max epilogue)", "bound": "mfma", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TF, 4),
@@ -1262,6 +1356,8 @@ def main():
         cpu = {"value": main_shape["value"], "unit": "queries/s", "cores": main_shape["threads"], "kind": "port", "host_cpu": host,
                "host_hardware_threads": cores, "sgemm_gflops": main_shape["sgemm_gflops"],
                "all_hardware_threads": shapes[cores] if cores != main_shape["threads"] else None,
+               "sample_short": f"score stage only: faiss flat-IP port (host sgemm + heap, oracle/score_cpu.c), {nqs} queries x {ns} docs, "
+                               f"median of 3, scaled to {args.n_docs} docs",
                "sample": f"scoring stage only (oracle.scoring.flat_ip_search_blas_heap = faiss IndexFlatIP.search as faiss-cpu runs it: "
                          f"host BLAS (OpenBLAS behind numpy) sgemm over (query block, database block) pairs + one heap per query in C / OpenMP, "
                          f"oracle/score_cpu.c): {nqs} queries x {ns} docs x {H}, top-{args.topk}, {main_shape['threads']} threads, median of 3 runs "
@@ -1468,7 +1564,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "exact_kernel_mode": exact_mode, "breakdown": breakdown, "small_batch": small, "fp32_class_mode": fp32_class, "fast_mode": fast,
             "drop_in": drop_in, "shard_1of8": shard_leg, "filter_robustness": robustness, "encode": encode, "sparse": sparse, "config5_8b": config5,
         }
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
