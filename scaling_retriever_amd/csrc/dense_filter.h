@@ -25,6 +25,9 @@ bool sr_filter_scale_of(float absmax, float* scale, float* inv_scale);
 //   xy[r] = ((|rows_r sd - plane_r| + sigma |rows_r sd|) * 1.001, |plane_r| * 1.001);  *d_bad |= 1 on any non-finite value
 int launch_filter_plane(const float* rows, int64_t n, int H, float sd, double sigma, unsigned short* plane, float* xy, int* d_bad,
                         hipStream_t s);
+// gmax[g] = (max x, max y) over the documents [128 g, 128 g + 128) of xy [n, 2]: what the upper-bound pass tests a whole block of
+// accumulators against before it forms a single per-pair bound (dense_split.hip split_epilogue)
+int launch_filter_group_max(const float* xy, int64_t n, float* gmax, hipStream_t s);
 // fp16 plane of the queries, each scaled by its own power of two sq, and qa[q] = (A', B', sq, 1 / sq):
 //   A' = |q sq| * 1.001, B' = |q sq - plane_q| * 1.001; a query that cannot be filtered (non-finite, out of the scale range)
 //   gets A' = +inf and is re-done by the exact kernel

@@ -153,6 +153,28 @@ int launch_filter_plane(const float* rows, int64_t n, int H, float sd, double si
     return SR_OK;
 }
 
+// one wave per group of 128 documents (2 per lane)
+__global__ __launch_bounds__(256) void filter_group_max_kernel(const float* __restrict__ xy, int64_t n, float* __restrict__ gmax) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 128 >= n) return;
+    float mx = 0.f, my = 0.f;                     // x, y are norms: >= 0
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t r = g * 128 + t * 64 + lane;
+        if (r < n) { mx = fmaxf(mx, xy[r * 2]); my = fmaxf(my, xy[r * 2 + 1]); }
+    }
+    for (int off = 32; off > 0; off >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, off)); my = fmaxf(my, __shfl_xor(my, off)); }
+    if (lane == 0) { gmax[g * 2] = mx; gmax[g * 2 + 1] = my; }
+}
+
+int launch_filter_group_max(const float* xy, int64_t n, float* gmax, hipStream_t s) {
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(filter_group_max_kernel, dim3((unsigned)ceil_div64(ceil_div64(n, 128), 4)), dim3(256), 0, s, xy, n, gmax);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* plane, float* qa, hipStream_t s) {
     if (nq == 0) return SR_OK;
     hipLaunchKernelGGL(filter_plane_kernel<true>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, s, Q, nq, H, 1.0f, 0.0f, plane, qa,

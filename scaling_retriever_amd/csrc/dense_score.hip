@@ -381,7 +381,7 @@ struct DenseSegment {
     // and the per-document error terms (x, y); f_state: 0 = not built, 1 = ready, -1 = cannot be filtered (non-finite or
     // out-of-range values, no memory)
     unsigned short* fpl = nullptr;
-    float* fxy = nullptr;
+    float* fxy = nullptr;               // [n, 2], then [ceil(n / 128), 2]: the maxima of x and of y over every group of 128 documents
     float fsd = 1.f, fisd = 1.f;
     int f_state = 0;
 };
@@ -441,7 +441,7 @@ static int filter_prepare_segment(sr_dense_index* idx, DenseSegment& seg) {
     memcpy(&absmax, &h[0], 4);
     if (h[0] >= 0x7f800000u || !sr_filter_scale_of(absmax, &seg.fsd, &seg.fisd)) return SR_OK;
     const size_t bytes = (size_t)seg.n * (size_t)idx->dim * 2;
-    if (hipMalloc((void**)&seg.fpl, bytes) != hipSuccess || hipMalloc((void**)&seg.fxy, (size_t)seg.n * 8) != hipSuccess) {
+    if (hipMalloc((void**)&seg.fpl, bytes) != hipSuccess || hipMalloc((void**)&seg.fxy, (size_t)(seg.n + ceil_div64(seg.n, 128)) * 8) != hipSuccess) {
         (void)hipGetLastError();
         if (seg.fpl) (void)hipFree(seg.fpl);
         seg.fpl = nullptr; seg.fxy = nullptr;
@@ -449,6 +449,7 @@ static int filter_prepare_segment(sr_dense_index* idx, DenseSegment& seg) {
     }
     SR_TRY(launch_filter_plane(seg.rows, seg.n, idx->dim, seg.fsd, sr_filter_sigma(idx->dim), seg.fpl, seg.fxy,
                                reinterpret_cast<int*>(idx->f_scratch) + 1, nullptr));
+    SR_TRY(launch_filter_group_max(seg.fxy, seg.n, seg.fxy + 2 * seg.n, nullptr));
     SR_CHECK_HIP(hipMemcpy(h, idx->f_scratch, 8, hipMemcpyDeviceToHost));
     if (h[1] != 0) {                          // a non-finite error term: the segment is not filterable, its plane is of no use
         (void)hipFree(seg.fpl); (void)hipFree(seg.fxy);
@@ -646,6 +647,7 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                     a.D[0] = seg.fpl;
                     a.upper_bound = 1;
                     a.dxy = seg.fxy; a.qa = idx->qa; a.sd = seg.fsd; a.isd = seg.fisd;
+                    a.dxy_gmax = seg.fxy + 2 * seg.n;
                 } else if (np == 2) {     // (d plane, q plane), smallest products first
                     a.n_pairs = 3;
                     const int pd[3] = {1, 0, 0}, pq[3] = {0, 1, 0};

@@ -24,6 +24,7 @@ struct DenseSplitArgs {
     int upper_bound;
     const float* dxy;            // [rows, 2]: per document (x, y) of the scaled plane, see filter_plane_kernel
     const float* qa;             // [nq, 4]: per query (A', B', sq, 1 / sq)
+    const float* dxy_gmax;       // [ceil(rows / 128), 2] or null: (max x, max y) per group of 128 documents - the epilogue's block test
     float sd, isd;               // the segment's power-of-two scale and its inverse
     // filled by launch_dense_split: workgroup -> tile mapping (dense_split.hip split_tile_of)
     int xcd_order, grid_qt, grid_dt, grid_bq, grid_bd, grid_nbq, grid_total;

@@ -80,7 +80,7 @@ __device__ __forceinline__ f32x4 split_mma(const mfma_bf16x8& w, const mfma_bf16
 // compared with tau[q] * sq * sd (a power of two: exact); a survivor's key carries U = U' / (sq sd).
 template <bool UB, int NB, int MB>
 __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&acc)[NB][MB], int64_t row0, int q0, int wn, int wm,
-                                               int frow, int fg, const float* xy_s, const float* qa_s, const float* tau_s) {
+                                               int frow, int fg, const float* xy_s, const float* qa_s, const float* tau_s, float gx, float gy) {
 #pragma clang fp contract(off)
     // the workgroup is persistent: without this hipcc hoists the 32 per-register row indices, id offsets and slots of this
     // epilogue out of the tile loop and carries (spills) them through the k-loop
@@ -90,10 +90,16 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
     const uint32_t gid0 = a.id_base + (uint32_t)row0 * a.id_stride;
     if (SR_SPLIT_DIAG_BIT(a, 2)) return;                   // timing only (SR_SPLIT_DIAG): no epilogue at all
     f32x4 qa[MB];
+    // UB, block test: a block of 4 accumulators is first held against tq - e_max, e_max the error term with the largest x and y of
+    // the wave's 128 documents (gx, gy: one scalar load per tile).  e(q, j) <= e_max, so a block without an accumulator at or above
+    // that line has no survivor and its 4 bounds are never formed; the blocks that pass (a handful per wave and tile) get their
+    // bounds, the test against tau and their keys exactly as before.  Two fmas and an LDS read per pair had been the bulk of the
+    // epilogue's instructions.
+    const bool pre = UB && a.dxy_gmax != nullptr;
     if constexpr (UB) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) qa[j] = *reinterpret_cast<const f32x4*>(qa_s + (wm * MB * 16 + j * 16 + frow) * 4);
-        if (!SR_SPLIT_DIAG_BIT(a, 1))                     // timing only (SR_SPLIT_DIAG): plane product without the error term
+        if (!pre && !SR_SPLIT_DIAG_BIT(a, 1))             // timing only (SR_SPLIT_DIAG): plane product without the error term
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const float* p = xy_s + 2 * (wn * NB * 16 + i * 16 + fg * 4);
@@ -137,6 +143,14 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
             out_scale[j] = qa[j][3] * a.isd;
         }
         uint64_t* seg_dst = a.cand_keys + (int64_t)q * a.cand_cap + a.seg_off + (int64_t)seg_idx * SR_SEG_P;
+        // the line of the block test.  Sound in fp32: a pair is kept when fl(A' x + fl(B' y + acc)) >= tq, which implies
+        // acc >= tq - e - 2.0001 u (|acc| + e), u = 2^-24; |acc| <= |q0||d0| (1 + H u) <= e (1 / sigma + 1) wherever the pair is near the
+        // line (dense_filter.hip: x carries sigma |d'|), so 2.0001 u |acc| < 2^-11 e; the line below sits at
+        // tq - e_max (1 + 2^-7) - 2^-22 |tq|, which also covers its own three roundings (<= 3 u (|tq| + 1.01 e_max)).
+        // tq = -inf (no threshold yet): the line is -inf and every block passes; a query that cannot be filtered (A' = inf) passes too.
+        float line = tq[j];
+        if constexpr (UB)
+            if (pre) line = (tq[j] - (qa[j][0] * gx + qa[j][1] * gy) * 1.0078125f) - fabsf(tq[j]) * 2.384185791015625e-07f;
         int n = 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -148,7 +162,16 @@ __device__ __forceinline__ void split_epilogue(const DenseSplitArgs& a, f32x4 (&
                 for (int r = 0; r < 4; ++r)
                     if (lr0 + r < rows_valid) m4 = fmaxf(m4, acc[i][j][r]);
             }
-            if (__ballot(m4 >= tq[j]) == 0) continue;                  // wave-uniform: nobody keeps anything of this block
+            if (__ballot(m4 >= line) == 0) continue;                   // wave-uniform: nobody keeps anything of this block
+            if constexpr (UB)
+                if (pre) {                                             // the block's 4 bounds, in place (the counted path below reads them)
+                    const float* p = xy_s + 2 * lr0;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                    const float x[4] = {v0[0], v0[2], v1[0], v1[2]}, y[4] = {v0[1], v0[3], v1[1], v1[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[i][j][r] = __builtin_fmaf(qa[j][0], x[r], __builtin_fmaf(qa[j][1], y[r], acc[i][j][r]));
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sc = acc[i][j][r];
@@ -243,13 +266,13 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     float* qa_s = xy_s + 2 * SP_BN;                                        // UB: (A', B', sq, 1 / sq) of the tile's 256 queries
     float* tau_s = qa_s + 4 * SP_BM;                                       // tau of the tile's 256 queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave / WAVES_M, wm = wave % WAVES_M;
     const int G = (int)gridDim.x;
     const int H = a.H;
 
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ (srow & 7);
-    int doff[4], qoff[4];          // element offsets inside the tile's row block (the block's base is wave-uniform)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // scalar: the LDS-DMA destinations (m0) need no vector arithmetic
+    const int wn = wave_s / WAVES_M, wm = wave_s % WAVES_M;       // scalar as well: the epilogue's row / query bases, the group of gx, gy
+    uint32_t doff[4], qoff[4];     // BYTE offsets inside the tile's row block: the block's base is wave-uniform, so a piece's address is
+                                   // scalar base + 32-bit lane offset (the saddr form of global_load_lds: no 64-bit vector add per piece)
     int64_t st_dbase = 0, st_qbase = 0;
     // k-tiles are staged strictly in order (0, 1, 2, ...), so the plane pair of the NEXT tile is tracked incrementally:
     // the plane pointers change once per H / 64 tiles.  (Looking them up per tile - a division, then two dependent
@@ -273,26 +296,37 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         st_qbase = (int64_t)st_q0 * H;
         const int64_t dleft = a.row_end - 1 - st_row0;
         const int dmax = dleft < SP_BN - 1 ? (int)dleft : SP_BN - 1, qmax = a.nq - 1 - st_q0 < SP_BM - 1 ? a.nq - 1 - st_q0 : SP_BM - 1;
+        // the workgroup is persistent and the k-loop leaves no register free: whatever is derived from the lane index alone is invariant in
+        // the tile loop, gets hoisted above it and is then SPILLED through it - the tile prologue had become a chain of scratch loads,
+        // each waited for on its own.  So the lane index is made opaque wherever a tile's set-up needs it: recomputing costs 2-3 VALU.
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int srow = lane_o >> 3;
+        const int schunk = (lane_o & 7) ^ (srow & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + srow;
-            doff[i] = (r < dmax ? r : dmax) * H + schunk * 8;
-            qoff[i] = (r < qmax ? r : qmax) * H + schunk * 8;
+            const int r = (wave_s * 4 + i) * 8 + srow;
+            doff[i] = (uint32_t)((r < dmax ? r : dmax) * H + schunk * 8) * 2u;
+            qoff[i] = (uint32_t)((r < qmax ? r : qmax) * H + schunk * 8) * 2u;
         }
         st_pair = 0; st_k0 = 0;
         st_d = a.D[a.pair_d[0]];
         st_q = a.Q[a.pair_q[0]];
     };
-    auto stage = [&](int st) {          // the next k-tile in order
-        unsigned char* wbase = smem + st * STAGE_BYTES + (wave * 4) * 1024;
-        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave * 4) * 1024;
+    auto stage_pieces = [&](int st) {   // the 8 pieces of the next k-tile in order; no branch: the steady-state k-step stays ONE scheduling region
+        unsigned char* wbase = smem + st * STAGE_BYTES + (wave_s * 4) * 1024;
+        unsigned char* abase = smem + st * STAGE_BYTES + W_BYTES + (wave_s * 4) * 1024;
+        const unsigned char* dsrc = reinterpret_cast<const unsigned char*>(st_d + (st_dbase + st_k0));
+        const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(st_q + (st_qbase + st_k0));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_d + (st_dbase + st_k0) + doff[i]), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(dsrc + doff[i]), (lds_void_ptr)(wbase + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(st_q + (st_qbase + st_k0) + qoff[i]), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(qsrc + qoff[i]), (lds_void_ptr)(abase + i * 1024), 16, 0, 0);
         st_k0 += 64;
+    };
+    auto stage_wrap = [&]() {           // the end of a plane: on to the next plane pair
         if (st_k0 == H) {
             st_k0 = 0;
             ++st_pair;
@@ -301,6 +335,10 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
                 st_q = a.Q[a.pair_q[st_pair]];
             }
         }
+    };
+    auto stage = [&](int st) {
+        stage_pieces(st);
+        stage_wrap();
     };
 
     const int frow = lane & 15, fg = lane >> 4;
@@ -337,6 +375,13 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         const int q0 = st_q0;
         const int tile_next = next_slot(tile + G);
         const bool has_next = tile_next < a.grid_total;
+        float gx = 0.f, gy = 0.f;           // UB: the largest x and y among the wave's 128 documents (a scalar load, under the k-loop)
+        if constexpr (UB)
+            if (a.dxy_gmax) {
+                const float* gm = a.dxy_gmax + 2 * ((row0 >> 7) + wn);
+                gx = gm[0];
+                gy = gm[1];
+            }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -346,22 +391,24 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned long long st0 = SR_SPLIT_STAMPS_PTR(a) ? __builtin_amdgcn_s_memrealtime() : 0;
-        if (wave >= 4) {      // tau of the tile's queries: one 4-byte LDS-DMA piece per lane of waves 4-7 (no wait in the epilogue)
-            int q = q0 + (wave - 4) * 64 + lane;
+        int lane_t = lane;            // opaque: see set_tile
+        asm volatile("" : "+v"(lane_t));
+        if (wave_s >= 4) {    // tau of the tile's queries: one 4-byte LDS-DMA piece per lane of waves 4-7 (no wait in the epilogue)
+            int q = q0 + (wave_s - 4) * 64 + lane_t;
             q = q < a.nq ? q : a.nq - 1;
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.tau + q), (lds_void_ptr)(tau_s + (wave - 4) * 64), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.tau + q), (lds_void_ptr)(tau_s + (wave_s - 4) * 64), 4, 0, 0);
         }
         if constexpr (UB) {
             // the tile's per-document (x, y): 512 floats, 64 per wave, one 4-byte LDS-DMA piece per lane, and its per-query
             // constants: 256 x 16 bytes, one 16-byte piece per lane of waves 0-3; they land under the k-loop (every k-step
             // drains vmcnt before its barrier) and cost no register there
-            int64_t r = row0 + wave * 32 + (lane >> 1);
+            int64_t r = row0 + wave_s * 32 + (lane_t >> 1);
             r = r < a.row_end ? r : a.row_end - 1;
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.dxy + r * 2 + (lane & 1)), (lds_void_ptr)(xy_s + wave * 64), 4, 0, 0);
-            if (wave < 4) {
-                int q = q0 + wave * 64 + lane;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.dxy + r * 2 + (lane_t & 1)), (lds_void_ptr)(xy_s + wave_s * 64), 4, 0, 0);
+            if (wave_s < 4) {
+                int q = q0 + wave_s * 64 + lane_t;
                 q = q < a.nq ? q : a.nq - 1;
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.qa + (int64_t)q * 4), (lds_void_ptr)(qa_s + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.qa + (int64_t)q * 4), (lds_void_ptr)(qa_s + wave_s * 256), 16, 0, 0);
             }
         }
         load_w(buf, 0, 0, wx);
@@ -369,7 +416,14 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         int kt = 0;
         // steady state with the issue order pinned (see gemm_bf16.hip): reads and LDS-DMA pieces dealt out one per MFMA
 #define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
-        for (; kt + 2 < nkt; ++kt) {
+        // The plane-pair switch of the staged stream used to be a branch inside stage(): it split the k-step's last phase into blocks,
+        // and that phase's 16 MFMAs were issued in a clump BEHIND the 8 LDS-DMA pieces and their address arithmetic instead of
+        // between them.  The steady state now runs in stretches that stay inside one plane (the whole tile for the filter's pass).
+        while (kt + 2 < nkt) {
+        const int in_plane = (H - st_k0) >> 6, to_go = nkt - 2 - kt;
+        const int stretch = in_plane < to_go ? in_plane : to_go;          // >= 1: st_k0 < H after every stage_wrap()
+#pragma unroll 1
+        for (int it = 0; it < stretch; ++it, ++kt) {
             load_w(buf, 0, 1, wy);
             load_a(buf, 1, a1);
             SR_MFMA_HALF(0, wx, a0)
@@ -393,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             __syncthreads();
             load_w(buf ^ 1, 0, 0, wx);
             load_a(buf ^ 1, 0, a0);
-            stage(buf);
+            stage_pieces(buf);
             SR_MFMA_HALF(1, wy, a1)
 #pragma unroll
             for (int i = 0; i < HB + MB; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x100, 1, 3); }
@@ -401,6 +455,8 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             for (int i = 0; i < 8; ++i) { SR_SGB(0x008, 1, 3); SR_SGB(0x010, 1, 3); }
             __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
+        }
+        stage_wrap();
         }
 #undef SR_SGB
         for (; kt < nkt; ++kt) {     // last two k-steps: 4 phases per k-step, see gemm_bf16.hip
@@ -429,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             buf ^= 1;
         }
         const unsigned long long st1 = SR_SPLIT_STAMPS_PTR(a) ? __builtin_amdgcn_s_memrealtime() : 0;
-        split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s, tau_s);
+        split_epilogue<UB, NB, MB>(a, acc, row0, q0, wn, wm, frow, fg, xy_s, qa_s, tau_s, gx, gy);
         if (SR_SPLIT_STAMPS_PTR(a)) {          // dev switch SR_SPLIT_STAMPS: 10 ns ticks per tile of wave 0: k-loop, epilogue issue, wait at the next tile's top
             const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,6 +520,8 @@ int launch_dense_split(const DenseSplitArgs& a, hipStream_t s) {
         *attr_slot = true;
     }
     DenseSplitArgs b = a;
+    if (const char* e = sr_dev_getenv("SR_SPLIT_BLOCKTEST")) if (atoi(e) == 0) b.dxy_gmax = nullptr;     // A/B switch: every bound formed
+    SR_REQUIRE(!b.dxy_gmax || a.row_begin % SP_BN == 0, "dense_split: the block test needs launches that start on a tile boundary");
     b.xcd_order = 1;
     if (const char* e = sr_dev_getenv("SR_SPLIT_XCD")) b.xcd_order = atoi(e);     // A/B switch
     b.diag = 0;
