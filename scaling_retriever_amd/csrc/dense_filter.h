@@ -28,6 +28,16 @@ int launch_filter_plane(const float* rows, int64_t n, int H, float sd, double si
 // gmax[g] = (max x, max y) over the documents [128 g, 128 g + 128) of xy [n, 2]: what the upper-bound pass tests a whole block of
 // accumulators against before it forms a single per-pair bound (dense_split.hip split_epilogue)
 int launch_filter_group_max(const float* xy, int64_t n, float* gmax, hipStream_t s);
+// The second threshold of the upper-bound pass.  The k documents with the largest upper bounds seen so far have exact scores
+// S >= U - 2 e >= U_(k) - 2 e_max(q), so a document whose U lies below  t2 = U_(k) - 2 e_max(q)  cannot enter the top-k or tie with its
+// last member - whatever the kp-th largest U is.  e_max(q) = max over the segments of (A' X_max + B' Y_max) / (sq sd), the error term
+// with the largest x and y of the segment.  On data whose scores are not bunched at the k-th one this is a far tighter filter than the
+// kp-th largest U (kp = 3 k keeps room for the certificate), and every pair it drops is one the epilogue does not turn into a key.
+//   slack[q] = 2 e_max(q) (1 + 2^-9) (rounded up by construction);  tau2[q] := -inf
+struct FilterSegMax { float x[SR_FILTER_MAX_SEGS], y[SR_FILTER_MAX_SEGS], isd[SR_FILTER_MAX_SEGS]; int count; };
+int launch_filter_slack(const float* qa, int64_t nq, const FilterSegMax& m, float* slack, float* tau2, hipStream_t s);
+//   tau_eff[q] = max(tau[q], tau2[q] - slack[q] - 2^-22 |tau2[q]|)      (tau: the kp-th largest U so far, tau2: the k-th, both -inf at first)
+int launch_filter_tau(const float* tau, const float* tau2, const float* slack, float* tau_eff, int64_t nq, hipStream_t s);
 // fp16 plane of the queries, each scaled by its own power of two sq, and qa[q] = (A', B', sq, 1 / sq):
 //   A' = |q sq| * 1.001, B' = |q sq - plane_q| * 1.001; a query that cannot be filtered (non-finite, out of the scale range)
 //   gets A' = +inf and is re-done by the exact kernel

@@ -175,6 +175,44 @@ int launch_filter_group_max(const float* xy, int64_t n, float* gmax, hipStream_t
     return SR_OK;
 }
 
+__global__ void filter_slack_kernel(const float* __restrict__ qa, int64_t nq, FilterSegMax m, float* __restrict__ slack, float* __restrict__ tau2) {
+#pragma clang fp contract(off)
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float A = qa[q * 4], B = qa[q * 4 + 1], isq = qa[q * 4 + 3];
+    float e = 0.f;
+    for (int i = 0; i < m.count; ++i) {
+        const float v = (A * m.x[i] + B * m.y[i]) * m.isd[i];      // isd, isq: powers of two
+        e = v > e || !(v == v) ? v : e;                           // a NaN (inf * 0) sticks: the threshold is then never used
+    }
+    slack[q] = 2.f * (e * isq) * 1.001953125f;                    // (1 + 2^-9): over the three roundings of e and of the subtraction
+    tau2[q] = -INFINITY;
+}
+
+int launch_filter_slack(const float* qa, int64_t nq, const FilterSegMax& m, float* slack, float* tau2, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    hipLaunchKernelGGL(filter_slack_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, qa, nq, m, slack, tau2);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
+__global__ void filter_tau_kernel(const float* __restrict__ tau, const float* __restrict__ tau2, const float* __restrict__ slack,
+                                  float* __restrict__ tau_eff, int64_t nq) {
+#pragma clang fp contract(off)
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float t = tau[q], u = tau2[q];
+    const float t2 = (u - slack[q]) - fabsf(u) * 2.384185791015625e-07f;      // -inf while fewer than k keys were seen; NaN never wins below
+    tau_eff[q] = t2 > t ? t2 : t;
+}
+
+int launch_filter_tau(const float* tau, const float* tau2, const float* slack, float* tau_eff, int64_t nq, hipStream_t s) {
+    if (nq == 0) return SR_OK;
+    hipLaunchKernelGGL(filter_tau_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, s, tau, tau2, slack, tau_eff, nq);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+}
+
 int launch_filter_queries(const float* Q, int64_t nq, int H, unsigned short* plane, float* qa, hipStream_t s) {
     if (nq == 0) return SR_OK;
     hipLaunchKernelGGL(filter_plane_kernel<true>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, s, Q, nq, H, 1.0f, 0.0f, plane, qa,

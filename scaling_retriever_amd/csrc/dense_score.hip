@@ -383,6 +383,7 @@ struct DenseSegment {
     unsigned short* fpl = nullptr;
     float* fxy = nullptr;               // [n, 2], then [ceil(n / 128), 2]: the maxima of x and of y over every group of 128 documents
     float fsd = 1.f, fisd = 1.f;
+    float fx_max = 0.f, fy_max = 0.f;   // the largest x and y of the segment (scaled domain): the second threshold's e_max (dense_filter.h)
     int f_state = 0;
 };
 
@@ -404,7 +405,7 @@ struct sr_dense_index {
                                       // its own, so an index that alternates pass kinds does not free and re-allocate GBs per search
     TopkWS ws2;                       // exact top-k over the re-scored candidates
     TopkWS ws3;                       // exact re-do of the queries without a certificate
-    float* qa = nullptr;              // [fq_cap, 4] per query (A', B', sq, 1 / sq)
+    float* qa = nullptr;              // [fq_cap, 4] per query (A', B', sq, 1 / sq), then 3 x [fq_cap]: slack, tau2, tau_eff (dense_filter.h)
     float* a_scores = nullptr;        // [fq_cap, fkp] the kp largest upper bounds U, sorted
     int64_t* a_ids = nullptr;
     int* flags = nullptr;             // [2 fq_cap + 2]: per-query flags, then the xmin scratch of the re-score
@@ -451,6 +452,15 @@ static int filter_prepare_segment(sr_dense_index* idx, DenseSegment& seg) {
                                reinterpret_cast<int*>(idx->f_scratch) + 1, nullptr));
     SR_TRY(launch_filter_group_max(seg.fxy, seg.n, seg.fxy + 2 * seg.n, nullptr));
     SR_CHECK_HIP(hipMemcpy(h, idx->f_scratch, 8, hipMemcpyDeviceToHost));
+    {
+        std::vector<float> gm((size_t)ceil_div64(seg.n, 128) * 2);
+        SR_CHECK_HIP(hipMemcpy(gm.data(), seg.fxy + 2 * seg.n, gm.size() * 4, hipMemcpyDeviceToHost));
+        seg.fx_max = seg.fy_max = 0.f;
+        for (size_t g = 0; g < gm.size(); g += 2) {
+            seg.fx_max = gm[g] > seg.fx_max ? gm[g] : seg.fx_max;
+            seg.fy_max = gm[g + 1] > seg.fy_max ? gm[g + 1] : seg.fy_max;
+        }
+    }
     if (h[1] != 0) {                          // a non-finite error term: the segment is not filterable, its plane is of no use
         (void)hipFree(seg.fpl); (void)hipFree(seg.fxy);
         seg.fpl = nullptr; seg.fxy = nullptr;
@@ -583,7 +593,7 @@ extern "C" int sr_dense_index_set_precision(sr_dense_index* idx, int mode) {
 
 // one pass in the given arithmetic (SR_PRECISION_FP32 | _BF16X3 | _BF16X6); caller holds idx->mu
 static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_t nq, int k, float* d_out_scores,
-                             int64_t* d_out_ids, int precision, hipStream_t s, bool force_tiled = false) {
+                             int64_t* d_out_ids, int precision, hipStream_t s, bool force_tiled = false, int k_inner = 0) {
     const bool pass16 = (planes_of(precision) || precision == SR_PASS_FILTER) && nq > 64;
     // the re-do of a few queries and the 16-bit passes keep their own (differently shaped) workspaces
     TopkWS& ws = force_tiled ? idx->ws3 : (pass16 ? idx->wsf : idx->ws);
@@ -605,7 +615,9 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
     while (t) { const int64_t r = g % t; g = t; t = r; }     // g = gcd(256, qtiles)
     const int64_t unit = 256 / g;
     const char* env_wgs = sr_dev_getenv("SR_DENSE_LAUNCH_WGS");      // A/B switch: workgroups per launch (default 2048)
-    const int64_t launch_wgs = env_wgs ? atoll(env_wgs) : 2048;
+    // the 16-bit passes take twice the docs per launch (28 rounds of tiles instead of 14 at 6 980 queries): half the launch ramps and
+    // compactions, 0.7606 -> 0.7417 ms per 14 rounds, search -2 % (same results; tools/split_ab.py SR_DENSE_LAUNCH_WGS=...)
+    const int64_t launch_wgs = env_wgs ? atoll(env_wgs) : (pass16 ? 7168 : 2048);
     int64_t chunk = TM * unit * ceil_div64(launch_wgs, unit * qtiles);
     int64_t max_cap = idx->ws_limit / (8 * nq);
     max_cap = (max_cap / TM) * TM;
@@ -623,8 +635,22 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
             for (int p = 0; p < 3; ++p) SR_CHECK_HIP(hipMalloc((void**)&idx->qpl[p], (size_t)nq * idx->dim * 2));
             idx->q_cap = nq;
         }
+        // the filter's second threshold (dense_filter.h): k_inner = the k of the search, `k` here = kp candidates
+        bool two = np == 0 && k_inner > 0 && k_inner < k;
+        if (const char* e = sr_dev_getenv("SR_FILTER_TAU2")) two = two && atoi(e) != 0;                  // A/B switch
+        // with the second threshold the running set is cut back (and both thresholds refreshed) once it holds k + 1 024 keys instead of 2 k:
+        // fresher thresholds save more in the pass than the extra selects cost (search 229.3 -> 224.4 ms at the MSMARCO shape)
+        int select_over = two ? k + 1024 : 2 * k;
+        if (const char* e = sr_dev_getenv("SR_FILTER_SELECT_OVER")) select_over = atoi(e);              // A/B switch
+        float* f_slack = idx->qa + 4 * idx->fq_cap, *f_tau2 = f_slack + idx->fq_cap, *f_tau_eff = f_tau2 + idx->fq_cap;
         if (np == 0) SR_TRY(launch_filter_queries(d_queries, nq, idx->dim, idx->qpl[0], idx->qa, s));     // idx->qa: dense_search_filtered
         else SR_TRY(launch_split_bf16(d_queries, idx->qpl[0], idx->qpl[1], idx->qpl[2], nq * (int64_t)idx->dim, s));
+        if (two) {
+            FilterSegMax fm;
+            fm.count = (int)idx->segs.size();
+            for (int i = 0; i < fm.count; ++i) { fm.x[i] = idx->segs[i].fx_max; fm.y[i] = idx->segs[i].fy_max; fm.isd[i] = idx->segs[i].fisd; }
+            SR_TRY(launch_filter_slack(idx->qa, nq, fm, f_slack, f_tau2, s));
+        }
         // segmented candidate slots: one segment per (256-doc tile of a launch, producer lane group), see common.h
         bool use_seg = true;
         if (const char* e = sr_dev_getenv("SR_SPLIT_SEG")) use_seg = atoi(e) != 0;       // A/B switch: 0 = atomic appends only
@@ -634,6 +660,7 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
         int64_t step = ceil_div64((int64_t)k + 1024, TM) * TM;   // short first launches, see below
         if (step < TM * ceil_div64(256, qtiles)) step = TM * ceil_div64(256, qtiles);
         if (step > chunk) step = chunk;
+        bool first_launch = true;
         for (const DenseSegment& seg : idx->segs) {
             for (int64_t r0 = 0; r0 < seg.n;) {
                 const int64_t r1 = r0 + step < seg.n ? r0 + step : seg.n;
@@ -658,13 +685,20 @@ static int dense_search_pass(sr_dense_index* idx, const float* d_queries, int64_
                     for (int i = 0; i < 6; ++i) { a.pair_d[i] = pd[i]; a.pair_q[i] = pq[i]; }
                 }
                 a.row_begin = r0; a.row_end = r1; a.H = idx->dim; a.nq = (int)nq;
-                a.tau = ws.tau; a.cand_keys = ws.cand_keys; a.cand_count = ws.cand_count;
+                a.tau = two ? f_tau_eff : ws.tau; a.cand_keys = ws.cand_keys; a.cand_count = ws.cand_count;
                 a.cand_cap = ws.cand_cap; a.id_base = (uint32_t)seg.id_base; a.id_stride = (uint32_t)seg.id_stride;
                 a.seg_cnt = ws.seg_n > 0 ? ws.seg_cnt : nullptr; a.seg_n = ws.seg_n; a.seg_off = ws.seg_off;
+                if (two && first_launch) SR_TRY(launch_filter_tau(ws.tau, f_tau2, f_slack, f_tau_eff, nq, s));    // both -inf
+                first_launch = false;
                 idx->prof.begin(s);
                 SR_TRY(launch_dense_split(a, s));
                 idx->prof.end(s, 2.0 * (double)nq * (double)(r1 - r0) * idx->dim, (double)(r1 - r0) * idx->dim * 4.0);
-                SR_TRY(topk_compact(ws, nq, k, s));
+                if (two) {
+                    SR_TRY(topk_compact2(ws, nq, k, k_inner, f_tau2, select_over, s));
+                    SR_TRY(launch_filter_tau(ws.tau, f_tau2, f_slack, f_tau_eff, nq, s));
+                } else {
+                    SR_TRY(topk_compact(ws, nq, k, s));
+                }
                 r0 = r0_next;
             }
         }
@@ -782,7 +816,7 @@ static int dense_filtered_candidates(sr_dense_index* idx, const float* d_queries
         F(idx->qa); F(idx->a_scores); F(idx->a_ids); F(idx->flags);
         idx->qa = nullptr; idx->a_scores = nullptr; idx->a_ids = nullptr; idx->flags = nullptr;
         idx->fq_cap = 0;
-        if (hipMalloc((void**)&idx->qa, (size_t)nq * 16) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
+        if (hipMalloc((void**)&idx->qa, (size_t)nq * 28) != hipSuccess || hipMalloc((void**)&idx->a_scores, (size_t)nq * kp * 4) != hipSuccess ||
             hipMalloc((void**)&idx->a_ids, (size_t)nq * kp * 8) != hipSuccess || hipMalloc((void**)&idx->flags, (size_t)(2 * nq + 2) * 4) != hipSuccess) {
             (void)hipGetLastError();
             return SR_OK;                                     // no room for the candidate lists: exact kernel
@@ -792,7 +826,7 @@ static int dense_filtered_candidates(sr_dense_index* idx, const float* d_queries
     }
     SR_CHECK_HIP(hipMemsetAsync(idx->flags, 0, (size_t)nq * 4, s));
     // 1. the kp documents with the largest upper bounds U (the query planes and constants are made by the pass)
-    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s));
+    SR_TRY(dense_search_pass(idx, d_queries, nq, kp, idx->a_scores, idx->a_ids, SR_PASS_FILTER, s, false, k));
     *done = true;
     return SR_OK;
 }

@@ -240,3 +240,39 @@ def test_filtered_with_tiny_norm_rows_next_to_a_large_absmax():
     # the same rows as a segment of their own get their own scale: still exact
     (es2, ei2), (fs2, fi2), _ = _both([D[:6000], D[6000:12000], D[12000:]], Q, k)
     assert torch.equal(fi2, ei2) and torch.equal(fs2, es2) and torch.equal(es2, es) and torch.equal(ei2, ei)
+
+
+def test_second_threshold_mixed_norm_segments(monkeypatch):
+    """The upper-bound pass drops a pair when its bound lies under the kp-th largest bound so far OR under U_(k) - 2 e_max(q), the k-th
+    largest bound less twice the largest error term any document of the index can have (dense_filter.h).  Segments of very different
+    norms (e_max comes from the large one, the scores that matter partly from the small one), documents of zero norm, near-ties at the
+    cut and k close to N: the result equals the exact kernel's bit for bit, with the second threshold (default) and without it."""
+    from scaling_retriever_amd.scoring import DenseIndexHIP
+    rng = np.random.default_rng(11)
+    H, nq = 256, 160
+    small = (rng.standard_normal((40000, H), dtype=np.float32) * 1e-3).astype(np.float32)
+    large = rng.standard_normal((25000, H), dtype=np.float32)
+    large[::7] *= np.float32(30.0)                                   # a few documents carry the segment's largest x and y
+    large[5:2000:5] = 0
+    mid = (rng.standard_normal((9000, H), dtype=np.float32) * 0.05).astype(np.float32)
+    Q = rng.standard_normal((nq, H), dtype=np.float32)
+    Q[1] = -large[7] / np.float32(30.0)                              # the big documents at the BOTTOM of this query's ranking
+    Q[2] = small[11] * np.float32(1e3)
+    for j in range(300):                                             # near-ties around rank k in the small segment
+        small[20000 + j] = small[11] * np.float32(1.0 - 1e-6 * j)
+    parts = [small, large, mid]
+    for k in (10, 1000, 3000):
+        exact = DenseIndexHIP(H)
+        for p_ in parts:
+            exact.add_host_rows(p_)
+        es, ei = exact.search(torch.from_numpy(Q).cuda(), k)
+        for on in ("1", "0"):
+            monkeypatch.setenv("SR_DEV_SWITCHES", "1")
+            monkeypatch.setenv("SR_FILTER_TAU2", on)
+            filt = DenseIndexHIP(H)
+            filt.set_precision("fp32_filtered")
+            for p_ in parts:
+                filt.add_host_rows(p_)
+            fs, fi = filt.search(torch.from_numpy(Q).cuda(), k)
+            assert torch.equal(fi, ei) and torch.equal(fs, es), (k, on)
+            assert sum(filt.filter_stats()) == 1

@@ -74,9 +74,13 @@ def test_bench_multi_rank_path_dry_run():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
     assert res["config"]["ranks"]["world_size"] == 2 and len(res["config"]["ranks"]["shard_docs"]) == 2
-    assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
-    assert res["fast_mode"]["value"] > 0 and res["small_batch"][0]["nq"] == 1
-    assert res["encode"]["value"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
+    assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1 and res["cpu_baseline"] is None
+    assert res["small_batch"][0]["nq"] == 1
+    assert res["encode"]["passages_per_s"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
+    assert len(line) < 4096 and out.stdout.rstrip().endswith(line)             # the contract line is the LAST line of stdout, and compact
+    # the full record goes to stderr (and to gpurun_out/bench_detail.json)
+    detail = json.loads([l for l in out.stderr.splitlines() if l.startswith("[bench detail] ")][-1][len("[bench detail] "):])
+    assert detail["fast_mode"]["value"] > 0 and detail["value"] == res["value"] and detail["config"]["ranks"] == res["config"]["ranks"]
 
 
 @pytest.mark.parametrize("W", [2, 8])
