@@ -20,6 +20,14 @@ What is pinned:
                   decorators stripped (numba is not installed).
   * plan_files.npz    obtain_doc_vec_dir_files ordering
                   (scaling_retriever/utils/utils.py:26-43).
+  * index_build.npz   SparseIndexer.index (scaling_retriever/indexer.py:239-308) over
+                  IndexDictOfArray.add_batch_document / save
+                  (scaling_retriever/utils/inverted_index.py:67-105) and merge_indexes
+                  (:108-170), imported and RUN (stubs: h5py -> tests/h5py_double.py,
+                  ujson -> json, faiss / numba -> empty modules; torch.distributed's rank
+                  and world size patched) with a fake model that emits fixed [B, V] reps,
+                  all-zero rows included, at world sizes 1 and 2: the per-term posting
+                  arrays, doc_ids, nb_docs(), L0_d and the merged index are recorded.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -250,9 +258,139 @@ def gen_plan_files():
     print("plan_files ok")
 
 
+def _install_index_stubs():
+    """What scaling_retriever.indexer / utils.inverted_index import beyond _install_stubs(): h5py (the test double), faiss and
+    numba (never called here: decorators pass functions through)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import h5py_double
+    if not hasattr(h5py_double.File, "close"):
+        h5py_double.File.close = lambda self: None                  # the reference closes its files by hand (:41, :100)
+    h5 = types.ModuleType("h5py")
+    h5.File = h5py_double.File
+    sys.modules["h5py"] = h5
+    sys.modules["faiss"] = types.ModuleType("faiss")
+    nb = types.ModuleType("numba")
+    nb.__path__ = []                                                # a package: `from numba.typed import Dict` (indexer.py:15)
+    nb.njit = lambda *a, **k: (lambda f: f)
+    nb.prange = range
+    nb.typed = types.ModuleType("numba.typed")
+    nb.typed.Dict = dict
+    nb.types = types.ModuleType("numba.types")
+    sys.modules["numba"], sys.modules["numba.typed"], sys.modules["numba.types"] = nb, nb.typed, nb.types
+
+
+class _OnAnyDevice:
+    """A batch value the reference can `.to(device)` on a box without a GPU (its device is the integer rank, indexer.py:233-235)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def to(self, *a, **k):
+        return self
+
+
+class _FixedReps(torch.nn.Module):
+    """encode(rows=...) -> the given rows of a fixed [n_docs, V] fp32 matrix (what LlamaBiSparse.encode returns, llm_encoder.py:186-196)."""
+
+    def __init__(self, reps):
+        super().__init__()
+        self.reps = reps
+
+    def to(self, *a, **k):
+        return self
+
+    def encode(self, rows):
+        return self.reps[rows.t]
+
+
+def gen_index_build():
+    _install_index_stubs()
+    import pickle
+    import torch.distributed as dist
+    from scaling_retriever import indexer as ref_indexer
+    from scaling_retriever.utils import inverted_index as ref_inv
+    rng = np.random.default_rng(17)
+    V, N, B = 37, 23, 5                                   # ragged last batch (23 = 4 * 5 + 3)
+    reps = np.zeros((N, V), dtype=np.float32)
+    for d in range(N):
+        nz = rng.choice(V, size=int(rng.integers(1, 9)), replace=False)
+        reps[d, nz] = np.log1p(rng.uniform(0, 20, size=len(nz))).astype(np.float32)
+    reps[[3, 4, 11, 22]] = 0                              # documents without a posting (indexer.py:271-283), one of them the very last
+    reps[:, [0, 5]] = 0                                   # terms without a posting
+    pids = [f"p{100 + 3 * d}" for d in range(N)]          # string ids, as dataset.py:25-26 keeps them
+    out = {"V": V, "N": N, "B": B, "reps": reps, "pids": np.array(pids)}
+    real_rank, real_ws = dist.get_rank, dist.get_world_size
+    with tempfile.TemporaryDirectory() as tmp:
+        for W in (1, 2):
+            for rank in range(W):
+                dist.get_rank, dist.get_world_size = (lambda r=rank: r), (lambda w=W: w)
+                mine = list(range(rank, N, W))            # DistributedSampler(shuffle=False) without its wrap-around pad (eval_sparse.py:96)
+                loader = [{"ids": [pids[d] for d in mine[b0:b0 + B]], "rows": _OnAnyDevice(torch.tensor(mine[b0:b0 + B]))}
+                          for b0 in range(0, len(mine), B)]
+                idx_dir = os.path.join(tmp, f"W{W}", f"index_{rank}")
+                ix = ref_indexer.SparseIndexer(_FixedReps(torch.from_numpy(reps)), idx_dir, device=rank, compute_stats=True, dim_voc=V,
+                                               force_new=True)
+                ix.index(loader)
+                tag = f"W{W}r{rank}"
+                si = ix.sparse_index
+                terms = sorted(int(t) for t in si.index_doc_id.keys())
+                lens = [len(si.index_doc_id[t]) for t in terms]
+                out[f"{tag}:terms"] = np.array(terms, dtype=np.int64)
+                out[f"{tag}:lens"] = np.array(lens, dtype=np.int64)
+                out[f"{tag}:doc_id"] = np.concatenate([np.asarray(si.index_doc_id[t], dtype=np.int32) for t in terms])
+                out[f"{tag}:value"] = np.concatenate([np.asarray(si.index_doc_value[t], dtype=np.float32) for t in terms])
+                out[f"{tag}:nb_docs"] = si.nb_docs()
+                doc_ids = pickle.load(open(os.path.join(idx_dir, "doc_ids.pkl"), "rb"))
+                out[f"{tag}:doc_ids_keys"] = np.array(list(doc_ids.keys()), dtype=np.int64)       # insertion order
+                out[f"{tag}:doc_ids_vals"] = np.array(list(doc_ids.values()))
+                out[f"{tag}:L0_d"] = np.float64(json.load(open(os.path.join(idx_dir, "index_stats.json")))["L0_d"])
+                dist_ = json.load(open(os.path.join(idx_dir, "index_dist.json")))
+                assert {int(k): v for k, v in dist_.items()} == dict(zip(terms, lens))
+                # what a reader of the saved file sees (inverted_index.py:22-55): n = len(doc_ids) for a list, max key + 1 for a dict
+                try:
+                    out[f"{tag}:nb_docs_reloaded"] = ref_inv.IndexDictOfArray(idx_dir, dim_voc=V).nb_docs()
+                except AssertionError:                    # a shard of rank >= 1 alone: its smallest key is not 0 (:54) - only merged indexes reload
+                    out[f"{tag}:nb_docs_reloaded"] = -1
+        dist.get_rank, dist.get_world_size = real_rank, real_ws
+        # merge_indexes over the two rank directories (inverted_index.py:108-170); it walks os.listdir order, so both orders are recorded
+        model_dir = os.path.join(tmp, "model")
+        os.makedirs(model_dir)
+        json.dump({"vocab_size": V}, open(os.path.join(model_dir, "config.json"), "w"))
+        real_listdir = os.listdir
+        for order in ("01", "10"):
+            names = [f"index_{c}" for c in order]
+            ref_inv.os.listdir = lambda p, names=names: list(names)
+            try:
+                ref_inv.merge_indexes(model_dir, index_name="index", index_dir=os.path.join(tmp, "W2"))
+            finally:
+                ref_inv.os.listdir = real_listdir
+            mdir = os.path.join(tmp, "W2", "index")
+            m = ref_inv.IndexDictOfArray(mdir, dim_voc=V)
+            tag = f"merge{order}"
+            out[f"{tag}:lens"] = np.array([len(m.index_doc_id[t]) for t in range(V)], dtype=np.int64)
+            out[f"{tag}:doc_id"] = np.concatenate([m.index_doc_id[t] for t in range(V)]).astype(np.int32)
+            out[f"{tag}:value"] = np.concatenate([m.index_doc_value[t] for t in range(V)]).astype(np.float32)
+            out[f"{tag}:nb_docs"] = m.nb_docs()
+            md = pickle.load(open(os.path.join(mdir, "doc_ids.pkl"), "rb"))
+            out[f"{tag}:doc_ids_keys"] = np.array(list(md.keys()), dtype=np.int64)
+            out[f"{tag}:doc_ids_vals"] = np.array(list(md.values()))
+            out[f"{tag}:L0_d"] = np.float64(json.load(open(os.path.join(mdir, "index_stats.json")))["L0_d"])
+            for f_ in os.listdir(mdir):
+                os.remove(os.path.join(mdir, f_))
+            os.rmdir(mdir)
+    np.savez_compressed(os.path.join(OUT, "index_build.npz"), **out)
+    print("index_build: V", V, "N", N, "postings W1", len(out["W1r0:doc_id"]), "nb_docs W1", out["W1r0:nb_docs"],
+          "W2", out["W2r0:nb_docs"], out["W2r1:nb_docs"], "reloaded", out["W2r0:nb_docs_reloaded"], out["W2r1:nb_docs_reloaded"],
+          "merged", out["merge01:nb_docs"])
+
+
 if __name__ == "__main__":
     _install_stubs()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["index_build"]:                   # one fixture only
+        gen_index_build()
+        sys.exit(0)
     gen_encoder()
     gen_sparse_score()
     gen_plan_files()
+    gen_index_build()

@@ -1,0 +1,175 @@
+"""The index build held to a RUN of the reference (tests/golden/index_build.npz, made by tests/golden/make_golden.py importing
+/root/reference/scaling_retriever/indexer.py:239-308 and utils/inverted_index.py:67-170 with a fake model that emits fixed [B, V] reps,
+all-zero rows included, at world sizes 1 and 2):
+  * CPU: IndexDictOfArray.add_batch_document (the reference's per-posting append order), save / reload and merge_indexes in both
+    directory orders - per-term doc ids and values, doc_ids.pkl (keys in insertion order), nb_docs(), L0_d;
+  * GPU (-m gpu): SparseIndexer.index -> sr_sparse_compact per batch + sr_sparse_csr_build, bit for bit the reference's posting arrays,
+    doc_ids and statistics, to disk and in memory, for every rank of both world sizes."""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+try:
+    import h5py
+    REAL_H5PY = True
+except Exception:
+    import h5py_double as h5py
+    REAL_H5PY = False
+
+
+@pytest.fixture(autouse=True)
+def _h5py_available(monkeypatch):
+    from scaling_retriever_amd.utils import inverted_index
+    if not REAL_H5PY:
+        monkeypatch.setitem(sys.modules, "h5py", h5py)
+        monkeypatch.setattr(inverted_index, "HAVE_H5PY", True)
+    yield
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "index_build.npz"))
+
+
+def _per_term(g, tag, V):
+    """{term: (doc ids int32, values fp32)} of one recorded index."""
+    if f"{tag}:terms" in g:
+        terms, lens = g[f"{tag}:terms"].tolist(), g[f"{tag}:lens"].tolist()
+    else:
+        terms, lens = list(range(V)), g[f"{tag}:lens"].tolist()
+    out, o = {}, 0
+    for t, n in zip(terms, lens):
+        if n:
+            out[t] = (g[f"{tag}:doc_id"][o:o + n], g[f"{tag}:value"][o:o + n])
+        o += n
+    return out
+
+
+def _assert_same_index(container, want, V):
+    have = {int(t) for t in container.index_doc_id.keys() if len(container.index_doc_id[t])}
+    assert have == set(want)
+    for t, (ids, vals) in want.items():
+        got_i, got_v = np.asarray(container.index_doc_id[t]), np.asarray(container.index_doc_value[t])
+        assert got_i.dtype == np.int32 and got_v.dtype == np.float32
+        assert np.array_equal(got_i, ids) and np.array_equal(got_v.view(np.uint32), vals.view(np.uint32)), t
+
+
+def _rank_loader(g, W, rank, wrap=lambda rows: rows):
+    N, B, pids = int(g["N"]), int(g["B"]), g["pids"].tolist()
+    mine = list(range(rank, N, W))
+    return [{"ids": [pids[d] for d in mine[b0:b0 + B]], "rows": wrap(mine[b0:b0 + B])} for b0 in range(0, len(mine), B)]
+
+
+def test_add_batch_document_matches_the_reference_appends(gold):
+    """The reference appends posting by posting in the order torch.nonzero yields them (row-major: doc, then term); fed the same
+    (row, col, value) triples batch by batch, the container holds the reference's per-term arrays."""
+    from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+    V, reps = int(gold["V"]), gold["reps"]
+    for W in (1, 2):
+        for rank in range(W):
+            ix = IndexDictOfArray(dim_voc=V)
+            count = 0
+            for b in _rank_loader(gold, W, rank):
+                r = reps[b["rows"]]
+                row, col = np.nonzero(r)
+                ix.add_batch_document((row + count) * W + rank, col, r[row, col], n_docs=len(b["ids"]))
+                count += len(b["ids"])
+            _assert_same_index(ix, _per_term(gold, f"W{W}r{rank}", V), V)
+            assert ix.nb_docs() == int(gold[f"W{W}r{rank}:nb_docs"])           # += n_docs per batch (inverted_index.py:70-73)
+
+
+def _write_rank_dir(gold, d, tag, V):
+    from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+    want = _per_term(gold, tag, V)
+    ix = IndexDictOfArray(d, dim_voc=V, force_new=True)
+    for t in sorted(want):
+        ix.add_batch_document(want[t][0], np.full(len(want[t][0]), t, np.int32), want[t][1], n_docs=0)
+    ix.save()
+    pickle.dump(dict(zip(gold[f"{tag}:doc_ids_keys"].tolist(), gold[f"{tag}:doc_ids_vals"].tolist())), open(os.path.join(d, "doc_ids.pkl"), "wb"))
+    json.dump({"L0_d": float(gold[f"{tag}:L0_d"])}, open(os.path.join(d, "index_stats.json"), "w"))
+
+
+@pytest.mark.parametrize("order", ["01", "10"])
+def test_merge_indexes_matches_the_reference_run(gold, tmp_path, monkeypatch, order):
+    """merge_indexes (inverted_index.py:108-170) walks os.listdir order and appends a term's arrays rank after rank; doc_ids is the
+    union in that order, L0_d the mean; a reader of the merged directory sees nb_docs() = largest global row + 1."""
+    from scaling_retriever_amd.utils import inverted_index as inv
+    V = int(gold["V"])
+    root = tmp_path / "W2"
+    for r in range(2):
+        _write_rank_dir(gold, str(root / f"index_{r}"), f"W2r{r}", V)
+    model = tmp_path / "model"
+    model.mkdir()
+    json.dump({"vocab_size": V}, open(model / "config.json", "w"))
+    names = [f"index_{c}" for c in order]
+    real = os.listdir
+    monkeypatch.setattr(inv.os, "listdir", lambda p: list(names) if os.path.abspath(p) == os.path.abspath(str(root)) else real(p))
+    inv.merge_indexes(str(model), index_name="index", index_dir=str(root))
+    monkeypatch.setattr(inv.os, "listdir", real)
+    merged = inv.IndexDictOfArray(str(root / "index"), dim_voc=V)
+    tag = f"merge{order}"
+    _assert_same_index(merged, _per_term(gold, tag, V), V)
+    assert merged.nb_docs() == int(gold[f"{tag}:nb_docs"])
+    doc_ids = pickle.load(open(root / "index" / "doc_ids.pkl", "rb"))
+    assert list(doc_ids.keys()) == gold[f"{tag}:doc_ids_keys"].tolist() and list(doc_ids.values()) == gold[f"{tag}:doc_ids_vals"].tolist()
+    assert json.load(open(root / "index" / "index_stats.json"))["L0_d"] == float(gold[f"{tag}:L0_d"])
+
+
+def test_single_rank_directory_reloads_like_the_reference(gold, tmp_path):
+    from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+    V = int(gold["V"])
+    _write_rank_dir(gold, str(tmp_path / "index"), "W1r0", V)
+    rd = IndexDictOfArray(str(tmp_path / "index"), dim_voc=V)
+    _assert_same_index(rd, _per_term(gold, "W1r0", V), V)
+    assert rd.nb_docs() == int(gold["W1r0:nb_docs_reloaded"])                  # max key + 1: the trailing docs without postings are gone
+    _write_rank_dir(gold, str(tmp_path / "r1"), "W2r1", V)
+    assert int(gold["W2r1:nb_docs_reloaded"]) == -1                            # the reference asserts min key == 0 (:54) ...
+    with pytest.raises(AssertionError):                                        # ... and so does this container
+        IndexDictOfArray(str(tmp_path / "r1"), dim_voc=V)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,rank", [(1, 0), (2, 0), (2, 1)])
+@pytest.mark.parametrize("to_disk", [True, False])
+def test_sparse_indexer_index_matches_the_reference_run(gold, tmp_path, monkeypatch, W, rank, to_disk):
+    """SparseIndexer.index with the HIP compaction + radix CSR build behind it reproduces what the reference's Python append loop
+    built from the same reps: per-term arrays bit for bit, doc_ids (docs without a posting left out, indexer.py:271-283), L0_d."""
+    import torch
+    from scaling_retriever_amd import indexer as ours
+    V = int(gold["V"])
+    reps = torch.from_numpy(gold["reps"]).cuda()
+
+    class FixedReps(torch.nn.Module):
+        def encode(self, rows):
+            return reps[rows]
+
+    monkeypatch.setattr(ours, "get_rank", lambda: rank)
+    monkeypatch.setattr(ours, "get_world_size", lambda: W)
+    loader = _rank_loader(gold, W, rank, wrap=lambda rows: torch.tensor(rows))
+    d = str(tmp_path / "index") if to_disk else None
+    res = ours.SparseIndexer(FixedReps(), d, torch.device("cuda", 0), compute_stats=True, dim_voc=V).index(loader)
+    tag = f"W{W}r{rank}"
+    want = _per_term(gold, tag, V)
+    if to_disk:
+        assert res is None
+        # a reader of a shard of rank >= 1 alone is refused, as in the reference: read the file with the doc count check off
+        from scaling_retriever_amd.utils.inverted_index import IndexDictOfArray
+        _assert_same_index(IndexDictOfArray(d, dim_voc=V, _count_docs=False), want, V)
+        doc_ids = pickle.load(open(os.path.join(d, "doc_ids.pkl"), "rb"))
+        stats = json.load(open(os.path.join(d, "index_stats.json")))
+        dist = {int(k): v for k, v in json.load(open(os.path.join(d, "index_dist.json"))).items()}
+        assert {t: n for t, n in dist.items() if n} == {t: len(v[0]) for t, v in want.items()}
+    else:
+        _assert_same_index(res["index"], want, V)
+        doc_ids, stats = res["ids_mapping"], res["stats"]
+        # nb_docs(): the reference counts THIS rank's documents (12 of 23 at W = 2) although its doc ids are global rows - it never
+        # scores from a shard (eval_sparse.py:114).  This container reports largest global row + 1, what a scorer over it needs.
+        n_ref = int(gold[f"{tag}:nb_docs"])
+        assert res["index"].nb_docs() == (n_ref if W == 1 else (n_ref - 1) * W + rank + 1)
+    assert list(doc_ids.keys()) == gold[f"{tag}:doc_ids_keys"].tolist() and list(doc_ids.values()) == gold[f"{tag}:doc_ids_vals"].tolist()
+    assert stats["L0_d"] == float(gold[f"{tag}:L0_d"])
