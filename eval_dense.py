@@ -179,8 +179,7 @@ class LocalFaissDenseRetriever(DenseRetriever):
         and writes piece c - 1 (the C call releases the GIL).  Exact results do not depend on how the queries are batched (pieces stay above
         64 queries) and the file is the one-call file byte for byte."""
         import time
-        from concurrent.futures import ThreadPoolExecutor
-        from scaling_retriever_amd.utils.run_file import id_table, write_run_json
+        from scaling_retriever_amd.utils.run_file import PiecewiseRunWriter, id_table, write_run_json
         t_start = time.perf_counter()
         batches = list(dataloader)
         sizes = [len(b["ids"]) for b in batches]
@@ -208,19 +207,16 @@ class LocalFaissDenseRetriever(DenseRetriever):
                 cuts.append(bi + 1)
         cuts.append(len(batches))
         pieces = [batches[cuts[c]:cuts[c + 1]] for c in range(len(cuts) - 1) if cuts[c + 1] > cuts[c]]
-        size, writes = 0, []
-        with ThreadPoolExecutor(max_workers=1) as writer:              # one worker: the pieces reach the file in order
+        with PiecewiseRunWriter(path) as writer:                       # run.json appears only when its last piece is written
             for c, piece in enumerate(pieces):
                 t0 = time.perf_counter()
                 reps, qids = generate_query_vecs(self.model, piece, self.device)
                 scores, positions = self.index.search_arrays(reps, top_docs)
                 t1 = time.perf_counter()
-                part = 1 if c == 0 else (3 if c + 1 == len(pieces) else 2)
-                writes.append(writer.submit(write_run_json, path, qids, scores, positions, table, None, 0, part))
+                writer.add(qids, scores, positions, table, None, last=c + 1 == len(pieces))
                 tl["pieces"].append({"queries": len(qids), "encode_and_search_ms": round((t1 - t0) * 1e3, 1)})
             t2 = time.perf_counter()
-            for w in writes:
-                size = w.result()
+            size = writer.finish()
             tl["waited_for_the_writer_after_the_last_search_ms"] = round((time.perf_counter() - t2) * 1e3, 1)
         tl["total_ms"] = round((time.perf_counter() - t_start) * 1e3, 1)
         return nq, size

@@ -142,6 +142,7 @@ struct RadixArgs {
     int64_t n_terms;     // range check of the terms (first histogram only)
     int* flags;          // |= 1: a term outside [0, n_terms), |= 2: a negative doc row
     int check;
+    int64_t row_limit;       // sort_docs: n_docs (a row at or beyond it would leave the lists not ascending by doc); 0 = rows are payload only
 };
 
 __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a) {
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a)
                 const int32_t t = a.term_in[j], rw = a.row_in[j];
                 if (t < 0 || (int64_t)t >= a.n_terms) bad |= 1;
                 if (rw < 0) bad |= 2;
+                if (a.row_limit > 0 && (int64_t)rw >= a.row_limit) bad |= 4;      // sort_docs: the doc digits cover [0, n_docs) only
             }
         }
 #pragma unroll
@@ -320,7 +322,7 @@ extern "C" int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols,
             a.term_in = tin; a.row_in = rin; a.val_in = vin;
             a.term_out = tout; a.row_out = rout; a.val_out = vout;
             a.n = nnz; a.by_row = passes[p].by_row; a.shift = passes[p].shift; a.bits = passes[p].bits;
-            a.hist = hist; a.n_waves = n_waves; a.n_terms = n_terms; a.flags = flags; a.check = p == 0;
+            a.hist = hist; a.n_waves = n_waves; a.n_terms = n_terms; a.flags = flags; a.check = p == 0; a.row_limit = sort_docs ? n_docs : 0;
             const unsigned grid = (unsigned)ceil_div64(n_waves, SBW_WAVES);
             hipLaunchKernelGGL(radix_hist_kernel, dim3(grid), dim3(64 * SBW_WAVES), 0, s, a);
             if (hipGetLastError() != hipSuccess) { rc = SR_ERR_HIP; break; }
@@ -330,8 +332,8 @@ extern "C" int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols,
                 int h = 0;
                 if (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = SR_ERR_HIP; break; }
                 if (h) {
-                    sr_set_error("sr_sparse_csr_build: invalid postings (%s%s)", (h & 1) ? "term outside [0, n_terms); " : "",
-                                 (h & 2) ? "negative doc row" : "");
+                    sr_set_error("sr_sparse_csr_build: invalid postings (%s%s%s)", (h & 1) ? "term outside [0, n_terms); " : "",
+                                 (h & 2) ? "negative doc row; " : "", (h & 4) ? "sort_docs with a doc row >= n_docs" : "");
                     rc = SR_ERR_INVALID;
                     break;
                 }

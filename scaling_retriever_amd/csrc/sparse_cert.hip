@@ -82,6 +82,8 @@ struct SparseCert {
     uint8_t* overflow = nullptr;      // [nq_pad]
     int32_t* m_count = nullptr;       // [nq_pad] candidates to re-score
     int* d_n_uncert = nullptr;
+    uint8_t* d_uncert = nullptr;      // [uncert_cap] flags of a search's batch (kept: a hipMalloc / hipFree pair per search synchronises the device)
+    int64_t uncert_cap = 0;
     int64_t ap_cap = 0;               // approximate top lists [nq][k_eff]
     int64_t* ap_ids = nullptr;
     TopkWS ws;
@@ -250,7 +252,7 @@ void sparse_cert_destroy(SparseCert* c) {
         (void)hipFree(c->d_stamps);
     }
     void* ptrs[] = {c->dslot, c->vmax, c->d16, c->P, c->S, c->E, c->fwd_indptr, c->fwd_tv, c->bfrag, c->rare_term, c->rare_w,
-                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->tau2, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->ap_ids, c->dump};
+                    c->cq, c->sq, c->n_rare, c->n_qt, c->n_drop, c->tau2, c->elig, c->overflow, c->m_count, c->d_n_uncert, c->d_uncert, c->ap_ids, c->dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws.release();
@@ -262,8 +264,16 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
     // default: collections of at least 64 tiles
     int mode = -1;
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT")) mode = atoi(e);
-    if (mode == 0) return SR_OK;
-    if (mode < 0 && idx->n_docs < 64 * SC_DT) return SR_OK;
+    // public switches (include/sr_hip.h): SR_SPARSE_SCORER=exact keeps the index without the scorer's side structures (they take up to half
+    // of the free device memory: ~22 bytes per posting + 8 bytes per (term, doc tile)); SR_LOG=1 says on stderr what was built or why not
+    const char* scorer = getenv("SR_SPARSE_SCORER");
+    const bool log = getenv("SR_LOG") && atoi(getenv("SR_LOG")) != 0;
+    if (scorer && strcmp(scorer, "exact") == 0) mode = 0;
+    if (mode == 0 || (mode < 0 && idx->n_docs < 64 * SC_DT)) {
+        if (log) fprintf(stderr, "[sr_hip] sparse index of %lld docs: exact kernels only (%s)\n", (long long)idx->n_docs,
+                         mode == 0 ? "certified scorer switched off" : "fewer than 65 536 docs");
+        return SR_OK;
+    }
     std::vector<int64_t> h_indptr((size_t)idx->n_terms + 1);
     SR_CHECK_HIP(hipMemcpyAsync(h_indptr.data(), idx->indptr, sizeof(int64_t) * h_indptr.size(), hipMemcpyDeviceToHost, s));
     SR_CHECK_HIP(hipStreamSynchronize(s));
@@ -324,7 +334,13 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { rc = SR_ERR_HIP; break; }
         const size_t need = d16_halves * 2 + (size_t)nnz * 12 + (s_words + e_words) * 4 + (size_t)N * 16 + (64u << 20);
-        if (need > free_b / 2) break;             // side structures may take at most half of what is free
+        if (need > free_b / 2) {                  // side structures may take at most half of what is free
+            if (log) fprintf(stderr, "[sr_hip] sparse index: the certified scorer needs %.2f GB, more than half of the %.2f GB free: exact kernels only\n",
+                             (double)need / 1e9, (double)free_b / 1e9);
+            break;
+        }
+        if (log) fprintf(stderr, "[sr_hip] sparse index of %lld docs, %lld postings: certified scorer with %d heavy terms, %.2f GB of side structures "
+                                 "(SR_SPARSE_SCORER=exact to do without)\n", (long long)N, (long long)nnz, c->T, (double)need / 1e9);
         if (hipMalloc((void**)&c->dslot, sizeof(int32_t) * (size_t)V) != hipSuccess || hipMalloc((void**)&c->d16, d16_halves * 2) != hipSuccess ||
             hipMalloc((void**)&c->P, sizeof(uint32_t) * ((size_t)nnz + 4)) != hipSuccess || hipMalloc((void**)&c->S, s_words * 4) != hipSuccess ||
             hipMalloc((void**)&c->E, e_words * 4) != hipSuccess ||
@@ -1290,11 +1306,69 @@ __global__ __launch_bounds__(256) void cert_rescore_kernel(CertRescoreArgs a) {
 
 // ------------------------------------------------------------------------------------------------------ driver ---
 template <typename T>
-static int cert_realloc(T*& p, size_t n) {
+static bool cert_realloc(T*& p, size_t n) {
     if (p) (void)hipFree(p);
     p = nullptr;
-    SR_CHECK_HIP(hipMalloc((void**)&p, sizeof(T) * n));
-    return SR_OK;
+    if (hipMalloc((void**)&p, sizeof(T) * n) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        return false;
+    }
+    return true;
+}
+
+// the per-call buffers of a batch of nq_pad queries; false = out of device memory: everything per-call is released (the index-side
+// structures stay) and the caller serves the batch with the exact kernels
+static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {
+    bool ok = true;
+    if (nq_pad > c->nq_cap) {
+        c->nq_cap = 0;
+        ok = ok && cert_realloc(c->bfrag, (size_t)nq_pad * (size_t)c->T);
+        ok = ok && cert_realloc(c->rare_term, (size_t)nq_pad * SC_MAXR);
+        ok = ok && cert_realloc(c->rare_w, (size_t)nq_pad * SC_MAXR);
+        ok = ok && cert_realloc(c->cq, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->sq, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->n_rare, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->n_qt, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->n_drop, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->tau2, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->elig, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->overflow, (size_t)nq_pad);
+        ok = ok && cert_realloc(c->m_count, (size_t)nq_pad);
+        if (ok) c->nq_cap = nq_pad;
+    }
+    if (ok && nq_pad * k_eff > c->ap_cap) {
+        c->ap_cap = 0;
+        ok = cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)(2 * k_eff));
+        if (ok) c->ap_cap = nq_pad * k_eff;
+    }
+    if (ok && !c->d_n_uncert && hipMalloc((void**)&c->d_n_uncert, 2 * sizeof(int)) != hipSuccess) {     // [0] uncertified queries, [1] candidates re-scored (in units of 16)
+        (void)hipGetLastError();
+        c->d_n_uncert = nullptr;
+        ok = false;
+    }
+    if (ok && c->ws.ensure(nq_pad, k_eff, SC_CAND_CAP) != SR_OK) ok = false;      // releases itself on failure
+    if (!ok) {
+        void** ptrs[] = {(void**)&c->bfrag, (void**)&c->rare_term, (void**)&c->rare_w, (void**)&c->cq, (void**)&c->sq, (void**)&c->n_rare, (void**)&c->n_qt,
+                         (void**)&c->n_drop, (void**)&c->tau2, (void**)&c->elig, (void**)&c->overflow, (void**)&c->m_count, (void**)&c->ap_ids};
+        for (void** pp : ptrs) {
+            if (*pp) (void)hipFree(*pp);
+            *pp = nullptr;
+        }
+        c->nq_cap = 0;
+        c->ap_cap = 0;
+        c->ws.release();
+    }
+    return ok;
+}
+
+uint8_t* sparse_cert_uncert_buffer(SparseCert* c, int64_t nq) {
+    if (nq > c->uncert_cap) {
+        c->uncert_cap = 0;
+        if (!cert_realloc(c->d_uncert, (size_t)nq)) return nullptr;
+        c->uncert_cap = nq;
+    }
+    return c->d_uncert;
 }
 
 template <int KS>
@@ -1313,37 +1387,25 @@ static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
 
 int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
                        int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
-                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, hipStream_t s) {
+                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, hipStream_t s) {
     SparseCert* c = idx->cert;
     const int k_eff = k + SC_BAND;
     const int64_t nq_pad = ceil_div64(nq, SC_QB) * SC_QB;
     const int n_qblocks = (int)(nq_pad / SC_QB);
-    if (nq_pad > c->nq_cap) {
-        SR_TRY(cert_realloc(c->bfrag, (size_t)nq_pad * (size_t)c->T));
-        SR_TRY(cert_realloc(c->rare_term, (size_t)nq_pad * SC_MAXR));
-        SR_TRY(cert_realloc(c->rare_w, (size_t)nq_pad * SC_MAXR));
-        SR_TRY(cert_realloc(c->cq, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->sq, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->n_rare, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->n_qt, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->n_drop, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->tau2, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->elig, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->overflow, (size_t)nq_pad));
-        SR_TRY(cert_realloc(c->m_count, (size_t)nq_pad));
-        c->nq_cap = nq_pad;
+    *no_memory = false;
+    if (!cert_ensure_call_buffers(c, nq_pad, k_eff)) {
+        *no_memory = true;
+        return SR_OK;
     }
-    if (nq_pad * k_eff > c->ap_cap) {
-        SR_TRY(cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)(2 * k_eff)));
-        c->ap_cap = nq_pad * k_eff;
-    }
-    if (!c->d_n_uncert) SR_CHECK_HIP(hipMalloc((void**)&c->d_n_uncert, 2 * sizeof(int)));      // [0] uncertified queries, [1] candidates re-scored (in units of 16)
     const int64_t dump_stride = (int64_t)c->n_tiles * SC_DT;
     if (c->want_dump && c->dump_nq < nq_pad) {
-        SR_TRY(cert_realloc(c->dump, (size_t)nq_pad * (size_t)dump_stride));
+        c->dump_nq = 0;
+        if (!cert_realloc(c->dump, (size_t)nq_pad * (size_t)dump_stride)) {
+            sr_set_error("sparse_cert_search: no device memory for the debug key dump");
+            return SR_ERR_NOMEM;
+        }
         c->dump_nq = nq_pad;
     }
-    SR_TRY(c->ws.ensure(nq_pad, k_eff, SC_CAND_CAP));
 
     // plan
     SR_CHECK_HIP(hipMemsetAsync(c->bfrag, 0, sizeof(_Float16) * (size_t)nq_pad * (size_t)c->T, s));
@@ -1449,7 +1511,8 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
 }
 
 // Which path served the searches so far.  out[0] = 1 if the certified scorer exists for this index, [1] dense terms (MFMA K),
-// [2] searches it ran, [3] queries it was given, [4] queries it handed to the exact kernels (uncertified), [5] doc tiles, [6] reserved
+// [2] searches it ran, [3] queries it was given, [4] queries it handed to the exact kernels (uncertified), [5] doc tiles, [6] candidates
+// re-scored, [7] query batches served by the exact kernels because the scorer's per-call buffers did not fit in device memory
 extern "C" int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8) {
     SR_REQUIRE(idx && out8, "sr_sparse_index_cert_stats: null argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -1457,6 +1520,7 @@ extern "C" int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8) {
     if (SparseCert* c = idx->cert) {
         out8[0] = 1; out8[1] = c->T; out8[2] = c->n_calls; out8[3] = c->n_queries; out8[4] = c->n_uncert; out8[5] = c->n_tiles; out8[6] = c->n_rescored;
     }
+    out8[7] = idx->n_cert_no_memory;
     return SR_OK;
 }
 

@@ -42,6 +42,7 @@ struct sr_sparse_index {
     unsigned long long* d_postings = nullptr;  // device counter of postings touched (profiling only)
     // certified two-stage scorer (null: the index or the device does not qualify; every search then runs the exact kernels)
     SparseCert* cert = nullptr;
+    int64_t n_cert_no_memory = 0;       // query batches served by the exact kernels because the certified scorer's buffers did not fit
     std::mutex mu;
 };
 
@@ -52,10 +53,15 @@ int sparse_cert_build(sr_sparse_index* idx, hipStream_t s);
 void sparse_cert_destroy(SparseCert* c);
 // Scores every query; d_uncert[q] = 1 marks the queries whose result rows were NOT written and must be served by the exact
 // kernels (query outside the fast path's preconditions, or its candidate set could not be certified).  *n_uncert = their number
-// (the call synchronises the stream once to read it).
+// (the call synchronises the stream once to read it).  *no_memory = true (with SR_OK): the per-call buffers of this batch did not fit
+// in device memory; they were released, nothing was computed, and the caller serves the batch with the exact kernels.
 int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
                        int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
-                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, hipStream_t s);
+                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, hipStream_t s);
+// [nq] flag bytes kept with the scorer (grown on demand); nullptr = out of device memory
+uint8_t* sparse_cert_uncert_buffer(SparseCert* c, int64_t nq);
+// queries per call of sparse_cert_search: its per-query workspace is ~200 KB (candidate slots of a launch, running set, approximate lists)
+#define SR_CERT_QUERY_BATCH 8192
 
 // ---- device-wide exclusive scan of int64 counts (sparse_build.hip): out[i] = sum_{j < i} in[j], out[n] = total; in == out allowed
 int sr_device_exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n, hipStream_t s);

@@ -1492,16 +1492,30 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
     }
     if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_SEARCH")) use_cert = use_cert && atoi(e) != 0;
     if (use_cert) {
-        uint8_t* d_uncert = nullptr;
-        SR_CHECK_HIP(hipMalloc((void**)&d_uncert, (size_t)nq));
-        int64_t n_un = 0;
-        int rc = sparse_cert_search(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
-                                    d_out_counts, d_uncert, &n_un, s);
-        if (rc == SR_OK && n_un > 0)
-            rc = sparse_redo_exact(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
-                                   d_out_counts, d_uncert, s);
-        (void)hipFree(d_uncert);       // sparse_cert_search synchronised the stream after its last use
-        return rc;
+        // The scorer's workspace is ~200 KB per query: the query set goes through in batches (a whole MSMARCO-Dev set is one batch), and
+        // a batch whose buffers do not fit in device memory is served by the exact kernels instead of failing the call.
+        int64_t batch = SR_CERT_QUERY_BATCH;
+        if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_BATCH")) batch = std::max<int64_t>(32, atoll(e) / 32 * 32);   // tests: several batches on small inputs
+        uint8_t* d_uncert = sparse_cert_uncert_buffer(idx->cert, nq < batch ? nq : batch);
+        for (int64_t qb = 0; qb < nq; qb += batch) {
+            const int64_t nqb = nq - qb < batch ? nq - qb : batch;
+            float* o_s = d_out_scores + qb * k;
+            int64_t* o_i = d_out_ids + qb * k;
+            int32_t* o_c = d_out_counts ? d_out_counts + qb : nullptr;
+            int64_t n_un = 0;
+            bool no_memory = d_uncert == nullptr;
+            if (sr_dev_getenv("SR_SPARSE_CERT_FAKE_OOM")) no_memory = true;          // tests: the fallback below
+            if (!no_memory)
+                SR_TRY(sparse_cert_search(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert,
+                                          &n_un, &no_memory, s));
+            if (no_memory) {
+                ++idx->n_cert_no_memory;
+                SR_TRY(sparse_exact_search(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, s));
+            } else if (n_un > 0) {
+                SR_TRY(sparse_redo_exact(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert, s));
+            }
+        }
+        return SR_OK;
     }
     return sparse_exact_search(idx, d_q_indptr, d_q_cols, d_q_vals, nq, k, threshold, id_base, id_stride, d_out_scores, d_out_ids,
                                d_out_counts, s);

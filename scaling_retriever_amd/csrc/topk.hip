@@ -406,7 +406,12 @@ int TopkWS::ensure_segments(int64_t nq, int kk, int64_t dense_cap, int sn) {
     if (nq <= nq_cap && kk <= k && seg_n == sn && seg_off == dense_cap && seg_cnt) return SR_OK;
     release();
     SR_TRY(ensure(nq, kk, dense_cap + (int64_t)sn * SR_SEG_P));
-    SR_CHECK_HIP(hipMalloc(&seg_cnt, (size_t)nq * (size_t)sn));
+    if (hipMalloc(&seg_cnt, (size_t)nq * (size_t)sn) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        sr_set_error("top-k workspace: out of device memory for the segment counts");
+        return SR_ERR_NOMEM;
+    }
     SR_CHECK_HIP(hipMemset(seg_cnt, 0, (size_t)nq * (size_t)sn));
     seg_n = sn;
     seg_off = dense_cap;
@@ -416,14 +421,19 @@ int TopkWS::ensure_segments(int64_t nq, int kk, int64_t dense_cap, int sn) {
 int TopkWS::ensure(int64_t nq, int kk, int64_t cc) {
     if (nq <= nq_cap && kk <= k && cc <= cand_cap && seg_n == 0) return SR_OK;
     release();
+    // the shape is recorded only once every buffer exists: after a failed allocation the next call with the same shape must not take the
+    // early-out above with null buffers behind it
+    if (hipMalloc(&run_keys, sizeof(uint64_t) * (size_t)nq * 2 * (size_t)kk) != hipSuccess || hipMalloc(&run_count, sizeof(int) * (size_t)nq) != hipSuccess ||
+        hipMalloc(&tau, sizeof(float) * (size_t)nq) != hipSuccess || hipMalloc(&cand_keys, sizeof(uint64_t) * (size_t)nq * (size_t)cc) != hipSuccess ||
+        hipMalloc(&cand_count, sizeof(int) * (size_t)nq) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        sr_set_error("top-k workspace: out of device memory (%lld queries, k = %d, %lld candidate slots each)", (long long)nq, kk, (long long)cc);
+        return SR_ERR_NOMEM;
+    }
     nq_cap = nq;
     k = kk;
     cand_cap = cc;
-    SR_CHECK_HIP(hipMalloc(&run_keys, sizeof(uint64_t) * (size_t)nq * 2 * (size_t)kk));
-    SR_CHECK_HIP(hipMalloc(&run_count, sizeof(int) * (size_t)nq));
-    SR_CHECK_HIP(hipMalloc(&tau, sizeof(float) * (size_t)nq));
-    SR_CHECK_HIP(hipMalloc(&cand_keys, sizeof(uint64_t) * (size_t)nq * (size_t)cc));
-    SR_CHECK_HIP(hipMalloc(&cand_count, sizeof(int) * (size_t)nq));
     return SR_OK;
 }
 

@@ -27,7 +27,7 @@ from tqdm import tqdm
 from . import _lib
 from .scoring import DenseIndexHIP, SparseIndexHIP, sparse_csr_build, sparse_csr_expand_terms
 from .utils.inverted_index import IndexDictOfArray
-from .utils.run_file import IdTable, RunResult, id_table, to_host, write_run_json
+from .utils.run_file import IdTable, PiecewiseRunWriter, RunResult, id_table, to_host, write_run_json
 from .utils.utils import get_rank, get_world_size, is_first_worker, to_list
 
 logger = logging.getLogger()
@@ -728,11 +728,10 @@ class SparseRetrieval:
             res, stats = self._sparse_retrieve_multithreaded(sparse_query_vecs, qids, threshold=threshold, topk=topk)
             self._write_outputs(res, stats)
             return res
-        from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.out_dir, exist_ok=True)
         path = os.path.join(self.out_dir, "run.json")
-        pieces, nnz, writes = [], 0, []
-        with ThreadPoolExecutor(max_workers=1) as writer:              # one worker: the pieces reach the file in order
+        pieces, nnz = [], 0
+        with PiecewiseRunWriter(path) as writer:                       # run.json appears only when its last piece is written
             for gi, group in enumerate(groups):
                 with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):  # indexer.py:390-391
                     reps = encode_group(self.model, group, self.device)
@@ -742,10 +741,8 @@ class SparseRetrieval:
                 scores, ids, counts = self.hip_index.search(q.row_ptr, q.cols, q.vals, topk, threshold=threshold)
                 piece = (to_host(scores), to_host(ids), to_host(counts))
                 pieces.append(piece)
-                part = 1 if gi == 0 else (3 if gi + 1 == len(groups) else 2)
-                writes.append(writer.submit(write_run_json, path, group_qids[gi], piece[0], piece[1], table, piece[2], 0, part))
-            for w in writes:
-                w.result()
+                writer.add(group_qids[gi], piece[0], piece[1], table, piece[2], last=gi + 1 == len(groups))
+            writer.finish()
         res = RunResult(qids, np.concatenate([p_[0] for p_ in pieces]), np.concatenate([p_[1] for p_ in pieces]), table,
                         np.concatenate([p_[2] for p_ in pieces]))
         if self.compute_stats:

@@ -269,10 +269,11 @@ class SparseIndexHIP:
 
     def cert_stats(self):
         """Certified two-stage scorer (csrc/sparse_cert.hip): {"present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles",
-        "candidates_rescored" (exact chains run by the certified path, rounded up to 16 per query)}."""
+        "candidates_rescored" (exact chains run by the certified path, rounded up to 16 per query), "batches_without_memory" (query batches
+        the exact kernels served because the scorer's per-call buffers did not fit)}."""
         out = (ctypes.c_int64 * 8)()
         _lib.check(self.lib.sr_sparse_index_cert_stats(self._h, out), "sr_sparse_index_cert_stats")
-        keys = ("present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles", "candidates_rescored")
+        keys = ("present", "dense_terms", "searches", "queries", "redone_exact", "doc_tiles", "candidates_rescored", "batches_without_memory")
         return {k_: int(v) for k_, v in zip(keys, out)}
 
     def cert_record_keys(self, enable):

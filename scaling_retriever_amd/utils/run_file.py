@@ -167,6 +167,57 @@ def write_run_json(path, qids, scores, positions, doc_table, counts=None, n_thre
     return nbytes.value
 
 
+class PiecewiseRunWriter:
+    """run.json written piece by piece on ONE worker thread (the pieces reach the file in order) while the caller encodes and searches the
+    next piece.  The pieces go to `path + ".tmp"`; the file takes its name only when the last piece is down (os.replace), so a failure in
+    a later piece - in the caller's encode / search or in the writer - leaves no half-written run.json behind (a reader of the one-shot
+    path never saw one either).  add() re-raises the exception of an earlier piece's write instead of computing on for nothing."""
+
+    def __init__(self, path):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        self.path, self.tmp = str(path), str(path) + ".tmp"
+        self._os = os
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._writes = []
+        self._closed = False
+
+    def _check(self):
+        for w in self._writes:
+            if w.done() and w.exception() is not None:
+                raise w.exception()
+
+    def add(self, qids, scores, positions, doc_table, counts=None, last=False):
+        self._check()
+        part = 3 if last else (1 if not self._writes else 2)
+        if last and not self._writes:
+            part = 0                                            # a single piece: the one-call writer
+        self._writes.append(self._pool.submit(write_run_json, self.tmp, qids, scores, positions, doc_table, counts, 0, part))
+        self._closed = self._closed or last
+
+    def finish(self):
+        """Wait for every piece; returns the file size.  Raises what a write raised."""
+        size = 0
+        for w in self._writes:
+            size = w.result()
+        if not self._closed:
+            raise RuntimeError("PiecewiseRunWriter.finish: the last piece was never added")
+        self._os.replace(self.tmp, self.path)
+        return size
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self._pool.shutdown(wait=True)
+        if self._os.path.exists(self.tmp):                      # finish() was not reached, or a write failed
+            try:
+                self._os.remove(self.tmp)
+            except OSError:
+                pass
+        return False
+
+
 class RunResult(Mapping):
     """The `res` / `qid_to_rankdata` dict of the reference's retrieval drivers, backed by the result arrays.
     res[str(qid)] -> {str(doc id): float(score)} in rank order (built on access); queries without a hit have no entry, as in the

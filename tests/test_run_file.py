@@ -178,3 +178,43 @@ def test_file_written_in_pieces_equals_the_whole(tmp_path, cuts):
         size = write_run_json(parts, qids[r0:r1], scores[r0:r1], positions[r0:r1], docs, n_threads=3, part=c + 1)
     assert size == n and parts.read_bytes() == whole.read_bytes()
     assert json.loads(parts.read_text()) == _reference_dict(qids, scores, positions, docs)
+
+
+def test_piecewise_writer_publishes_run_json_only_when_complete(tmp_path):
+    """PiecewiseRunWriter (SparseRetrieval.retrieve, eval_dense write_run): the pieces go to run.json.tmp and the file takes its name after
+    the last piece - the bytes of one call; a failure between pieces (the caller's next encode / search, or a write) leaves the
+    previous run.json untouched and no .tmp behind, and a failed write is re-raised at the next add()."""
+    from scaling_retriever_amd.utils.run_file import PiecewiseRunWriter
+    rng = np.random.default_rng(5)
+    nq, k, N = 600, 20, 3000
+    scores, positions = _case(rng, nq, k, N)
+    qids = [str(i) for i in range(nq)]
+    docs = np.arange(N)
+    whole, path = tmp_path / "whole.json", tmp_path / "run.json"
+    write_run_json(whole, qids, scores, positions, docs)
+    with PiecewiseRunWriter(path) as w:
+        for c, (r0, r1) in enumerate([(0, 256), (256, 512), (512, nq)]):
+            w.add(qids[r0:r1], scores[r0:r1], positions[r0:r1], docs, last=c == 2)
+            assert not path.exists()                                   # nothing under the final name before the end
+        size = w.finish()
+    assert path.read_bytes() == whole.read_bytes() and size == path.stat().st_size and not (tmp_path / "run.json.tmp").exists()
+    with PiecewiseRunWriter(tmp_path / "single.json") as w:            # one piece: the one-call writer
+        w.add(qids, scores, positions, docs, last=True)
+        w.finish()
+    assert (tmp_path / "single.json").read_bytes() == whole.read_bytes()
+    before = path.read_bytes()
+    with pytest.raises(RuntimeError, match="search failed"):           # the caller fails after the first piece
+        with PiecewiseRunWriter(path) as w:
+            w.add(qids[:256], scores[:256], positions[:256], docs)
+            raise RuntimeError("search failed")
+    assert path.read_bytes() == before and not (tmp_path / "run.json.tmp").exists()
+    with pytest.raises(AssertionError):                                # a write fails (row count mismatch): re-raised, not swallowed
+        with PiecewiseRunWriter(path) as w:
+            w.add(qids[:256], scores[:255], positions[:255], docs)
+            import time
+            for _ in range(200):
+                if w._writes[0].done():
+                    break
+                time.sleep(0.01)
+            w.add(qids[256:], scores[256:], positions[256:], docs, last=True)
+    assert path.read_bytes() == before and not (tmp_path / "run.json.tmp").exists()

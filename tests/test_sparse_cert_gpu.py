@@ -342,3 +342,32 @@ def test_long_queries_take_the_scalar_ordered_sum(forced):
     _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, 100)
     st = idx.cert_stats()
     assert st["searches"] == 1 and st["redone_exact"] <= nq // 4 and st["candidates_rescored"] > 0
+
+
+def test_query_set_in_batches_and_without_memory_for_the_scorer(forced, monkeypatch):
+    """sr_sparse_search hands the certified scorer at most 8 192 queries at a time (its workspace is ~200 KB per query) and serves a
+    batch with the exact kernels when that workspace cannot be allocated - the call does not fail, the rows are the same.  Here: batches
+    of 64 (three whole ones and a ragged one), then every batch 'out of memory', then the scorer again (its buffers come back)."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(77)
+    V, N, k = 1500, 40000, 200
+    indptr, ids, vals = _zipf_index(rng, V, N, 40)
+    qi, qc, qv = _zipf_queries(rng, V, 230, 24)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    s1, i1, c1 = _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+    st = idx.cert_stats()
+    assert st["searches"] == 1 and st["queries"] == 230 and st["batches_without_memory"] == 0
+    monkeypatch.setenv("SR_SPARSE_CERT_BATCH", "64")
+    s2, i2, c2 = _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+    st = idx.cert_stats()
+    assert st["searches"] == 1 + 4 and st["queries"] == 460
+    assert np.array_equal(s1, s2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
+    monkeypatch.setenv("SR_SPARSE_CERT_FAKE_OOM", "1")
+    s3, i3, c3 = _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+    st = idx.cert_stats()
+    assert st["searches"] == 5 and st["batches_without_memory"] == 4
+    assert np.array_equal(s1, s3) and np.array_equal(i1, i3)
+    monkeypatch.delenv("SR_SPARSE_CERT_FAKE_OOM")
+    monkeypatch.delenv("SR_SPARSE_CERT_BATCH")
+    s4, i4, c4 = _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+    assert idx.cert_stats()["searches"] == 6 and np.array_equal(s1, s4) and np.array_equal(i1, i4)

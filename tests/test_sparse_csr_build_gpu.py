@@ -73,6 +73,11 @@ def test_csr_build_keeps_insertion_order_inside_a_term_and_handles_the_edges():
     # a term outside the vocabulary is an error, not a wild write
     with pytest.raises(ValueError):
         sparse_csr_build(rows, torch.tensor([2, 2, 4, 0, 0, 2], dtype=torch.int32, device=dev), vals, 4)
+    # sort_docs orders by the digits of [0, n_docs): a row beyond a stale n_docs would leave the lists not ascending - refused
+    with pytest.raises(ValueError, match="n_docs"):
+        sparse_csr_build(rows, cols, vals, 4, n_docs=9, sort_docs=True)
+    ip, r, v = sparse_csr_build(rows, cols, vals, 4, n_docs=9)              # without sort_docs the rows are payload: any value >= 0
+    assert r.tolist() == [1, 5, 5, 1, 9, 0]
 
 
 def test_csr_build_large_and_the_index_it_feeds():
