@@ -124,7 +124,14 @@ def contract_line(res):
     line["drop_in"] = {"retrieval_qps": _get(di, "retrieval_task_with_run_json", "queries_per_s"), "search_knn_qps": _get(di, "search_knn", "queries_per_s")}
     line["encode"] = {"passages_per_s": enc.get("value"), "frac": _get(enc, "roofline", "frac"), "sample_passages": enc.get("sample_passages"),
                       "padded_128_passages_per_s": _get(enc, "padded_batch_128_mode", "passages_per_s")} if enc else None
-    line["sparse"] = {"qps": sp.get("value"), "ms_per_pass": sp.get("ms_per_pass"), "kernel": _get(sp, "roofline", "kernel"),
+    if sp and sp.get("n_gpus", 1) > 1:                    # the doc-sharded leg of a multi-GPU run
+        line["sparse"] = {"qps": sp["value"], "ms_per_pass": sp["ms_per_pass"], "n_gpus": sp["n_gpus"], "sharded": True,
+                          "redone_exact": sum(sp["queries_redone_by_the_exact_kernels"]), "oracle_bit_exact_queries": sp["oracle_bit_exact_queries"]}
+        sp = {}
+    else:
+        line["sparse"] = None
+    if sp:
+      line["sparse"] = {"qps": sp.get("value"), "ms_per_pass": sp.get("ms_per_pass"), "kernel": _get(sp, "roofline", "kernel"),
                       "bound": _get(sp, "roofline", "bound"), "achieved_GBps": _get(sp, "roofline", "achieved"),
                       "frac": _get(sp, "roofline", "frac"), "traffic": _get(sp, "roofline", "traffic"),
                       "kernel_ms_per_pass": _get(sp, "roofline", "kernel_ms_per_pass"),
@@ -142,7 +149,7 @@ def contract_line(res):
                       "sweep": {"cells": len(sweep), "min_qps": min((x["queries_per_s"] for x in sweep), default=None),
                                 "max_L0_q": max((x["L0_q"] for x in sweep), default=None),
                                 "redone_exact": sum(x["queries_redone_by_the_exact_kernels"] for x in sweep),
-                                "all_bit_exact": all(x.get("queries_bit_exact_vs_oracle", 0) >= 64 for x in sweep)} if sweep else None} if sp else None
+                                "all_bit_exact": all(x.get("queries_bit_exact_vs_oracle", 0) >= 64 for x in sweep)} if sweep else None}
     line["config5_8b"] = {"encode_passages_per_s": _get(c5, "encode", "value"), "encode_frac": _get(c5, "encode", "roofline", "frac"),
                           "score_shard_qps": _get(c5, "score_shard_filtered", "queries_per_s")} if c5 else None
     line["small_batch"] = [{"nq": x["nq"], "frac_hbm": x["frac"]} for x in (res.get("small_batch") or [])] or None
@@ -519,6 +526,74 @@ def sparse_leg(args, device):
     if not args.no_sparse_sweep:
         out["sparse_sweep"] = sparse_sweep_leg(args, device)
     return out
+
+
+def sparse_sharded_leg(args, device, rank, world, share_gpu):
+    """BASELINE.json configs[2] doc-sharded over the ranks of a multi-GPU run (the reference scores on one process after a merge_indexes
+    pass, eval_sparse.py:98-114): every rank builds the SAME synthetic index from the same seed, keeps the postings of the docs
+    r, r + W, ... (what `eval_sparse.py --task_name indexing` leaves in index_dir_{r}), scores its shard and the per-shard top-k meet in
+    ONE gather + sr_topk_merge on rank 0 (distributed.ShardedSparseRetriever).  Timed like the headline: barrier + synchronize on both
+    sides, max over ranks.  A sample of the merged rows is compared with the oracle on rank 0."""
+    import synth
+    from scaling_retriever_amd.distributed import ShardedSparseRetriever
+    from scaling_retriever_amd.scoring import sparse_csr_expand_terms
+    V, N, L0_d, L0_q, nq, k = 128256, args.sparse_docs, 128, 32, min(args.n_queries, 6980), min(args.topk, 1000)
+    indptr, doc_ids, vals, _ = synth.build_index(V, N, L0_d, device, 3)
+    q_indptr, q_cols, q_vals = synth.build_queries(V, nq, L0_q, device, 4)
+    # this rank's shard: the postings of its docs, term order kept
+    mine = (doc_ids % world) == rank
+    term = sparse_csr_expand_terms(indptr, doc_ids.numel())
+    counts = torch.bincount(term[mine].long(), minlength=V)
+    s_indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(counts, 0)])
+    shard = ShardedSparseRetriever(s_indptr, doc_ids[mine].to(torch.int64), vals[mine], N, rank=rank, world_size=world, device=device)
+    nnz_local = int(mine.sum().item())
+    host = None
+    if rank == 0 and args.sparse_cpu_queries > 0:
+        host = (indptr.cpu().numpy(), doc_ids.cpu().numpy(), vals.cpu().numpy())
+    del indptr, doc_ids, vals, mine, term
+    torch.cuda.empty_cache()
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    out = shard.search(q_indptr, q_cols, q_vals, k)          # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    steps = 3
+    for _ in range(steps):
+        out = shard.search(q_indptr, q_cols, q_vals, k)
+    barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if share_gpu else device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item()) / steps
+    cs = shard.index.cert_stats()
+    info = torch.tensor([nnz_local, cs["redone_exact"], cs["present"]], dtype=torch.int64, device="cpu" if share_gpu else device)
+    got = [torch.zeros_like(info) for _ in range(world)]
+    dist.all_gather(got, info)
+    res = None
+    if rank == 0:
+        s, i, c = out
+        checked = 0
+        if host is not None:
+            from oracle import scoring as O
+            nqc = min(nq, max(8, args.sparse_cpu_queries // 12))
+            hq = (q_indptr[:nqc + 1].cpu().numpy(), q_cols[:nqc * L0_q].cpu().numpy(), q_vals[:nqc * L0_q].cpu().numpy())
+            oi, os_, oc = O.sparse_retrieve_c(host[0], host[1], host[2], hq[0], hq[1], hq[2], k, 0.0, N, q_threads=4,
+                                              inner_threads=max(1, min(32, os.cpu_count() or 1) // 4))
+            gi, gs, gc = i[:nqc].cpu().numpy(), s[:nqc].cpu().numpy(), c[:nqc].cpu().numpy()
+            for q in range(nqc):
+                assert gc[q] == oc[q] and np.array_equal(gi[q, :gc[q]], oi[q, :oc[q]]) and np.array_equal(gs[q, :gc[q]], os_[q, :oc[q]]), q
+            checked = nqc
+        res = {"metric": "sparse inverted-index queries/s, corpus doc-sharded over the ranks, ONE gather of the per-shard top-k + merge",
+               "value": round(nq / dt, 1), "unit": "queries/s", "ms_per_pass": round(dt * 1e3, 1), "n_gpus": world,
+               "config": {"V": V, "N": N, "L0_d": L0_d, "L0_q": L0_q, "nq": nq, "k": k},
+               "shard_postings": [int(x[0]) for x in got], "certified_scorer_on_every_rank": all(int(x[2]) == 1 for x in got),
+               "queries_redone_by_the_exact_kernels": [int(x[1]) for x in got], "oracle_bit_exact_queries": checked}
+        log("[sparse sharded]", res)
+    del shard
+    torch.cuda.empty_cache()
+    return res
 
 
 def sparse_build_only(indptr, doc_ids, vals, V, N, device):
@@ -1037,6 +1112,7 @@ def main():
     ap.add_argument("--token-budget", type=int, default=16384, help="real tokens per doc_encode batch of the encode leg")
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-sparse", action="store_true")
+    ap.add_argument("--sparse-docs", type=int, default=8_841_823, help="collection size of the doc-sharded sparse leg of a multi-GPU run")
     ap.add_argument("--no-config5", action="store_true", help="skip the Lion-DS-8B leg (BASELINE.json configs[4], one GPU's share)")
     ap.add_argument("--config5-passages", type=int, default=8192)
     ap.add_argument("--sparse-cpu-queries", type=int, default=768, help="bounded CPU sample of the sparse baseline (~10 s per threading shape)")
@@ -1519,6 +1595,10 @@ def main():
         if not args.no_sparse_index:
             torch.cuda.empty_cache()
             sparse["sparse_index"] = sparse_index_leg(args, device)
+    if world > 1 and not args.no_sparse:                  # configs[2] doc-sharded over the ranks (every rank takes part)
+        del model
+        torch.cuda.empty_cache()
+        sparse = sparse_sharded_leg(args, device, rank, world, share_gpu)
     config5 = None
     if rank == 0 and world == 1 and not args.no_config5 and not args.layers:
         torch.cuda.empty_cache()

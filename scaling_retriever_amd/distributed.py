@@ -47,9 +47,14 @@ def unpack_topk(packed):
     return scores, ids
 
 
-def gather_topk(scores, ids, dst=0, group=None, compact=True):
+def gather_topk(scores, ids, dst=0, group=None, compact=None):
     """The single data collective of doc-sharded retrieval.  Every rank passes its local (scores, global ids) [nq, k]; rank `dst`
     gets (scores [W, nq, k], ids [W, nq, k]), the others (None, None).
+
+    compact=None (default): over RCCL the padded [nq, k] buffer travels as it is, in ONE gather and without a host sync - 55.8 MB per
+    rank at MS MARCO Dev, 0.4 ms on a rank's own xGMI link (153 GB/s; the 7 senders use 7 different links of rank dst) - because what
+    compaction saves there (0.3 ms at W = 8) is what its size exchange, its host syncs and the re-padding on rank dst cost; over gloo
+    (CPU tests, ranks sharing a GPU: a transport of ~1 GB/s) the valid slots alone travel.  True / False force either.
 
     compact: ship only the VALID slots.  With the threshold exchange a dense shard returns what can reach the global top-k -
     193 of 1 000 slots per query on average at W = 8 - and the rest of its [nq, k] output is padding (id -1); a sparse shard pads
@@ -65,6 +70,8 @@ def gather_topk(scores, ids, dst=0, group=None, compact=True):
     device = packed.device
     use_cpu = dist.get_backend(group) == "gloo"       # gloo (CPU tests, or several ranks sharing one GPU) has no CUDA collectives
     nq, k = packed.shape
+    if compact is None:
+        compact = use_cpu
     if compact:
         valid = ids >= 0
         counts = valid.sum(1).to(torch.int64)
@@ -221,11 +228,14 @@ class ShardedSparseRetriever:
             raise ValueError(f"rank {r} of {W}: the index holds documents of other shards (global row % W != rank)")
         local = torch.div(g - r, W, rounding_mode="floor").to(torch.int32)
         indptr_t, vals_t = to(indptr, torch.int64), to(vals, torch.float32)
-        if local.numel():      # posting lists sorted by doc (a merged / bucketed build is not necessarily)
-            term = torch.repeat_interleave(torch.arange(indptr_t.numel() - 1, device=device), indptr_t[1:] - indptr_t[:-1])
-            order = torch.argsort(term * (int(local.max().item()) + 1) + local.long())
-            local, vals_t = local[order].contiguous(), vals_t[order].contiguous()
         self.n_local = max(1, len(range(r, int(n_docs_global), W)))
+        if local.numel():      # posting lists sorted by doc (a merged / bucketed build is not necessarily): this library's stable radix
+            # passes over the local rows, then over the terms (sr_sparse_csr_build with sort_docs, csrc/sparse_build.hip)
+            from .scoring import sparse_csr_build, sparse_csr_expand_terms
+            term = sparse_csr_expand_terms(indptr_t, local.numel())
+            n_rows = max(self.n_local, int(local.max().item()) + 1)
+            indptr2, local, vals_t = sparse_csr_build(local, term, vals_t, indptr_t.numel() - 1, n_docs=n_rows, sort_docs=True)
+            assert torch.equal(indptr2, indptr_t)
         self.index = SparseIndexHIP(indptr_t, local, vals_t, self.n_local, device=device)
 
     def search(self, q_indptr, q_cols, q_vals, k, threshold=0.0, dst=0):

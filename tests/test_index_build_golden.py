@@ -172,4 +172,6 @@ def test_sparse_indexer_index_matches_the_reference_run(gold, tmp_path, monkeypa
         n_ref = int(gold[f"{tag}:nb_docs"])
         assert res["index"].nb_docs() == (n_ref if W == 1 else (n_ref - 1) * W + rank + 1)
     assert list(doc_ids.keys()) == gold[f"{tag}:doc_ids_keys"].tolist() and list(doc_ids.values()) == gold[f"{tag}:doc_ids_vals"].tolist()
-    assert stats["L0_d"] == float(gold[f"{tag}:L0_d"])
+    # L0_d = mean over the batches of torch's fp32 .mean() of the rows' non-zero counts (losses/regulariaztion.py:13-14): the fixture's
+    # run took that mean on the CPU (sum / n), this one on the GPU (sum * (1 / n)): one rounding apart
+    assert abs(stats["L0_d"] - float(gold[f"{tag}:L0_d"])) <= 2e-7 * float(gold[f"{tag}:L0_d"])
