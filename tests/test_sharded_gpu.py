@@ -67,7 +67,7 @@ def test_bench_multi_rank_path_dry_run():
     env.pop("WORLD_SIZE", None)
     # no launcher on the command line: `bench.py --gpus 2` starts its two ranks itself (the driver's command shape)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-docs", "300000",
-           "--encode-passages", "4096", "--layers", "2", "--no-cpu-baseline"]
+           "--encode-passages", "4096", "--layers", "2", "--no-cpu-baseline", "--sparse-docs", "200000"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -76,11 +76,15 @@ def test_bench_multi_rank_path_dry_run():
     assert res["config"]["ranks"]["world_size"] == 2 and len(res["config"]["ranks"]["shard_docs"]) == 2
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1 and res["cpu_baseline"] is None
     assert res["small_batch"][0]["nq"] == 1
-    assert res["encode"]["passages_per_s"] > 0 and res["encode"]["sample_passages"] == 4096 and res["sparse"] is None
+    assert res["encode"]["passages_per_s"] > 0 and res["encode"]["sample_passages"] == 4096
+    # BASELINE configs[2] doc-sharded over the two ranks: one gather of the per-shard top-k, merged rows checked against the oracle
+    assert res["sparse"]["sharded"] is True and res["sparse"]["n_gpus"] == 2 and res["sparse"]["qps"] > 0
+    assert res["sparse"]["oracle_bit_exact_queries"] >= 8 and res["sparse"]["redone_exact"] == 0
     assert len(line) < 4096 and out.stdout.rstrip().endswith(line)             # the contract line is the LAST line of stdout, and compact
     # the full record goes to stderr (and to gpurun_out/bench_detail.json)
     detail = json.loads([l for l in out.stderr.splitlines() if l.startswith("[bench detail] ")][-1][len("[bench detail] "):])
     assert detail["fast_mode"]["value"] > 0 and detail["value"] == res["value"] and detail["config"]["ranks"] == res["config"]["ranks"]
+    assert len(detail["sparse"]["shard_postings"]) == 2 and detail["sparse"]["certified_scorer_on_every_rank"] is True
 
 
 @pytest.mark.parametrize("W", [2, 8])
