@@ -620,7 +620,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 #ifdef KL_NO_STAGING
     constexpr bool KL_STAGED = false;
 #else
-    constexpr bool KL_STAGED = KL == 1 && (BEPI == EPI_STORE_BF16 || BEPI == EPI_SWIGLU);
+    constexpr bool KL_STAGED = KL == 1 && (BEPI == EPI_STORE_BF16 || BEPI == EPI_SWIGLU || BEPI == EPI_QKV_ROPE);
 #endif
     // The workgroup is persistent: whatever an epilogue computes from the lane index alone (feature offsets, n % head_dim, swizzled
     // LDS offsets ...) is invariant in the TILE loop, and hipcc hoists it above the k-loop and carries it through - behind the
@@ -665,6 +665,40 @@ void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = (gt[r] * __builtin_amdgcn_rcpf(1.f + __expf(-gt[r]))) * up[r];   // as EPI_SWIGLU below
                     put((i >> 1) * 16 + fg_e * 4, y);
+                }
+            } else if constexpr (BEPI == EPI_QKV_ROPE) {
+                // q / k heads rotated in fp32 on the accumulators (the same sr_rope_lo / sr_rope_hi on the same MFMA chains as the direct-store
+                // epilogue below: the same bits), v heads stored as they are.  A wave's 128 features are whole heads (64 or 128 wide) that start
+                // at a multiple of 128, so d = n % head_dim needs no division and the rotation partner of block i is block i + head_dim / 32 of
+                // the same lane.  Two table loads (L2-resident, 16 bytes each) per pair of blocks; nothing here is invariant in the tile loop
+                // except through frow_e / fg_e, which are opaque.
+                const int mtok = mrow + frow_e;
+                const int pos_t = mtok < g.M ? g.pos[mtok] : 0;
+                const int hd2 = g.head_dim >> 1;
+                const float* ct = g.rope_cos + (int64_t)pos_t * hd2 + fg_e * 4;
+                const float* st = g.rope_sin + (int64_t)pos_t * hd2 + fg_e * 4;
+                if (n0 + wn * NB * 16 < g.n_rope) {
+                    if (g.head_dim == 64) {
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            if ((i & 2) != 0) continue;                  // blocks 2, 3, 6, 7: written with their partners 0, 1, 4, 5
+                            const f32x4 c = *reinterpret_cast<const f32x4*>(ct + (i & 1) * 16), sn = *reinterpret_cast<const f32x4*>(st + (i & 1) * 16);
+                            const f32x4 x1 = acc[i][j], x2 = acc[i + 2][j];
+                            put(i * 16 + fg_e * 4, sr_rope_lo(x1, x2, c, sn));
+                            put((i + 2) * 16 + fg_e * 4, sr_rope_hi(x1, x2, c, sn));
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NB / 2; ++i) {
+                            const f32x4 c = *reinterpret_cast<const f32x4*>(ct + i * 16), sn = *reinterpret_cast<const f32x4*>(st + i * 16);
+                            const f32x4 x1 = acc[i][j], x2 = acc[i + 4][j];
+                            put(i * 16 + fg_e * 4, sr_rope_lo(x1, x2, c, sn));
+                            put((i + 4) * 16 + fg_e * 4, sr_rope_hi(x1, x2, c, sn));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) put(i * 16 + fg_e * 4, acc[i][j]);
                 }
             }
             // rows back out: lane_e -> (token row, 16-byte piece)
@@ -1100,17 +1134,18 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         // everywhere (A/B); SR_GEMM_BIG=4w: the four-wave loop also for the fp32 regime's fp16-plane GEMMs, which have staged
         // epilogues too but measure 2 % SLOWER on it (query encode 300 -> 307 ms: K' = 3 K k-steps per tile, the epilogue does
         // not matter there and the 8-wave loop's second wave per SIMD does) - tests force it to keep that path covered.
-        // The QKV + RoPE epilogues stay on the 8-wave loop (12 % of a layer's GEMM work): every output needs an accumulator AND its
-        // rotation partner plus two table loads, and behind the asm-pinned loop hipcc then spills to scratch - inside the k-loop
-        // before the lane coordinates were made opaque (fp32-regime query encode 300 -> 670 ms), in the epilogue after.
+        // The bf16 regime's QKV + RoPE epilogue (12 % of a layer's GEMM work) joined in round 6: rotation on the accumulators, staged
+        // through LDS like the plain store.  The fp32 regime's QKV epilogues (fp32 output, fp16-plane operands) stay on the 8-wave loop.
         // tests/test_abi.py holds every four-wave instantiation to zero scratch.  The loop's buffer descriptors address a tile's
         // rows with 32-bit byte offsets: 256 rows x 2 K bytes must stay below 2^31.
         const char* big = sr_dev_getenv("SR_GEMM_BIG");
         const bool want8 = big && big[0] == '8', want4 = big && big[0] == '4';
-        constexpr bool STAGED_BF16 = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32;
+        constexpr bool STAGED_BF16 = EPI == EPI_STORE_BF16 || EPI == EPI_SWIGLU || EPI == EPI_STORE_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE;
         constexpr bool STAGED_F16 = EPI == EPI_RESID_F32_H || EPI == EPI_SWIGLU_SPLIT_H;
         if constexpr (STAGED_BF16 || STAGED_F16) {
-            if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && (STAGED_BF16 || want4) && !(env && *env == '0'))
+            // QKV + RoPE: a wave's 128 features must lie on one side of n_rope (two heads of 64 per wave)
+            const bool rope_ok = EPI != EPI_QKV_ROPE || g.n_rope % 128 == 0;
+            if (g.K / G_BK >= 4 && (int64_t)g.K * 512 < (1ll << 31) && !want8 && (STAGED_BF16 || want4) && rope_ok && !(env && *env == '0'))
                 return launch_cfg<EPI, 2, 2, 8, 8, true, 2, 1>(g, s);
         }
     }

@@ -526,8 +526,8 @@ def test_gemm_four_wave_loop_equals_eight_wave_loop(M, N, K, monkeypatch):
     C = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     L.check(lib.sr_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, 4, C.data_ptr(), None, L.stream_ptr()), "sr_gemm_bf16")
     assert torch.equal(C, ref[0])
-    # QKV + RoPE (bf16 out; 8-wave loop under either setting - a regression guard for its shared rotation helper) for both head
-    # sizes, and the fp32 regime's scaled fp16 GEMM (+= into fp32) on the four-wave loop (SR_GEMM_BIG=4w)
+    # QKV + RoPE (bf16 out): the four-wave loop's staged epilogue (rotation on the accumulators, round 6) against the 8-wave loop's
+    # direct stores, for both head sizes; and the fp32 regime's scaled fp16 GEMM (+= into fp32) on the four-wave loop (SR_GEMM_BIG=4w)
     if N % 128 == 0:
         pos = torch.randint(0, 300, (M,), device="cuda", generator=g).to(torch.int32)
         for hd in (64, 128):
