@@ -733,7 +733,7 @@ def sparse_csr_expand_terms_cached(indptr, nnz):
 
 
 def sparse_sweep_leg(args, device):
-    """SURVEY.md 8(d) config 3 "as a function of L0": L0_d in {64, 128, 256} x L0_q in {16, 32, 64} on the Zipf(1.0) index, and one
+    """SURVEY.md 8(d) config 3 "as a function of L0": L0_d in {64, 128, 256} x L0_q in {16, 32, 64} (+ 128, 256 at L0_d = 128) on the Zipf(1.0) index, and one
     flatter index (df ~ r^-0.7 capped at N / 5: no term in a quarter of the documents, so no dense column and the per-query
     kernel serves every block) - queries/s, which kernel ran, and ids + fp32 scores of the first queries compared bit for bit with the
     oracle's C port of numba_score_float + select_topk (indexer.py:315-344) at full collection size."""
@@ -747,7 +747,10 @@ def sparse_sweep_leg(args, device):
             indptr, doc_ids, vals, df = synth.build_index(V, N, L0_d, device, 3, alpha=alpha, cap=cap)
             idx = SparseIndexHIP(indptr, doc_ids, vals, N, device=device)
             host = None
-            for L0_q in (16, 32, 64):
+            # L0_q 128 / 256 (on the L0_d = 128 indexes): queries with 70-150 terms outside the 128 heaviest lists - more than the 64 a
+            # scatter wave stages; the certified scorer adds the rest by its plain walk, `queries_redone_by_the_exact_kernels` says how
+            # many it still hands back
+            for L0_q in ((16, 32, 64, 128, 256) if L0_d == 128 else (16, 32, 64)):
                 q_indptr, q_cols, q_vals = synth.build_queries(V, nq, L0_q, device, 4, alpha=alpha)
                 s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
                 torch.cuda.synchronize()

@@ -170,7 +170,7 @@ int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, in
  * pipe for the heavy terms, 16-bit fixed-point LDS atomics for the others), keeps the k + 1024 best keys, certifies that the
  * true top-k lies among them, re-scores those candidates with the reference's exact fp32 chain
  * (scaling_retriever/indexer.py:324-340) from the forward index and returns their exact top-k: the same bits as the exact
- * kernels.  Queries it cannot certify (a negative or unordered query, more than 64 rare terms, a band of undecided keys
+ * kernels.  Queries it cannot certify (a negative or unordered query, more than 256 rare terms, a band of undecided keys
  * wider than 1024, fewer than k docs with a non-zero key) are re-done by the exact kernels inside the same call.
  * out8: [0] 1 if this index has the scorer, [1] heavy terms on the matrix pipe, [2] searches it ran, [3] queries it was
  * given, [4] queries re-done by the exact kernels, [5] doc tiles of 1024, [6] candidates whose exact chain the certified
@@ -180,8 +180,8 @@ int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, in
  * take ~22 bytes per posting + 8 bytes per (term, 1 024-doc tile), at most half of the free device memory: 25 GB at the MS MARCO
  * shape); SR_LOG=1 prints one line per index on stderr saying what was built, with how many bytes, or why not.
  * Limits of the fast path, beyond which a query is served by the exact kernels (same results, about a quarter of the speed):
- * k <= SR_MAX_TOPK - 1024 = 3 072 (the band of extra keys), <= 256 query terms, <= 64 of them outside the index's 128 heaviest
- * terms, terms strictly ascending, values >= 0, at least 8 (k + 1 024) documents in the collection.                            */
+ * k <= SR_MAX_TOPK - 1024 = 3 072 (the band of extra keys), <= 256 query terms (those outside the index's 128 heaviest terms beyond
+ * the first 64 take a slower walk inside the same kernel), terms strictly ascending, values >= 0, at least 8 (k + 1 024) documents in the collection.                            */
 int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8);
 /* Test hook for the error bound: enable = 1 / 0 switches the recording of the stage-1 keys of every (query, doc) pair on /
  * off; enable = 2 copies the last search's keys to h_keys uint16 [nq_pad][n_tiles * 1024] (nq_pad = nq rounded up to 32)

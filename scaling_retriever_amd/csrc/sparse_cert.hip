@@ -37,7 +37,10 @@
 #define SC_QB 32                      // queries per workgroup (one MFMA N block)
 #define SC_MB (SC_DT / 32)            // 32-doc M blocks per tile
 #define SC_PITCH_W (SC_DT / 2 + 2)    // 32-bit words per query row of the LDS tile (two 16-bit slots per word; + 2: bank spread)
-#define SC_MAXR 64                    // rare terms per query (one lane each)
+#define SC_MAXR 64                    // rare terms per group: one lane of a scatter wave each
+#define SC_MAXG 4                     // groups per query: the first runs through the staged, flattened walk, the others (queries with more than 64
+                                      // rare terms) through a plain per-lane walk in the same step
+#define SC_MAXRT (SC_MAXR * SC_MAXG)  // rare terms per query
 #define SC_BAND 1024                  // keys kept beyond k
 #define SC_CAND_CAP 16384             // candidate slots per query and launch
 #define SC_MAXQT 256                  // terms of a fast-path query
@@ -70,8 +73,8 @@ struct SparseCert {
     // per-call plan (grown on demand)
     int64_t nq_cap = 0;
     _Float16* bfrag = nullptr;        // [nq_pad / 32][KS][64][8]: MFMA B fragments (k = dense slot, col = query)
-    int32_t* rare_term = nullptr;     // [nq_pad][SC_MAXR], -1 = none
-    float* rare_w = nullptr;          // [nq_pad][SC_MAXR]: q_t * s_q * 65535 / vscale
+    int32_t* rare_term = nullptr;     // [nq_pad][SC_MAXRT], -1 = none
+    float* rare_w = nullptr;          // [nq_pad][SC_MAXRT]: q_t * s_q * 65535 / vscale
     float* cq = nullptr;              // [nq_pad]: MFMA sum -> [0, 1]
     float* sq = nullptr;              // [nq_pad]: score -> [0, 0.98]
     int32_t* n_rare = nullptr;        // [nq_pad]
@@ -426,8 +429,11 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
     const int64_t nq_pad = (a.nq + SC_QB - 1) / SC_QB * SC_QB;
     if (q >= nq_pad) return;
     // defaults: a query outside the fast path contributes nothing to stage 1
-    a.rare_term[q * SC_MAXR + lane] = -1;
-    a.rare_w[q * SC_MAXR + lane] = 0.f;
+#pragma unroll
+    for (int g = 0; g < SC_MAXG; ++g) {
+        a.rare_term[q * SC_MAXRT + g * SC_MAXR + lane] = -1;
+        a.rare_w[q * SC_MAXRT + g * SC_MAXR + lane] = 0.f;
+    }
     if (lane == 0) { a.cq[q] = 0.f; a.sq[q] = 0.f; a.n_rare[q] = 0; a.n_qt[q] = 0; a.n_drop[q] = 0; a.elig[q] = 0; a.overflow[q] = 0; }
     if (q >= a.nq) return;
     const int64_t tb = a.q_indptr[q], te = a.q_indptr[q + 1];
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
         nd += __shfl_xor(nd, off);
     }
     ok = __ballot(!ok) == 0;
-    if (!ok || nr > SC_MAXR || !(tot > 0.f) || !(tot < 1.0e30f)) return;
+    if (!ok || nr > SC_MAXRT || !(tot > 0.f) || !(tot < 1.0e30f)) return;
     const float sq = 0.98f / (tot * 1.0001f);               // every real-arithmetic score * sq <= 0.98
     // dense operand: q_t * sq * 2^e with the largest one in [2^13, 2^14); all of them normal fp16 numbers
     float two_e = 1.f;
@@ -496,8 +502,8 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
         }
         if (is_r) {
             const int j = rbase + __popcll(m & ((1ull << lane) - 1ull));
-            a.rare_term[q * SC_MAXR + j] = term[c];
-            a.rare_w[q * SC_MAXR + j] = wr;
+            a.rare_term[q * SC_MAXRT + j] = term[c];
+            a.rare_w[q * SC_MAXRT + j] = wr;
         }
         rbase += __popcll(m);
     }
@@ -661,6 +667,34 @@ __device__ __noinline__ void cert_overflow_windows(unsigned short* mark, const u
                 if (tail == 0 || tail == 3) cert_add_posting(row, pw[it].z, wv);
                 if (tail == 0) cert_add_posting(row, pw[it].w, wv);
             }
+    }
+}
+
+// The rare terms of a query beyond its first 64 (group g >= 1, lane j = rare term 64 g + j), for the wave's 4 queries and one tile: the term,
+// its E word and, for a run, its start in table S are looked up on the spot and a lane walks its run posting by posting.  Not inlined, like
+// the overflow path above: the kernel's registers are sized for the staged walk.
+__device__ __noinline__ void cert_extra_groups(const int32_t* rare_term, const float* rare_w, const uint32_t* E, const uint32_t* S, const uint32_t* P,
+                                               int e_stride, int s_stride, int64_t q0, int ng0, int ng1, int ng2, int ng3, int tile, uint32_t* wrow) {
+    const int lane = threadIdx.x & 63;
+    const int ngq[4] = {ng0, ng1, ng2, ng3};
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        uint32_t* const row = wrow + qi * SC_PITCH_W;
+#pragma unroll 1
+        for (int g = 1; g < ngq[qi]; ++g) {
+            const int32_t t = rare_term[(q0 + qi) * SC_MAXRT + g * SC_MAXR + lane];
+            if (t < 0 || (SC_DIAG & 1)) continue;
+            const uint32_t e = E[(uint32_t)t * (uint32_t)e_stride + (uint32_t)tile];
+            if (e == 0u) continue;
+            const float w = (float)(_Float16)rare_w[(q0 + qi) * SC_MAXRT + g * SC_MAXR + lane];
+            if ((e >> 16) != 0xffffu) {
+                cert_add_posting(row, e, w);                     // the term's only posting in this tile
+            } else {
+                const uint32_t p0 = S[(int64_t)t * s_stride + tile];
+                const uint32_t len = e & 0xffffu;
+                for (uint32_t u = 0; u < len; ++u) cert_add_posting(row, P[p0 + u], w);
+            }
+        }
     }
 }
 
@@ -850,7 +884,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const int64_t q = (int64_t)qb * SC_QB + sw * 4 + qi;
-            term[qi] = a.rare_term[q * SC_MAXR + lane];
+            term[qi] = a.rare_term[q * SC_MAXRT + lane];
             cur[qi] = term[qi] >= 0 ? a.S[(int64_t)term[qi] * a.s_stride + tile0] : 0u;
         }
         // the E words of tile pair g (tiles 2 g, 2 g + 1); pairs behind the chunk read the row's zero padding or a later chunk's words
@@ -890,7 +924,7 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
         _Float16* const tab_w = reinterpret_cast<_Float16*>(tab_delta + 256);
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi)
-            tab_w[qi * 64 + lane] = (_Float16)a.rare_w[((int64_t)qb * SC_QB + sw * 4 + qi) * SC_MAXR + lane];
+            tab_w[qi * 64 + lane] = (_Float16)a.rare_w[((int64_t)qb * SC_QB + sw * 4 + qi) * SC_MAXRT + lane];
         uint4 pp[SC_ITERS];
         uint32_t rid8[SC_ITERS / 4];      // run id of the lane's quad per step, 8 bits each
         uint32_t tail2;                   // tail code per step, 2 bits each
@@ -994,10 +1028,24 @@ __global__ __launch_bounds__(1024) void cert_score_kernel(CertArgs a) {
                 for (int qi = 0; qi < 4; ++qi) ecur[qi].x = ecur[qi].y;
             }
         };
+        // Queries with more than 64 rare terms: the terms beyond the first group (lane j of group g = rare term 64 g + j) are added in the
+        // same step by a plain walk - the term, its E word and, for a run, its start in table S are looked up on the spot and a lane walks
+        // its run posting by posting.  No prefetch, no flattening: a step of such a block takes a few memory round trips longer, which
+        // only queries of 65-256 rare terms pay (they were handed to the exact kernels before, at a quarter of this speed).  Integer adds
+        // commute: the keys do not depend on which path added a posting.
+        int ngq[4], ng_max = 1;
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            ngq[qi] = __builtin_amdgcn_readfirstlane((a.n_rare[(int64_t)qb * SC_QB + sw * 4 + qi] + SC_MAXR - 1) / SC_MAXR);
+            ng_max = ngq[qi] > ng_max ? ngq[qi] : ng_max;
+        }
         stage_all(tile0);
         advance_queue(tile0);
         for (int tile = tile0; tile < tile1; ++tile) {
             consume_all(slots + (tile & 1) * SC_SLOT_WORDS);     // the loads were issued a step ago
+            if (ng_max > 1)                                      // wave-uniform, off at the MSMARCO shape
+                cert_extra_groups(a.rare_term, a.rare_w, a.E, a.S, a.P, a.e_stride, a.s_stride, (int64_t)qb * SC_QB + sw * 4, ngq[0], ngq[1], ngq[2], ngq[3],
+                                  tile, slots + (tile & 1) * SC_SLOT_WORDS + sw * 4 * SC_PITCH_W);
             SC_STAMP(1);                                         // end of the adds
             stage_all(tile + 1);
             advance_queue(tile + 1);
@@ -1324,8 +1372,8 @@ static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {
     if (nq_pad > c->nq_cap) {
         c->nq_cap = 0;
         ok = ok && cert_realloc(c->bfrag, (size_t)nq_pad * (size_t)c->T);
-        ok = ok && cert_realloc(c->rare_term, (size_t)nq_pad * SC_MAXR);
-        ok = ok && cert_realloc(c->rare_w, (size_t)nq_pad * SC_MAXR);
+        ok = ok && cert_realloc(c->rare_term, (size_t)nq_pad * SC_MAXRT);
+        ok = ok && cert_realloc(c->rare_w, (size_t)nq_pad * SC_MAXRT);
         ok = ok && cert_realloc(c->cq, (size_t)nq_pad);
         ok = ok && cert_realloc(c->sq, (size_t)nq_pad);
         ok = ok && cert_realloc(c->n_rare, (size_t)nq_pad);

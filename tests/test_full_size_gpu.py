@@ -99,6 +99,10 @@ def test_full_msmarco_shape_sparse_search_bit_exact():
     q_indptr, q_cols, q_vals = synth.build_queries(V, 256, 32, dev, 4)
     idx = SparseIndexHIP(indptr, doc_ids, vals, N, device=dev)
     s, i, c = idx.search(q_indptr, q_cols, q_vals, k)
+    # which path served the queries: the certified two-stage scorer, all 256 of them (none handed to the exact kernels, no batch
+    # without memory for its buffers) - what is compared with the oracle below is the product's fast path
+    st = idx.cert_stats()
+    assert st["present"] == 1 and st["searches"] == 1 and st["queries"] == 256 and st["redone_exact"] == 0 and st["batches_without_memory"] == 0, st
     assert bool((c == k).all()) and bool((s[:, :-1] >= s[:, 1:]).all()) and bool((s[:, -1] > 0).all())
     assert bool(((i >= 0) & (i < N)).all())
     assert all(len(set(r.tolist())) == k for r in i[:8])                       # no duplicate docs in a row
@@ -115,3 +119,15 @@ def test_full_msmarco_shape_sparse_search_bit_exact():
     for q in range(n_check):
         assert oc[q] == int(c[q])
         assert np.array_equal(i[q].cpu().numpy(), oi[q]) and np.array_equal(s[q].cpu().numpy(), os_[q]), q
+    # long queries at full size: 128 and 200 terms, 70-110 of them outside the 128 heaviest lists - beyond the first 64 rare terms the
+    # scorer's plain walk adds them (round 6; the exact kernels served such queries before).  Still certified, still the oracle's bits.
+    for L0_q, n_q in ((128, 64), (200, 32)):
+        ql_indptr, ql_cols, ql_vals = synth.build_queries(V, n_q, L0_q, dev, 40 + L0_q)
+        st0 = idx.cert_stats()
+        sl, il, cl = idx.search(ql_indptr, ql_cols, ql_vals, k)
+        st1 = idx.cert_stats()
+        assert st1["queries"] - st0["queries"] == n_q and st1["redone_exact"] - st0["redone_exact"] == 0, (L0_q, st0, st1)
+        hq = (ql_indptr.cpu().numpy(), ql_cols.cpu().numpy(), ql_vals.cpu().numpy())
+        oi, os_, oc = SC.sparse_retrieve_c(*h, *hq, k, 0.0, N, q_threads=max(1, min(32, (os.cpu_count() or 8) // 4)), inner_threads=4)
+        for q in range(n_q):
+            assert oc[q] == int(cl[q]) and np.array_equal(il[q].cpu().numpy(), oi[q]) and np.array_equal(sl[q].cpu().numpy(), os_[q]), (L0_q, q)
