@@ -370,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
     stage(0);
     stage(1);
     int buf = 0;
+    bool carried = false;       // the previous tile's last k-step already read this tile's first fragments (and its barriers vouched for k-step 0)
     for (;;) {
         const int64_t row0 = st_row0;           // this tile (set_tile moves st_* on to the next one inside the k-loop)
         const int q0 = st_q0;
@@ -386,10 +387,16 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // k-steps 0 and 1 of this tile are on their way (issued above, or under the previous tile's last two k-steps);
-        // the barrier also ends the previous tile's epilogue reads of xy_s
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // k-steps 0 and 1 of this tile are on their way (issued above, or under the previous tile's last two k-steps).  The barrier ends
+        // the previous tile's epilogue reads of xy_s / qa_s / tau_s before they are refilled below.  A carried tile needs no more than
+        // that: k-step 0 landed before the previous tile's last barrier, k-step 1 is drained by this tile's first k-step barrier, and
+        // the epilogue's stores of candidates stay in flight (a bare s_barrier: __syncthreads() would wait for every one of them)
+        if (carried) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         const unsigned long long st0 = SR_SPLIT_STAMPS_PTR(a) ? __builtin_amdgcn_s_memrealtime() : 0;
         int lane_t = lane;            // opaque: see set_tile
         asm volatile("" : "+v"(lane_t));
@@ -411,16 +418,28 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a.qa + (int64_t)q * 4), (lds_void_ptr)(qa_s + wave_s * 256), 16, 0, 0);
             }
         }
-        load_w(buf, 0, 0, wx);
-        load_a(buf, 0, a0);
+        if (!carried) {
+            load_w(buf, 0, 0, wx);
+            load_a(buf, 0, a0);
+        }
         int kt = 0;
         // steady state with the issue order pinned (see gemm_bf16.hip): reads and LDS-DMA pieces dealt out one per MFMA
 #define SR_SGB(MASK, N, ID) __builtin_amdgcn_sched_group_barrier(MASK, N, ID)
         // The plane-pair switch of the staged stream used to be a branch inside stage(): it split the k-step's last phase into blocks,
         // and that phase's 16 MFMAs were issued in a clump BEHIND the 8 LDS-DMA pieces and their address arithmetic instead of
         // between them.  The steady state now runs in stretches that stay inside one plane (the whole tile for the filter's pass).
-        while (kt + 2 < nkt) {
-        const int in_plane = (H - st_k0) >> 6, to_go = nkt - 2 - kt;
+        // With a next tile the same k-step body also runs this tile's LAST TWO k-steps: the stage they free takes the next tile's k-steps
+        // 0 and 1, and the very last one reads the next tile's first fragments (`carried`).  The plain two-k-step tail below (reads in
+        // clumps, a drain of every outstanding store at the next tile's top) is left to a workgroup's last tile.
+        const int n_sched = has_next ? nkt : nkt - 2;
+        bool switched = false;
+        while (kt < n_sched) {
+        int to_go = nkt - 2 - kt;
+        if (to_go <= 0) {                   // the staged stream has reached the next tile
+            if (!switched) { set_tile(tile_next); switched = true; }
+            to_go = nkt - kt;
+        }
+        const int in_plane = (H - st_k0) >> 6;
         const int stretch = in_plane < to_go ? in_plane : to_go;          // >= 1: st_k0 < H after every stage_wrap()
 #pragma unroll 1
         for (int it = 0; it < stretch; ++it, ++kt) {
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         stage_wrap();
         }
 #undef SR_SGB
-        for (; kt < nkt; ++kt) {     // last two k-steps: 4 phases per k-step, see gemm_bf16.hip
+        for (; kt < nkt; ++kt) {     // the last two k-steps of the workgroup's last tile: 4 phases per k-step, see gemm_bf16.hip
             load_w(buf, 0, 1, wy);
             SR_MFMA_HALF(0, wx, a0)
             load_w(buf, 1, 0, wx);
@@ -471,13 +490,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
             // emits no vmcnt wait for this barrier, so drain it by hand (every wave its own pieces, then the barrier).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 2 < nkt) {
-                stage(buf);
-            } else if (has_next) {          // the freed stage takes the next tile's k-step kt + 2 - nkt
-                if (kt + 2 == nkt) set_tile(tile_next);
-                stage(buf);
-            }
-            if (kt + 1 < nkt) {
+            if (kt + 1 < nkt) {             // (a workgroup's last tile: nothing left to stage)
                 load_w(buf ^ 1, 0, 0, wx);
                 load_a(buf ^ 1, 0, a0);
             }
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(512, 2) void dense_split_kernel(DenseSplitArgs a) {
         }
         if (!has_next) break;
         tile = tile_next;
+        carried = true;
     }
 #undef SR_MFMA_HALF
 }
