@@ -453,14 +453,14 @@ def sparse_leg(args, device):
     sp_traffic, sp_traffic_src = None, None
     try:
         import hashlib
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_sparse_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_pmc_sparse_traffic.json")) as f:
             pm = json.load(f)
         with open(os.path.join(ROOT, pm["kernel_source"]["file"]), "rb") as f:
             same = hashlib.sha256(f.read()).hexdigest() == pm["kernel_source"]["sha256"]
         sh = pm["shape"]
         if same and (sh["V"], sh["N"], sh["L0_d"], sh["L0_q"], sh["nq"]) == (V, N, L0_d, L0_q, nq):
             sp_traffic = int(pm["traffic_bytes_per_pass"])
-            sp_traffic_src = "profiles/r05_pmc_sparse_traffic.json (" + pm.get("how", "") + ")"
+            sp_traffic_src = "profiles/r06_pmc_sparse_traffic.json (" + pm.get("how", "") + ")"
     except Exception:
         sp_traffic = None
     out = {"metric": "sparse inverted-index queries/s (index resident in HBM, top-%d)" % k, "value": round(nq / dt, 1), "unit": "queries/s",
@@ -1243,7 +1243,7 @@ def main():
     # run inside this process), used only when measured on the same problem shape; the file names the commit it was taken at
     split_traffic, split_traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) as f:
             pmc2 = json.load(f)
         shape2 = pmc2["dense_split_launch"]
         import hashlib
@@ -1252,7 +1252,7 @@ def main():
         if (same_kernel and shape2["nq"] == args.n_queries and shape2["dim"] == H and shape2["n_docs"] == n_local and world == 1
                 and abs(n_l.value / max(1, args.steps) / shape2["launches_per_search"] - 1) < 0.02):
             split_traffic = [v for kname, v in pmc2["kernels"].items() if kname.startswith("dense_split_kernel") and "<false>" not in kname][0]["traffic_bytes"]
-            split_traffic_src = "profiles/r05_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
+            split_traffic_src = "profiles/r06_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, " + pmc2.get("commit", "?") + ")"
     except Exception:
         split_traffic = None
     if filtered:

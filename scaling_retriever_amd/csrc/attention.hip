@@ -262,8 +262,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 // sequence are spread over several workgroups (each stages K and V^T of the sequence again - a few KB from L2) instead
 // of one workgroup walking them while the rest of the chip has finished.  MAXKB = key blocks (of 32) the batch needs:
 // it sizes the LDS image and the score registers, so short batches run at higher occupancy.
+// Workgroups per CU the register allocation is sized for.  Heads of 128 (Lion-DS-8B) hold twice the output accumulators and twice the K
+// fragments of heads of 64: at the occupancy of the 64-wide kernels (4 or 3 workgroups: 128 / 168 VGPRs) the 4- and 6-key-block
+// instantiations spilled 1 300 registers per lane to scratch (kernel metadata, round 6); two workgroups (256 VGPRs) hold them.
+constexpr int at_small_blocks(int hd, int maxkb) { return hd > 64 && maxkb > 2 ? 2 : (maxkb <= 4 ? 4 : (maxkb <= 6 ? 3 : 2)); }
 template <int HD, int MAXKB>
-__global__ __launch_bounds__(256, MAXKB <= 4 ? 4 : (MAXKB <= 6 ? 3 : 2)) void attention_small_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, at_small_blocks(HD, MAXKB)) void attention_small_kernel(AttnArgs a) {
     constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, KC = MAXKB * 32, VT_LD = KC + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [KC][HD], chunk-swizzled

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 profile snapshot, ONE pass, run through gpurun from the repo root as the round's last GPU step:
-#   bash tools/profile_r05.sh        (writes gpurun_out/r05_prof; tools/profile_r05_collect.py copies the judged summaries into profiles/)
+# Round-6 profile snapshot, ONE pass, run through gpurun from the repo root as the round's last GPU step:
+#   bash tools/profile_r06.sh        (writes gpurun_out/r06_prof; tools/profile_r06_collect.py copies the judged summaries into profiles/)
 # Every rocprofv3 call sits under its own `timeout`: a counter set the hardware cannot collect aborts the profiled process and leaves
 # rocprofv3 hanging until the box's limit (that cost 25 GPU-minutes once).  PMC passes are --kernel-trace only (gpurun refuses --pmc
 # together with the sys / hip / hsa trace domains).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05_prof
+O=$R/gpurun_out/r06_prof
 rm -rf $O; mkdir -p $O
 cd $R
 cd /tmp && export TMPDIR=/tmp
@@ -40,9 +40,9 @@ python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /de
 python3 tools/pmc_traffic.py $O/pmc_sp_fetch $O/pmc_sp_write $O/pmc_sparse_traffic.json > /dev/null 2>> $O/pmc_traffic.err
 python3 tools/pmc_counters.py $O/pmc_mfma --out $O/pmc_mfma.json --match dense_split > /dev/null 2>> $O/pmc_traffic.err
 python3 tools/pmc_counters.py $O/pmc_sp? --out $O/pmc_sparse.json --match cert_score_kernel > /dev/null 2>> $O/pmc_traffic.err
-# 6. the bench line itself (what the driver runs), AFTER the counter passes: its sparse leg reads profiles/r05_pmc_sparse_traffic.json, which
+# 6. the bench line itself (what the driver runs), AFTER the counter passes: its sparse leg reads profiles/r06_pmc_sparse_traffic.json, which
 #    the collector ties to the sha256 of the kernel source that was profiled above
-python3 tools/profile_r05_collect.py > $O/collect_on_box.log 2>&1
+python3 tools/profile_r06_collect.py > $O/collect_on_box.log 2>&1
 python3 bench.py > $O/bench_line.json 2> $O/bench.log || echo "bench failed"
 # 7. the GPU suite on the same box
 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_suite.txt
