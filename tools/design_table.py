@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Regenerates the measurement table of DESIGN.md section 6 from a bench line, so that the document cannot drift from the numbers:
-python tools/design_table.py profiles/r05_bench_line.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
+"""Regenerates the measurement table of DESIGN.md section 6 from a bench record (the full one: gpurun_out/bench_detail.json, kept as profiles/r06_bench_detail.json), so that the document cannot drift from the numbers:
+python tools/design_table.py profiles/r06_bench_detail.json  (rewrites the block between the BEGIN / END markers in DESIGN.md)."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_line.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_bench_detail.json")
 r = json.load(open(src))
 rf, bd = r["roofline"], r["breakdown"]
 rows = []
@@ -22,7 +22,7 @@ row("queries/s end to end at the reference's precision: fp32-regime query encode
 row("dominant kernel `dense_split_kernel<true>` (the certified filter's upper-bound pass, fp16 MFMA)",
     f"{rf['achieved']:.0f} TFLOP/s = **{rf['frac']:.3f} of the 16-bit MFMA peak**; {rf['avg_launch_ms']:.4f} ms per launch by HIP events, {rf['launches'] // r['steps']} launches per search = "
     f"{100 * rf['kernel_share_of_step']:.0f} % of the step; {rf['queries_certified']} queries certified, {rf['queries_redone_by_exact_kernel']} re-done; "
-    f"traffic beyond L2 per launch: {(rf['traffic'] or 0) / 1e9:.2f} GB (`profiles/r05_pmc_traffic.json`)")
+    f"traffic beyond L2 per launch: {(rf['traffic'] or 0) / 1e9:.2f} GB (`profiles/r06_pmc_traffic.json`)")
 em = r.get("exact_kernel_mode") or {}
 if em:
     row("the same step through the exact fp32 MFMA kernel (`exact_kernel_mode`: the data-independent floor)",
@@ -75,7 +75,7 @@ if sp:
         f"kernel / floors = **{b['kernel_over_sum_of_floors']}**")
     row("... HBM side of the sparse scorer", f"unique posting bytes per pass {rf2['unique_index_bytes_per_pass'] / 1e9:.1f} GB (all 6 980 queries in one batch; {rf2['unique_index_bytes_per_pass_in_batches_of_1024'] / 1e9:.1f} GB in "
         f"batches of 1 024 as round 4 ran them): HBM floor {rf2['hbm_floor_ms_per_pass']} ms, frac {rf2['frac']}"
-        + (f"; traffic beyond L2 per pass {rf2['traffic'] / 1e9:.0f} GB (`profiles/r05_pmc_sparse_traffic.json`)" if rf2.get("traffic") else ""))
+        + (f"; traffic beyond L2 per pass {rf2['traffic'] / 1e9:.0f} GB (`profiles/r06_pmc_sparse_traffic.json`)" if rf2.get("traffic") else ""))
     ib = sp.get("index_build")
     if ib:
         row("CSR-by-term build (`sr_sparse_csr_build`), full MSMARCO shape", f"**{ib['postings_per_s'] / 1e9:.1f} G postings/s** ({ib['seconds'] * 1e3:.0f} ms for {sp['config']['postings']} postings, "
@@ -87,7 +87,8 @@ if sp:
             f"**{d2['retrieve']['queries_per_s']:.0f} queries/s** ({d2['retrieve']['ms']} ms: query encode {d2['generate_query_vecs_ms']} ms, search → RunResult {d2['search_to_RunResult_ms']} ms)")
     sw = sp.get("sparse_sweep")
     if sw:
-        cells = "; ".join(f"{x['index']} {x['L0_d']}/{x['L0_q']}: {x['queries_per_s'] / 1e3:.1f} k" for x in sw["rows"])
+        cells = "; ".join(f"{x['index']} {x['L0_d']}/{x['L0_q']}: {x['queries_per_s'] / 1e3:.1f} k"
+                          + (f" ({x['queries_redone_by_the_exact_kernels']} of {sw['nq']} re-done by the exact kernels)" if x["queries_redone_by_the_exact_kernels"] else "") for x in sw["rows"])
         row("sparse sweep (index L0_d/L0_q: queries/s; 64 queries per cell bit-exact vs the C oracle)", cells)
     si = sp.get("sparse_index")
     if si:
@@ -100,10 +101,10 @@ if cb:
     al = cb.get("all_hardware_threads")
     row("dense CPU baseline (faiss's algorithm: BLAS sgemm blocks + a heap per query)", f"**{cb['value']} queries/s** with {cb['cores']} threads on {cb.get('host_cpu')} (median of 3 runs, sgemm at {cb.get('sgemm_gflops')} GFLOP/s)"
         + (f"; with all {al['threads']} hardware threads: {al['value']} queries/s (runs {al['seconds']} s)" if al else ""))
-table = "\n".join([f"| r05, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
+table = "\n".join([f"| r06, 1 × MI355X (`{os.path.relpath(src, ROOT)}`) | value |", "|---|---|"] + rows)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-B, E = "<!-- BEGIN r05 table (tools/design_table.py) -->", "<!-- END r05 table -->"
+B, E = "<!-- BEGIN r06 table (tools/design_table.py) -->", "<!-- END r06 table -->"
 if B in s:
     s = s[:s.index(B) + len(B)] + "\n" + table + "\n" + s[s.index(E):]
     open(p, "w").write(s)
