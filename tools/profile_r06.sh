@@ -35,6 +35,7 @@ done
 # 5. encode kernels (corpus + fp32-regime queries), as in round 4
 $T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/qenc_stats -o q -- python3 $R/tools/quick_query_encode.py 16 > $O/qenc.log 2> $O/qenc.err
 $T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc_stats -o e -- python3 $R/tools/quick_encode_budget.py 16384 > $O/enc.log 2> $O/enc.err
+$T2 rocprofv3 --kernel-trace --stats --output-format csv -d $O/encfix_stats -o f -- python3 $R/tools/micro/enc_fixed_batch.py > $O/encfix.log 2> $O/encfix.err
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null 2> $O/pmc_traffic.err
 python3 tools/pmc_traffic.py $O/pmc_sp_fetch $O/pmc_sp_write $O/pmc_sparse_traffic.json > /dev/null 2>> $O/pmc_traffic.err
@@ -44,6 +45,7 @@ python3 tools/pmc_counters.py $O/pmc_sp? --out $O/pmc_sparse.json --match cert_s
 #    the collector ties to the sha256 of the kernel source that was profiled above
 python3 tools/profile_r06_collect.py > $O/collect_on_box.log 2>&1
 python3 bench.py > $O/bench_line.json 2> $O/bench.log || echo "bench failed"
+cp gpurun_out/bench_detail.json $O/bench_detail.json
 # 7. the GPU suite on the same box
 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_suite.txt
 # keep the summaries, drop the bulky per-dispatch traces

@@ -23,10 +23,11 @@ def copy(src, dst):
 
 
 copy("bench_line.json", "r06_bench_line.json")
+copy("bench_detail.json", "r06_bench_detail.json")
 copy("bench_under_rocprof.json", "r06_bench_under_rocprof.json")
 copy("bench_stats/**/bench_kernel_stats.csv", "r06_bench_kernel_stats.csv") if glob.glob(os.path.join(O, "bench_stats/**/bench_kernel_stats.csv"), recursive=True) else None
 for src, dst in (("bench_stats", "r06_bench_kernel_stats.csv"), ("sparse_stats", "r06_sparse_kernel_stats.csv"), ("qenc_stats", "r06_query_encode_kernel_stats.csv"),
-                 ("enc_stats", "r06_encode_kernel_stats.csv")):
+                 ("enc_stats", "r06_encode_kernel_stats.csv"), ("encfix_stats", "r06_encode_fixed_batch_kernel_stats.csv")):
     f = glob.glob(os.path.join(O, src, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(P, dst))
