@@ -276,10 +276,16 @@ static int write_run_json_impl(const char* path, int64_t nq, int64_t k, const fl
                     const std::string& s = bufs[(size_t)t];
                     if (s.size() > skip[(size_t)t]) memcpy(base + off[(size_t)t], s.data() + skip[(size_t)t], s.size() - skip[(size_t)t]);
                 };
+                // The copy is page faults of a fresh mapping, and those contend in the kernel: 64 copying threads take 60-75 ms for a 70 MB round
+                // where 16 take 18-22 (tools/micro/run_writer_threads.py; formatting, which is pure CPU, wants all 64).  So at most 16 copiers,
+                // each walking a contiguous run of the round's buffers.
+                const int nc = nt < 16 ? nt : 16;
+                auto copy_run = [&](int c) {
+                    for (int t = (int)((int64_t)c * nt / nc); t < (int)((int64_t)(c + 1) * nt / nc); ++t) copy(t);
+                };
                 std::vector<std::thread> th;
-                for (int t = 1; t < nt; ++t)
-                    if (!bufs[(size_t)t].empty()) th.emplace_back(copy, t);
-                copy(0);
+                for (int c = 1; c < nc; ++c) th.emplace_back(copy_run, c);
+                copy_run(0);
                 for (auto& x : th) x.join();
                 mapped = munmap(m, (size_t)(total - map_begin)) == 0;
                 if (mapped) g_mapped_rounds.fetch_add(1);
