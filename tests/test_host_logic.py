@@ -132,6 +132,18 @@ rows = np.array(list(shard_rows(len(D), rank, W)))
 s, li = SC.flat_ip_search(Q, D[rows], k)                 # test double for the per-shard HIP search
 gi = np.where(li >= 0, li * W + rank, -1)                # g_row = local * W + rank
 gs, gids = gather_topk(torch.from_numpy(s), torch.from_numpy(gi), dst=0)
+# the plain gather of the padded [nq, k] buffer - what travels over RCCL (no size exchange, no host sync) - and the compacting one (this
+# transport's default) hand rank 0 the same rows; padded slots (id -1) included
+s_pad, gi_pad = s.copy(), gi.copy()
+s_pad[:, k // 2:], gi_pad[:, k // 2:] = 0.0, -1
+for padded in (False, True):
+    a_s, a_i = (s_pad, gi_pad) if padded else (s, gi)
+    p_s, p_i = gather_topk(torch.from_numpy(a_s), torch.from_numpy(a_i), dst=0, compact=False)
+    c_s, c_i = gather_topk(torch.from_numpy(a_s), torch.from_numpy(a_i), dst=0, compact=True)
+    if rank == 0:
+        assert torch.equal(p_i, c_i) and torch.equal(p_s[c_i >= 0], c_s[c_i >= 0]) and p_i.shape == (W, 6, k), padded
+    else:
+        assert p_s is None and c_s is None
 if rank == 0:
     assert gs.shape == (W, 6, k)
     cs = gs.permute(1, 0, 2).reshape(6, -1).numpy(); ci = gids.permute(1, 0, 2).reshape(6, -1).numpy()
