@@ -180,8 +180,9 @@ int sr_sparse_index_block_stats(sr_sparse_index* idx, int64_t* n_dense_terms, in
  * take ~22 bytes per posting + 8 bytes per (term, 1 024-doc tile), at most half of the free device memory: 25 GB at the MS MARCO
  * shape); SR_LOG=1 prints one line per index on stderr saying what was built, with how many bytes, or why not.
  * Limits of the fast path, beyond which a query is served by the exact kernels (same results, about a quarter of the speed):
- * k <= SR_MAX_TOPK - 1024 = 3 072 (the band of extra keys), <= 256 query terms (those outside the index's 128 heaviest terms beyond
- * the first 64 take a slower walk inside the same kernel), terms strictly ascending, values >= 0, at least 8 (k + 1 024) documents in the collection.                            */
+ * k <= SR_MAX_TOPK - 1024 = 3 072 (the band of extra keys: 1 024, or 2 048 / 3 072 for batches whose queries bring more than 96 / 160
+ * terms outside the index's 128 heaviest ones, capped at SR_MAX_TOPK - k), <= 256 query terms (rare terms beyond the first 64 take a
+ * slower walk inside the same kernel), terms strictly ascending, values >= 0, at least 8 (k + 1 024) documents in the collection.                            */
 int sr_sparse_index_cert_stats(sr_sparse_index* idx, int64_t* out8);
 /* Test hook for the error bound: enable = 1 / 0 switches the recording of the stage-1 keys of every (query, doc) pair on /
  * off; enable = 2 copies the last search's keys to h_keys uint16 [nq_pad][n_tiles * 1024] (nq_pad = nq rounded up to 32)

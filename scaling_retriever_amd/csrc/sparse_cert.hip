@@ -421,6 +421,7 @@ struct CertPlanArgs {
     int32_t* n_drop;
     uint8_t* elig;
     uint8_t* overflow;
+    int* max_rare;           // largest rare-term count among the queries on the fast path (sizes the certificate's band)
 };
 
 __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
     nr = rbase;
     if (lane == 0) a.n_drop[q] = n_drop;
     if (lane == 0) { a.cq[q] = cqv; a.sq[q] = sq; a.n_rare[q] = nr; a.n_qt[q] = n; a.elig[q] = 1; }
+    if (lane == 0 && nr > 64) atomicMax(a.max_rare, nr);
 }
 
 // ------------------------------------------------------------------------------------------------- score kernel ---
@@ -1367,7 +1369,7 @@ static bool cert_realloc(T*& p, size_t n) {
 
 // the per-call buffers of a batch of nq_pad queries; false = out of device memory: everything per-call is released (the index-side
 // structures stay) and the caller serves the batch with the exact kernels
-static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {
+static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {      // k_eff = 0: the plan's buffers only (the band is chosen after the plan)
     bool ok = true;
     if (nq_pad > c->nq_cap) {
         c->nq_cap = 0;
@@ -1385,17 +1387,17 @@ static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {
         ok = ok && cert_realloc(c->m_count, (size_t)nq_pad);
         if (ok) c->nq_cap = nq_pad;
     }
-    if (ok && nq_pad * k_eff > c->ap_cap) {
+    if (ok && k_eff > 0 && nq_pad * k_eff > c->ap_cap) {
         c->ap_cap = 0;
         ok = cert_realloc(c->ap_ids, (size_t)nq_pad * (size_t)(2 * k_eff));
         if (ok) c->ap_cap = nq_pad * k_eff;
     }
-    if (ok && !c->d_n_uncert && hipMalloc((void**)&c->d_n_uncert, 2 * sizeof(int)) != hipSuccess) {     // [0] uncertified queries, [1] candidates re-scored (in units of 16)
+    if (ok && !c->d_n_uncert && hipMalloc((void**)&c->d_n_uncert, 4 * sizeof(int)) != hipSuccess) {     // [0] uncertified queries, [1] candidates re-scored (in units of 16), [2] largest rare-term count
         (void)hipGetLastError();
         c->d_n_uncert = nullptr;
         ok = false;
     }
-    if (ok && c->ws.ensure(nq_pad, k_eff, SC_CAND_CAP) != SR_OK) ok = false;      // releases itself on failure
+    if (ok && k_eff > 0 && c->ws.ensure(nq_pad, k_eff, SC_CAND_CAP) != SR_OK) ok = false;      // releases itself on failure
     if (!ok) {
         void** ptrs[] = {(void**)&c->bfrag, (void**)&c->rare_term, (void**)&c->rare_w, (void**)&c->cq, (void**)&c->sq, (void**)&c->n_rare, (void**)&c->n_qt,
                          (void**)&c->n_drop, (void**)&c->tau2, (void**)&c->elig, (void**)&c->overflow, (void**)&c->m_count, (void**)&c->ap_ids};
@@ -1408,6 +1410,14 @@ static bool cert_ensure_call_buffers(SparseCert* c, int64_t nq_pad, int k_eff) {
         c->ws.release();
     }
     return ok;
+}
+
+// a sub-batch of `ns` handed-back queries went through the scorer a second time: count them once (queries given; handed to the exact kernels
+// = what the second pass handed back)
+void sparse_cert_count_retry(SparseCert* c, int64_t ns) {
+    c->n_queries -= ns;
+    c->n_uncert -= ns;
+    --c->n_calls;
 }
 
 uint8_t* sparse_cert_uncert_buffer(SparseCert* c, int64_t nq) {
@@ -1435,13 +1445,12 @@ static int cert_launch_score(const CertArgs& a, unsigned grid, hipStream_t s) {
 
 int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
                        int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
-                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, hipStream_t s) {
+                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, int band_keys, int* band_used, hipStream_t s) {
     SparseCert* c = idx->cert;
-    const int k_eff = k + SC_BAND;
     const int64_t nq_pad = ceil_div64(nq, SC_QB) * SC_QB;
     const int n_qblocks = (int)(nq_pad / SC_QB);
     *no_memory = false;
-    if (!cert_ensure_call_buffers(c, nq_pad, k_eff)) {
+    if (!cert_ensure_call_buffers(c, nq_pad, 0)) {
         *no_memory = true;
         return SR_OK;
     }
@@ -1457,14 +1466,35 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
 
     // plan
     SR_CHECK_HIP(hipMemsetAsync(c->bfrag, 0, sizeof(_Float16) * (size_t)nq_pad * (size_t)c->T, s));
-    SR_CHECK_HIP(hipMemsetAsync(c->d_n_uncert, 0, 2 * sizeof(int), s));
+    SR_CHECK_HIP(hipMemsetAsync(c->d_n_uncert, 0, 4 * sizeof(int), s));
     CertPlanArgs pa;
     pa.q_indptr = d_q_indptr; pa.q_cols = d_q_cols; pa.q_vals = d_q_vals; pa.nq = nq; pa.n_terms = idx->n_terms;
     pa.indptr = idx->indptr; pa.dslot = c->dslot; pa.vmax = c->vmax; pa.KS = c->KS; pa.vscale = c->vscale;
     pa.bfrag = c->bfrag; pa.rare_term = c->rare_term; pa.rare_w = c->rare_w; pa.cq = c->cq; pa.sq = c->sq; pa.n_rare = c->n_rare; pa.n_qt = c->n_qt; pa.n_drop = c->n_drop;
-    pa.elig = c->elig; pa.overflow = c->overflow;
+    pa.elig = c->elig; pa.overflow = c->overflow; pa.max_rare = c->d_n_uncert + 2;
     hipLaunchKernelGGL(cert_plan_kernel, dim3((unsigned)ceil_div64(nq_pad, 4)), dim3(256), 0, s, pa);
     SR_CHECK_LAUNCH();
+    // The band: how many keys beyond k the running set keeps.  The certificate needs every key that the 16-bit arithmetic cannot tell from
+    // the k-th inside it, and each rare term of a query widens that stretch by one key unit (the bound of DESIGN.md 4.6): 1 024 keys hold
+    // it up to ~100 rare terms (L0_q = 128 at the MSMARCO shape: all certified), beyond that the band grows - at 145 rare terms (L0_q = 256)
+    // 2 048 keys certify 93 % of the queries and 3 072 all of them, at 12 100 instead of 4 900 queries/s through the exact kernels.  The
+    // short queries of a default batch keep the band that is fastest for them (140 000 q/s at 1 024, 130 000 at 3 072).
+    int band = band_keys;
+    if (band <= 0) {
+        int h_max_rare = 0;
+        SR_CHECK_HIP(hipMemcpyAsync(&h_max_rare, c->d_n_uncert + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        SR_CHECK_HIP(hipStreamSynchronize(s));
+        band = h_max_rare > 160 ? 3072 : (h_max_rare > 96 ? 2048 : SC_BAND);
+        if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_BANDKEYS")) band = atoi(e);        // A/B switch: keys kept beyond k
+    }
+    if (band < 64) band = 64;
+    if (k + band > SR_MAX_TOPK) band = SR_MAX_TOPK - k;
+    const int k_eff = k + band;
+    if (band_used) *band_used = band;
+    if (!cert_ensure_call_buffers(c, nq_pad, k_eff)) {
+        *no_memory = true;
+        return SR_OK;
+    }
 
     // stage 1: doc tiles in launches that grow geometrically (the threshold tightens early), at most 512 tiles each
     SR_TRY(topk_reset(c->ws, nq_pad, s));

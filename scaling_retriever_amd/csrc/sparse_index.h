@@ -43,6 +43,7 @@ struct sr_sparse_index {
     // certified two-stage scorer (null: the index or the device does not qualify; every search then runs the exact kernels)
     SparseCert* cert = nullptr;
     int64_t n_cert_no_memory = 0;       // query batches served by the exact kernels because the certified scorer's buffers did not fit
+    int64_t n_cert_retries = 0;         // sub-batches of handed-back queries sent through the scorer again with the widest band
     std::mutex mu;
 };
 
@@ -57,7 +58,10 @@ void sparse_cert_destroy(SparseCert* c);
 // in device memory; they were released, nothing was computed, and the caller serves the batch with the exact kernels.
 int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
                        int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
-                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, hipStream_t s);
+                       int32_t* d_out_counts, uint8_t* d_uncert, int64_t* n_uncert, bool* no_memory, int band_keys, int* band_used, hipStream_t s);
+// band_keys: keys the running set keeps beyond k (the certificate's room); 0 = chosen from the batch's largest rare-term count (1 024 /
+// 2 048 / 3 072, capped at SR_MAX_TOPK - k); *band_used returns it.
+void sparse_cert_count_retry(SparseCert* c, int64_t ns);
 // [nq] flag bytes kept with the scorer (grown on demand); nullptr = out of device memory
 uint8_t* sparse_cert_uncert_buffer(SparseCert* c, int64_t nq);
 // queries per call of sparse_cert_search: its per-query workspace is ~200 KB (candidate slots of a launch, running set, approximate lists)

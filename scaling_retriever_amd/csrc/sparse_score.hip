@@ -1421,9 +1421,13 @@ __global__ void sparse_sub_scatter_kernel(const int64_t* __restrict__ sel, int k
     if (c_out && threadIdx.x == 0) c_out[q] = c_in[j];
 }
 
+// wide_band > 0 (and at least SR_CERT_RETRY_MIN queries handed back): the sub-batch first goes through the certified scorer once more with
+// that many keys beyond k - a certificate that failed for want of room is then usually given - and only what it hands back again reaches
+// the exact kernels.
+#define SR_CERT_RETRY_MIN 256
 static int sparse_redo_exact(sr_sparse_index* idx, const int64_t* d_q_indptr, const int32_t* d_q_cols, const float* d_q_vals, int64_t nq,
                              int k, float threshold, int64_t id_base, int64_t id_stride, float* d_out_scores, int64_t* d_out_ids,
-                             int32_t* d_out_counts, const uint8_t* d_uncert, hipStream_t s) {
+                             int32_t* d_out_counts, const uint8_t* d_uncert, hipStream_t s, int wide_band = 0) {
     std::vector<uint8_t> h_un((size_t)nq);
     std::vector<int64_t> h_ip((size_t)nq + 1);
     SR_CHECK_HIP(hipMemcpyAsync(h_un.data(), d_uncert, (size_t)nq, hipMemcpyDeviceToHost, s));
@@ -1454,7 +1458,30 @@ static int sparse_redo_exact(sr_sparse_index* idx, const int64_t* d_q_indptr, co
         rc = SR_ERR_HIP;
     if (rc == SR_OK) {
         hipLaunchKernelGGL(sparse_sub_gather_kernel, dim3((unsigned)ns), dim3(64), 0, s, d_q_indptr, d_q_cols, d_q_vals, d_sel, d_sip, d_cols, d_vals);
-        rc = sparse_exact_search(idx, d_sip, d_cols, d_vals, ns, k, threshold, id_base, id_stride, d_sc, d_ids, d_cnt, s);
+        bool done = false;
+        if (wide_band > 0 && ns >= SR_CERT_RETRY_MIN && idx->cert) {
+            uint8_t* d_un2 = nullptr;
+            if (hipMalloc((void**)&d_un2, (size_t)ns) == hipSuccess) {
+                int64_t n_un2 = 0;
+                bool no_memory = false;
+                int band_used = 0;
+                rc = sparse_cert_search(idx, d_sip, d_cols, d_vals, ns, k, threshold, id_base, id_stride, d_sc, d_ids, d_cnt, d_un2, &n_un2, &no_memory,
+                                        wide_band, &band_used, s);
+                if (rc == SR_OK && !no_memory) {
+                    ++idx->n_cert_retries;
+                    sparse_cert_count_retry(idx->cert, ns);
+                    if (n_un2 > 0)
+                        rc = sparse_redo_exact(idx, d_sip, d_cols, d_vals, ns, k, threshold, id_base, id_stride, d_sc, d_ids, d_cnt, d_un2, s);
+                    done = true;
+                }
+                if (hipStreamSynchronize(s) != hipSuccess && rc == SR_OK) rc = SR_ERR_HIP;
+                (void)hipFree(d_un2);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (rc == SR_OK && !done)
+            rc = sparse_exact_search(idx, d_sip, d_cols, d_vals, ns, k, threshold, id_base, id_stride, d_sc, d_ids, d_cnt, s);
     }
     if (rc == SR_OK) {
         hipLaunchKernelGGL(sparse_sub_scatter_kernel, dim3((unsigned)ns), dim3(256), 0, s, d_sel, k, d_sc, d_ids, d_cnt, d_out_scores, d_out_ids,
@@ -1505,14 +1532,18 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
             int64_t n_un = 0;
             bool no_memory = d_uncert == nullptr;
             if (sr_dev_getenv("SR_SPARSE_CERT_FAKE_OOM")) no_memory = true;          // tests: the fallback below
+            int band_used = 0;
             if (!no_memory)
                 SR_TRY(sparse_cert_search(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert,
-                                          &n_un, &no_memory, s));
+                                          &n_un, &no_memory, 0, &band_used, s));
             if (no_memory) {
                 ++idx->n_cert_no_memory;
                 SR_TRY(sparse_exact_search(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, s));
             } else if (n_un > 0) {
-                SR_TRY(sparse_redo_exact(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert, s));
+                // many queries handed back under a band that could still grow: once more through the scorer with the widest band, then the exact kernels
+                const int widest = SR_MAX_TOPK - k;
+                SR_TRY(sparse_redo_exact(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert, s,
+                                         band_used < widest ? widest : 0));
             }
         }
         return SR_OK;

@@ -120,15 +120,15 @@ def test_full_msmarco_shape_sparse_search_bit_exact():
         assert oc[q] == int(c[q])
         assert np.array_equal(i[q].cpu().numpy(), oi[q]) and np.array_equal(s[q].cpu().numpy(), os_[q]), q
     # long queries at full size: 128 and 200 terms, 70-110 of them outside the 128 heaviest lists - beyond the first 64 rare terms the
-    # scorer's plain walk adds them (round 6; the exact kernels served such queries before).  128 terms: all certified.  200 terms: the
-    # certificate's band (1 024 keys beyond k) no longer holds every key the 16-bit stage-1 arithmetic cannot tell from the k-th - each
-    # rare term widens it by one key unit - so most of them come back through the exact kernels: the oracle's bits either way.
+    # scorer's plain walk adds them (round 6; the exact kernels served such queries before).  128 terms: all certified under the default band
+    # of 1 024 keys beyond k.  200 terms (~110 rare): each rare term widens the stretch of keys the 16-bit stage-1 arithmetic cannot tell
+    # from the k-th by one unit, so the batch gets a band of 2 048 keys (chosen from its largest rare-term count) and nearly all are certified.
     for L0_q, n_q in ((128, 64), (200, 32)):
         ql_indptr, ql_cols, ql_vals = synth.build_queries(V, n_q, L0_q, dev, 40 + L0_q)
         st0 = idx.cert_stats()
         sl, il, cl = idx.search(ql_indptr, ql_cols, ql_vals, k)
         st1 = idx.cert_stats()
-        assert st1["queries"] - st0["queries"] == n_q and (L0_q > 128 or st1["redone_exact"] - st0["redone_exact"] == 0), (L0_q, st0, st1)
+        assert st1["queries"] - st0["queries"] == n_q and st1["redone_exact"] - st0["redone_exact"] <= (0 if L0_q <= 128 else n_q // 4), (L0_q, st0, st1)
         hq = (ql_indptr.cpu().numpy(), ql_cols.cpu().numpy(), ql_vals.cpu().numpy())
         oi, os_, oc = SC.sparse_retrieve_c(*h, *hq, k, 0.0, N, q_threads=max(1, min(32, (os.cpu_count() or 8) // 4)), inner_threads=4)
         for q in range(n_q):

@@ -417,3 +417,43 @@ def test_up_to_256_rare_terms_stay_on_the_fast_path(forced):
         assert (kq >= tf * (1 - dd) - 1.2 - 2.03 * n_drop).all(), q
         assert (kq <= tf * (1 + dd) + 1.2 + 1.01 * n_r).all(), q
         assert kq.max() <= 65535 * 0.99
+
+
+def test_band_grows_with_the_rare_terms_and_a_failed_batch_is_retried_wider(forced, monkeypatch):
+    """The certificate's band (keys kept beyond k) is chosen per batch from its largest rare-term count - each rare term widens the stretch
+    of keys the 16-bit arithmetic cannot tell from the k-th by one unit: 1 024 keys up to 96 rare terms, 2 048 up to 160, 3 072 beyond -
+    and when at least 256 queries of a batch are handed back under a band that could still grow, they go through the scorer once more
+    with the widest one before the exact kernels get what is left.  Rows are the oracle's either way."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(321)
+    V, N, k = 3000, 120000, 100
+    indptr, ids, vals = _zipf_index(rng, V, N, 60)
+    order = np.argsort(-np.diff(indptr), kind="stable")
+    heavy, rare = order[:128], order[128:]
+
+    def queries(nq, n_rare):
+        qi, qc, qv = [0], [], []
+        for _ in range(nq):
+            cols = np.sort(np.concatenate([rng.choice(heavy, size=20, replace=False), rng.choice(rare, size=n_rare, replace=False)])).astype(np.int32)
+            qc.append(cols)
+            qv.append(np.log1p(rng.uniform(0, 20, size=len(cols))).astype(np.float32))
+            qi.append(qi[-1] + len(cols))
+        return np.array(qi, np.int64), np.concatenate(qc), np.concatenate(qv)
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    for n_rare in (30, 120, 200):                                   # bands 1 024 / 2 048 / 3 072
+        qi, qc, qv = queries(40, n_rare)
+        st0 = idx.cert_stats()
+        _search_and_compare(idx, indptr, ids, vals, N, qi, qc, qv, k)
+        st1 = idx.cert_stats()
+        assert st1["searches"] == st0["searches"] + 1 and st1["redone_exact"] - st0["redone_exact"] <= 4, (n_rare, st0, st1)
+    # the retry: a band of 64 keys certifies next to nothing of 300 near-tie queries; the second pass with the widest band does
+    indptr_t, ids_t, vals_t = _zipf_index(rng, 1200, 90000, 30, vals="ties")
+    qi, qc, qv = _zipf_queries(rng, 1200, 300, 16, vals="ties")
+    idx_t = SparseIndexHIP(indptr_t, ids_t, vals_t, 90000)
+    s_ref, i_ref, c_ref = _search_and_compare(idx_t, indptr_t, ids_t, vals_t, 90000, qi, qc, qv, 50)
+    base = idx_t.cert_stats()
+    monkeypatch.setenv("SR_SPARSE_CERT_BANDKEYS", "64")
+    s2, i2, c2 = _search_and_compare(idx_t, indptr_t, ids_t, vals_t, 90000, qi, qc, qv, 50)
+    st = idx_t.cert_stats()
+    assert np.array_equal(s_ref, s2) and np.array_equal(i_ref, i2)
+    assert st["searches"] == base["searches"] + 1 and st["queries"] == base["queries"] + 300        # a retried sub-batch is counted once
