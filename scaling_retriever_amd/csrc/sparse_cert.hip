@@ -40,7 +40,7 @@
 #define SC_MAXR 64                    // rare terms per group: one lane of a scatter wave each
 #define SC_MAXG 4                     // groups per query: the first runs through the staged, flattened walk, the others (queries with more than 64
                                       // rare terms) through a plain per-lane walk in the same step
-#define SC_MAXRT (SC_MAXR * SC_MAXG)  // rare terms per query
+#define SC_MAXRT (SC_MAXR * SC_MAXG)  // rare terms per query the scatter role can add
 #define SC_BAND 1024                  // keys kept beyond k
 #define SC_CAND_CAP 16384             // candidate slots per query and launch
 #define SC_MAXQT 256                  // terms of a fast-path query
@@ -421,7 +421,7 @@ struct CertPlanArgs {
     int32_t* n_drop;
     uint8_t* elig;
     uint8_t* overflow;
-    int* max_rare;           // largest rare-term count among the queries on the fast path (sizes the certificate's band)
+    int* max_rare;           // [0] largest rare-term count among the queries on the fast path (sizes the certificate's band), [1] how many queries are on it
 };
 
 __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(CertPlanArgs a) {
     if (lane == 0) a.n_drop[q] = n_drop;
     if (lane == 0) { a.cq[q] = cqv; a.sq[q] = sq; a.n_rare[q] = nr; a.n_qt[q] = n; a.elig[q] = 1; }
     if (lane == 0 && nr > 64) atomicMax(a.max_rare, nr);
+    if (lane == 0) atomicAdd(a.max_rare + 1, 1);         // queries on the fast path
 }
 
 // ------------------------------------------------------------------------------------------------- score kernel ---
@@ -1480,17 +1481,30 @@ int sparse_cert_search(sr_sparse_index* idx, const int64_t* d_q_indptr, const in
     // 2 048 keys certify 93 % of the queries and 3 072 all of them, at 12 100 instead of 4 900 queries/s through the exact kernels.  The
     // short queries of a default batch keep the band that is fastest for them (140 000 q/s at 1 024, 130 000 at 3 072).
     int band = band_keys;
-    if (band <= 0) {
-        int h_max_rare = 0;
-        SR_CHECK_HIP(hipMemcpyAsync(&h_max_rare, c->d_n_uncert + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    int h_plan[2] = {0, 0};                                  // largest rare-term count, queries on the fast path
+    SR_CHECK_HIP(hipMemcpyAsync(h_plan, c->d_n_uncert + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SR_CHECK_HIP(hipStreamSynchronize(s));
+    if (h_plan[1] == 0) {                                    // nothing for the scorer in this batch (negative / unordered / too long queries): no pass over the collection
+        SR_CHECK_HIP(hipMemsetAsync(d_uncert, 1, (size_t)nq, s));
         SR_CHECK_HIP(hipStreamSynchronize(s));
-        band = h_max_rare > 160 ? 3072 : (h_max_rare > 96 ? 2048 : SC_BAND);
+        if (band_used) *band_used = SR_MAX_TOPK;             // no retry either
+        *n_uncert = nq;
+        ++c->n_calls;
+        c->n_queries += nq;
+        c->n_uncert += nq;
+        return SR_OK;
+    }
+    if (band <= 0) {
+        band = h_plan[0] > 160 ? 3072 : (h_plan[0] > 96 ? 2048 : SC_BAND);
         if (const char* e = sr_dev_getenv("SR_SPARSE_CERT_BANDKEYS")) band = atoi(e);        // A/B switch: keys kept beyond k
     }
     if (band < 64) band = 64;
     if (k + band > SR_MAX_TOPK) band = SR_MAX_TOPK - k;
     const int k_eff = k + band;
     if (band_used) *band_used = band;
+    if (const char* e = getenv("SR_LOG")) if (atoi(e) >= 2)
+        fprintf(stderr, "[sr_hip] certified sparse search: %lld queries, %d on the fast path, largest rare-term count %d, band %d keys%s\n", (long long)nq, h_plan[1], h_plan[0],
+                band, band_keys > 0 ? " (second pass)" : "");
     if (!cert_ensure_call_buffers(c, nq_pad, k_eff)) {
         *no_memory = true;
         return SR_OK;

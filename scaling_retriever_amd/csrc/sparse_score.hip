@@ -1541,9 +1541,9 @@ extern "C" int sr_sparse_search(sr_sparse_index* idx, const int64_t* d_q_indptr,
                 SR_TRY(sparse_exact_search(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, s));
             } else if (n_un > 0) {
                 // many queries handed back under a band that could still grow: once more through the scorer with the widest band, then the exact kernels
-                const int widest = SR_MAX_TOPK - k;
+                const int widest = SR_MAX_TOPK - k;                // worth a second pass only if it at least doubles the band
                 SR_TRY(sparse_redo_exact(idx, d_q_indptr + qb, d_q_cols, d_q_vals, nqb, k, threshold, id_base, id_stride, o_s, o_i, o_c, d_uncert, s,
-                                         band_used < widest ? widest : 0));
+                                         2 * band_used <= widest ? widest : 0));
             }
         }
         return SR_OK;

@@ -129,7 +129,7 @@ def test_certified_search_is_bit_exact(forced, V, N, L0_d, nq, L0_q, k, thr):
 def test_queries_outside_the_fast_path_come_back_identical(forced):
     """Negative weights, descending / shuffled term order, duplicate terms, empty queries, unknown terms, zero weights, more than 256
     terms: all flagged by the plan kernel and served by the exact kernels inside the same call, next to certified queries (one of them
-    with 90 rare terms: on the fast path since round 6)."""
+    with 90 rare terms: on the fast path since round 6).  A batch with NO query for the fast path costs the scorer no pass at all."""
     from scaling_retriever_amd.scoring import SparseIndexHIP
     rng = np.random.default_rng(11)
     V, N = 2500, 33000
@@ -457,3 +457,25 @@ def test_band_grows_with_the_rare_terms_and_a_failed_batch_is_retried_wider(forc
     st = idx_t.cert_stats()
     assert np.array_equal(s_ref, s2) and np.array_equal(i_ref, i2)
     assert st["searches"] == base["searches"] + 1 and st["queries"] == base["queries"] + 300        # a retried sub-batch is counted once
+
+
+def test_batch_without_a_fast_path_query_costs_no_pass(forced):
+    """Every query negative / unordered / too long: the plan kernel reports no query for the scorer, stage 1 does not run (no
+    candidates re-scored, every query handed back) and the exact kernels serve the batch - the oracle's rows."""
+    from scaling_retriever_amd.scoring import SparseIndexHIP
+    rng = np.random.default_rng(55)
+    V, N = 2500, 70000
+    indptr, ids, vals = _zipf_index(rng, V, N, 40)
+    qi, qc, qv = _zipf_queries(rng, V, 40, 20)
+    qv = -qv                                                     # all weights negative
+    idx = SparseIndexHIP(indptr, ids, vals, N)
+    s, i, c = idx.search(qi, qc, qv, 50)
+    torch.cuda.synchronize()
+    st = idx.cert_stats()
+    assert st["searches"] == 1 and st["queries"] == 40 and st["redone_exact"] == 40 and st["candidates_rescored"] == 0
+    s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
+    for q in range(40):
+        cols, v = qc[qi[q]:qi[q + 1]], qv[qi[q]:qi[q + 1]]
+        fi, neg = O.numba_score_float(indptr, ids, vals, cols, v, 0.0, N)
+        ei, es = O.select_topk(fi, neg, 50)
+        assert c[q] == len(ei) and np.array_equal(i[q, :c[q]], ei) and np.array_equal(s[q, :c[q]], es), q
