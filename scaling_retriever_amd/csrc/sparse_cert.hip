@@ -680,22 +680,47 @@ __device__ __noinline__ void cert_extra_groups(const int32_t* rare_term, const f
                                                int e_stride, int s_stride, int64_t q0, int ng0, int ng1, int ng2, int ng3, int tile, uint32_t* wrow) {
     const int lane = threadIdx.x & 63;
     const int ngq[4] = {ng0, ng1, ng2, ng3};
+    constexpr int XG = SC_MAXG - 1;
+    // every look-up level for all (query, group) pairs of the wave at once - 12 independent loads in flight per level instead of 12 dependent
+    // chains of three (a step of a block of 256-term queries took 7 x a plain step when the chains ran one after the other)
+    int32_t t[4][XG];
+    uint32_t e[4][XG], p0[4][XG];
+    float w[4][XG];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int g = 0; g < XG; ++g)
+            t[qi][g] = (g + 1 < ngq[qi] && !(SC_DIAG & 1)) ? rare_term[(q0 + qi) * SC_MAXRT + (g + 1) * SC_MAXR + lane] : -1;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int g = 0; g < XG; ++g)
+            e[qi][g] = t[qi][g] >= 0 ? E[(uint32_t)t[qi][g] * (uint32_t)e_stride + (uint32_t)tile] : 0u;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int g = 0; g < XG; ++g) {
+            w[qi][g] = e[qi][g] != 0u ? (float)(_Float16)rare_w[(q0 + qi) * SC_MAXRT + (g + 1) * SC_MAXR + lane] : 0.f;
+            p0[qi][g] = (e[qi][g] >> 16) == 0xffffu ? S[(int64_t)t[qi][g] * s_stride + tile] : 0u;
+        }
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) {
         uint32_t* const row = wrow + qi * SC_PITCH_W;
-#pragma unroll 1
-        for (int g = 1; g < ngq[qi]; ++g) {
-            const int32_t t = rare_term[(q0 + qi) * SC_MAXRT + g * SC_MAXR + lane];
-            if (t < 0 || (SC_DIAG & 1)) continue;
-            const uint32_t e = E[(uint32_t)t * (uint32_t)e_stride + (uint32_t)tile];
-            if (e == 0u) continue;
-            const float w = (float)(_Float16)rare_w[(q0 + qi) * SC_MAXRT + g * SC_MAXR + lane];
-            if ((e >> 16) != 0xffffu) {
-                cert_add_posting(row, e, w);                     // the term's only posting in this tile
-            } else {
-                const uint32_t p0 = S[(int64_t)t * s_stride + tile];
-                const uint32_t len = e & 0xffffu;
-                for (uint32_t u = 0; u < len; ++u) cert_add_posting(row, P[p0 + u], w);
+#pragma unroll
+        for (int g = 0; g < XG; ++g) {
+            if (g + 1 >= ngq[qi]) continue;                      // wave-uniform
+            const uint32_t ev = e[qi][g];
+            if (ev != 0u && (ev >> 16) != 0xffffu) cert_add_posting(row, ev, w[qi][g]);      // the term's only posting in this tile
+            const uint32_t len = (ev >> 16) == 0xffffu ? (ev & 0xffffu) : 0u;
+            uint32_t longest = len;                              // the walk runs as long as the wave's longest run, four postings per round trip
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, off); longest = o > longest ? o : longest; }
+            for (uint32_t u = 0; u < longest; u += 4) {
+                uint32_t pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = u + r < len ? P[p0[qi][g] + u + r] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (u + r < len) cert_add_posting(row, pv[r], w[qi][g]);
             }
         }
     }
