@@ -4,19 +4,22 @@
 // the rank-major concatenation of merge_indexes (:108-170).  SparseIndexer.index (indexer.py:239-308) hands over the postings of
 // its encoded batches as (global doc row, term, value) triples in insertion order; the reference's posting list of a term holds
 // that term's postings in insertion order.  That is a STABLE sort of the triples by term: here a least-significant-digit radix
-// sort with digits of up to 9 bits, one wave per 8 192 consecutive postings:
-//   pass = histogram kernel (digit counts per wave, digit-major) -> exclusive scan -> scatter kernel (a wave walks its postings
-//   in rounds of 64; a lane's rank among the round's lanes with the same digit comes from one ballot per digit bit, the wave's
-//   running digit counters live in 2 KB of LDS, so equal digits keep their input order).
+// sort with digits of up to 9 bits over tiles of 8 192 consecutive postings:
+//   pass = histogram kernel (digit counts per tile, digit-major; one wave per tile) -> exclusive scan -> scatter kernel (one workgroup
+//   per tile: every wave ranks its 1 024 postings in rounds of 64 - the lanes of a round with the same digit find each other through
+//   a 64-bit word per digit in LDS - the waves' counts are scanned in wave order, the tile is put in digit order in LDS and leaves as
+//   runs of neighbouring slots; equal digits keep their input order).  radix_scatter_tile_kernel's comment has the measurements that
+//   shaped it (round 6: 78 -> 17 ms for the 1.12 G postings of the MSMARCO-sized collection).
 // With sort_docs the triples are first sorted by doc row the same way (posting lists ascending by doc id whatever the input
 // order: a merged multi-rank index is rank-major inside a term, inverted_index.py:139-146).  indptr = lower bound of every term
 // in the sorted term array.  Traffic per pass: 4 B (histogram) + 24 B (scatter) per posting, HBM-bound.
 #include "sparse_index.h"
 #include <type_traits>
 
-#define SBW_ELEMS 8192        // postings per wave
-#define SBW_WAVES 4           // waves per workgroup
+#define SBW_ELEMS 8192        // postings per tile (the unit of the histogram)
+#define SBW_WAVES 4           // tiles (one wave each) per workgroup of the histogram kernel
 #define SB_MAXBITS 9
+#define SBH_COPIES 4
 
 // ------------------------------------------------------------------------------------------------ exclusive scan ---
 // Three launches: per-block sums (2 048 items per block), one workgroup scans the block sums in place (loop with carry), every
@@ -145,40 +148,85 @@ struct RadixArgs {
     int64_t row_limit;       // sort_docs: n_docs (a row at or beyond it would leave the lists not ascending by doc); 0 = rows are payload only
 };
 
+// Workgroup b runs on XCD b % 8: every XCD gets one contiguous eighth of the work, so that what is in flight on an XCD is neighbouring
+// tiles - their 4-byte histogram entries of a digit (and, in the scatter, the ends of the runs they write) share lines in that XCD's L2.
+__device__ __forceinline__ int64_t xcd_contiguous(unsigned b, int64_t n_items) {
+    const int64_t per_xcd = (n_items + 7) / 8;
+    const int64_t i = (int64_t)(b & 7u) * per_xcd + (b >> 3);
+    return (int64_t)(b >> 3) < per_xcd && i < n_items ? i : -1;
+}
+static unsigned xcd_contiguous_grid(int64_t n_items) { return (unsigned)(((n_items + 7) / 8) * 8); }
+
+__device__ __forceinline__ int check_posting(const RadixArgs& a, int32_t t, int32_t rw) {
+    int bad = 0;
+    if ((uint32_t)t >= (uint64_t)a.n_terms) bad |= 1;                      // negative or beyond the vocabulary
+    if (rw < 0) bad |= 2;
+    if (a.row_limit > 0 && (int64_t)rw >= a.row_limit) bad |= 4;           // sort_docs: the doc digits cover [0, n_docs) only
+    return bad;
+}
+
 __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a) {
-    __shared__ uint32_t cnt[SBW_WAVES][1 << SB_MAXBITS];
+    // SBH_COPIES counters per digit and wave, lane l counts in copy l % SBH_COPIES: the high digits of the terms are skewed (half the postings
+    // of a Zipf collection in one digit), and LDS atomics of one instruction on one address are taken one after the other
+    __shared__ uint32_t cnt[SBW_WAVES][SBH_COPIES][1 << SB_MAXBITS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wid = (int64_t)blockIdx.x * SBW_WAVES + wave;
+    const int64_t group = xcd_contiguous(blockIdx.x, (a.n_waves + SBW_WAVES - 1) / SBW_WAVES);
+    const int64_t wid = group * SBW_WAVES + wave;
     const int nbins = 1 << a.bits;
-    for (int i = lane; i < nbins; i += 64) cnt[wave][i] = 0;
+    for (int i = lane; i < SBH_COPIES << SB_MAXBITS; i += 64) (&cnt[wave][0][0])[i] = 0;
+    uint32_t* const mine = cnt[wave][lane % SBH_COPIES];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (wid >= a.n_waves) return;
+    if (group < 0 || wid >= a.n_waves) return;
     const int32_t* key = a.by_row ? a.row_in : a.term_in;
+    const int32_t* other = a.by_row ? a.term_in : a.row_in;      // read for the range check only
     const int64_t e0 = wid * SBW_ELEMS;
     const uint32_t mask = (uint32_t)nbins - 1u;
     int bad = 0;
-    for (int r = 0; r < SBW_ELEMS / 64; r += 4) {
-        int32_t kv[4];
+    const bool aligned = ((reinterpret_cast<uintptr_t>(key) | reinterpret_cast<uintptr_t>(other)) & 15u) == 0;      // a caller's view may start anywhere
+    if (e0 + SBW_ELEMS <= a.n && aligned) {
+        // a whole tile: 16 bytes per lane and load, four loads in flight (4 KB per wave - with one dword per lane the kernel waited on
+        // 1 KB per wave at a time and read at 2 TB/s)
+        const uint4* k4 = reinterpret_cast<const uint4*>(key + e0);
+        const uint4* o4 = reinterpret_cast<const uint4*>(other + e0);
+        for (int it = 0; it < SBW_ELEMS / (4 * 64 * 4); ++it) {
+            uint4 kv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t j = e0 + (int64_t)(r + u) * 64 + lane;
-            kv[u] = j < a.n ? key[j] : -1;
-            if (a.check && j < a.n) {
-                const int32_t t = a.term_in[j], rw = a.row_in[j];
-                if (t < 0 || (int64_t)t >= a.n_terms) bad |= 1;
-                if (rw < 0) bad |= 2;
-                if (a.row_limit > 0 && (int64_t)rw >= a.row_limit) bad |= 4;      // sort_docs: the doc digits cover [0, n_docs) only
+            for (int u = 0; u < 4; ++u) kv[u] = k4[(it * 4 + u) * 64 + lane];
+            if (a.check) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 ov = o4[(it * 4 + u) * 64 + lane];
+                    const uint32_t kk[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bad |= a.by_row ? check_posting(a, (int32_t)oo[c], (int32_t)kk[c]) : check_posting(a, (int32_t)kk[c], (int32_t)oo[c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                atomicAdd(&mine[(kv[u].x >> a.shift) & mask], 1u);
+                atomicAdd(&mine[(kv[u].y >> a.shift) & mask], 1u);
+                atomicAdd(&mine[(kv[u].z >> a.shift) & mask], 1u);
+                atomicAdd(&mine[(kv[u].w >> a.shift) & mask], 1u);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t j = e0 + (int64_t)(r + u) * 64 + lane;
-            if (j < a.n) atomicAdd(&cnt[wave][((uint32_t)kv[u] >> a.shift) & mask], 1u);
+    } else {
+        for (int r = 0; r < SBW_ELEMS / 64; ++r) {               // the last, partial tile (or input that is not 16-byte aligned)
+            const int64_t j = e0 + (int64_t)r * 64 + lane;
+            if (j < a.n) {
+                const int32_t kv = key[j];
+                if (a.check) bad |= a.by_row ? check_posting(a, other[j], kv) : check_posting(a, kv, other[j]);
+                atomicAdd(&mine[((uint32_t)kv >> a.shift) & mask], 1u);
+            }
         }
     }
     if (a.check && bad) atomicOr(a.flags, bad);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = lane; i < nbins; i += 64) a.hist[(int64_t)i * a.n_waves + wid] = cnt[wave][i];
+    for (int i = lane; i < nbins; i += 64) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < SBH_COPIES; ++u) c += cnt[wave][u][i];
+        a.hist[(int64_t)i * a.n_waves + wid] = c;
+    }
 }
 
 __global__ __launch_bounds__(64 * SBW_WAVES) void radix_scatter_kernel(RadixArgs a) {
@@ -217,6 +265,142 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_scatter_kernel(RadixArgs
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+}
+
+// The scatter of a pass with the tile's postings put in digit order in LDS first (round 6).  radix_scatter_kernel above stores a round's 64
+// postings straight to their slots: three 4-byte stores per posting into up to 64 different lines per instruction, each output line
+// completed by 16 separate stores rounds apart - far more lines in flight than the L2s hold, so lines reach HBM half written again and
+// again: 33 ms a pass of 1.12 G postings.  Here one workgroup of 8 waves takes the tile (the 8 192 postings the histogram counted):
+//   1. wave w ranks its 1 024 postings among themselves, 16 rounds of 64 (see the loop), the wave's running count per digit in LDS - the
+//      stable order inside a wave;
+//   2. per digit: the waves' counts are summed in wave order and scanned over the digits: where a (wave, digit) group starts in the tile;
+//   3. the output slot of every posting, then its term, row and value go to their place in digit order in ONE 32 KB LDS array and are read
+//      back in that order, thread i taking places i, i + 512, ...: neighbouring lanes store to neighbouring slots, a digit's run of
+//      16-32 postings leaves as one 64-128-byte piece.
+// Same result, posting for posting (a stable sort has only one); tests/test_sparse_csr_build_gpu.py compares both kernels with the stable
+// sort of the triples.  Dev switch SR_SPARSE_BUILD_TILE=0: the per-wave kernel.  What the measurements said, per pass of 1.12 G postings
+// (tools/micro/csr_build_ab.py, rocprofv3 kernel trace):
+//   three LDS arrays at once (96 KB, one workgroup per CU)                        12.7 ms
+//   one array at a time (56 KB, two workgroups per CU)                            ~11.5 ms
+//   ranking by digit words instead of a ballot per digit bit                      ~10 ms   (skipping all global stores: 3.8 ms - the stores
+//                                                                                           were the bound, not the arithmetic)
+//   tiles of an XCD contiguous (xcd_contiguous)                                    5.9 ms   = 4.5 TB/s of reads + writes
+#define SBT_THREADS 512
+__global__ __launch_bounds__(SBT_THREADS, 4) void radix_scatter_tile_kernel(RadixArgs a) {
+    constexpr int NW = SBT_THREADS / 64, PER_WAVE = SBW_ELEMS / NW, ROUNDS = PER_WAVE / 64;      // 8 waves x 1 024 postings, 16 rounds
+    extern __shared__ __attribute__((aligned(16))) unsigned char sbt_smem[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sbt_smem);                  // [NW][nbins]: running counts, then group starts inside the tile
+    uint32_t* lstart = cnt + NW * (1 << SB_MAXBITS);                         // [nbins]: where a digit starts inside the tile
+    uint32_t* gbase = lstart + (1 << SB_MAXBITS);                            // [nbins]: first output slot of (digit, this tile)
+    uint32_t* st = gbase + (1 << SB_MAXBITS);                                // [SBW_ELEMS]: one array of the tile in digit order
+    __shared__ uint32_t wtot[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the tiles in flight on an XCD are neighbours: the runs they write for a digit adjoin, and the partly written lines at their ends
+    // meet in that XCD's L2 (with tile = blockIdx.x the neighbours sat on 8 different XCDs: 12.7 ms a pass of 1.12 G postings, now 5.9)
+    const int64_t tile = xcd_contiguous(blockIdx.x, a.n_waves);
+    if (tile < 0) return;
+    const int nbins = 1 << a.bits;
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    for (int i = tid; i < NW * nbins; i += SBT_THREADS) cnt[i] = 0;
+    for (int i = tid; i < SBW_ELEMS / 4; i += SBT_THREADS) reinterpret_cast<uint4*>(st)[i] = make_uint4(0u, 0u, 0u, 0u);      // the waves' digit words
+    for (int i = tid; i < nbins; i += SBT_THREADS) gbase[i] = a.hist[(int64_t)i * a.n_waves + tile];
+    __syncthreads();
+    const int64_t e0 = tile * SBW_ELEMS + (int64_t)wave * PER_WAVE;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int32_t t[ROUNDS], rw[ROUNDS];
+    float v[ROUNDS];
+    uint32_t dr[ROUNDS];                     // digit | rank inside (wave, digit) << 9; 0xffffffff = past the end
+    uint32_t* const mycnt = cnt + wave * nbins;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t j = e0 + (int64_t)r * 64 + lane;
+        const bool live = j < a.n;
+        t[r] = 0; rw[r] = 0; v[r] = 0.f;
+        if (live) { t[r] = a.term_in[j]; rw[r] = a.row_in[j]; v[r] = a.val_in[j]; }
+    }
+    // the lanes of a round with my digit: every lane ORs its bit into the wave's 64-bit word of that digit (LDS, in the buffer the
+    // exchanges use later; an OR does not depend on the order the hardware takes the lanes in), reads the word back, and the group's
+    // first lane advances the running count and clears the word.  A wave's LDS operations complete in program order, so the reads see
+    // every lane's OR and happen before the clear.  (Until round 6 this was a ballot per digit bit: ~9 VALU instructions per bit and
+    // round, which made the kernel instruction-bound - without any global load or store it took as long as with them.)
+    static_assert(sizeof(uint32_t) * SBW_ELEMS >= sizeof(unsigned long long) * NW * (1 << SB_MAXBITS), "the digit words of all waves fit the exchange buffer");
+    unsigned long long* const mymask = reinterpret_cast<unsigned long long*>(st) + wave * nbins;
+    const unsigned long long mybit = 1ull << lane;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool live = e0 + (int64_t)r * 64 + lane < a.n;
+        const uint32_t d = live ? (((uint32_t)(a.by_row ? rw[r] : t[r]) >> a.shift) & mask) : 0u;
+        if (live) atomicOr(&mymask[d], mybit);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dr[r] = 0xffffffffu;
+        if (live) {
+            const uint64_t same = mymask[d];
+            const uint32_t first = mycnt[d];                     // every lane of the group reads before its leader writes
+            dr[r] = d | ((first + (uint32_t)__popcll(same & lt)) << SB_MAXBITS);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if ((same & lt) == 0) { mycnt[d] = first + (uint32_t)__popcll(same); mymask[d] = 0ull; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    // per digit: counts of the waves -> exclusive sums in wave order (kept in cnt), the digit's total -> exclusive scan over the digits
+    uint32_t tot = 0;
+    if (tid < nbins) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t c = cnt[w * nbins + tid];
+            cnt[w * nbins + tid] = tot;
+            tot += c;
+        }
+    }
+    uint32_t incl = tot;                     // SBT_THREADS >= nbins: thread d owns digit d
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wbase += w < wave ? wtot[w] : 0u;
+    if (tid < nbins) lstart[tid] = wbase + incl - tot;
+    __syncthreads();
+    // every posting to its place in the tile's digit order - one array at a time through ONE 32 KB buffer (56 KB of LDS with the counters:
+    // two workgroups per CU, so one's barriers and loads overlap the other's stores; three buffers at once was one workgroup per CU).
+    // First the output slots themselves: the owner of a posting knows its digit, so it computes the slot; the thread that stores place p
+    // reads it from there (the slots of a digit's run are consecutive: that is what makes the stores coalesce).
+    uint32_t lp[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t d = dr[r] & ((1u << SB_MAXBITS) - 1u);
+        lp[r] = dr[r] == 0xffffffffu ? 0xffffffffu : lstart[d] + mycnt[d] + (dr[r] >> SB_MAXBITS);
+        if (lp[r] != 0xffffffffu) st[lp[r]] = gbase[d] + mycnt[d] + (dr[r] >> SB_MAXBITS);
+    }
+    __syncthreads();
+    const int64_t left = a.n - tile * SBW_ELEMS;
+    const int n_tile = left < SBW_ELEMS ? (int)left : SBW_ELEMS;
+    uint32_t slot[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) slot[r] = st[tid + r * SBT_THREADS];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (lp[r] != 0xffffffffu) st[lp[r]] = (uint32_t)t[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (tid + r * SBT_THREADS < n_tile) a.term_out[slot[r]] = (int32_t)st[tid + r * SBT_THREADS];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (lp[r] != 0xffffffffu) st[lp[r]] = (uint32_t)rw[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (tid + r * SBT_THREADS < n_tile) a.row_out[slot[r]] = (int32_t)st[tid + r * SBT_THREADS];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (lp[r] != 0xffffffffu) st[lp[r]] = __float_as_uint(v[r]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) if (tid + r * SBT_THREADS < n_tile) a.val_out[slot[r]] = __uint_as_float(st[tid + r * SBT_THREADS]);
 }
 
 __global__ void csr_indptr_kernel(const int32_t* __restrict__ sorted_terms, int64_t n, int64_t n_terms, int64_t* __restrict__ indptr) {
@@ -277,36 +461,43 @@ extern "C" int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols,
     int np = 0;
     auto add_passes = [&](int by_row, int total_bits) {
         const int n = (total_bits + SB_MAXBITS - 1) / SB_MAXBITS;
-        const int per = (total_bits + n - 1) / n;
-        for (int i = 0; i < n; ++i) passes[np++] = Pass{by_row, i * per, (i + 1) * per <= total_bits ? per : total_bits - i * per};
+        // the narrower digits first: the low bits of a key are spread evenly, so a tile's run per digit is shortest there (8 192 / 256 =
+        // 32 postings = one 128-byte line with 8 bits, half a line with 9); the high bits are skewed (frequent terms have small ids)
+        const int base = total_bits / n, extra = total_bits % n;
+        for (int i = 0, sh = 0; i < n; ++i) {
+            const int b = base + (i >= n - extra ? 1 : 0);
+            passes[np++] = Pass{by_row, sh, b};
+            sh += b;
+        }
     };
     if (sort_docs) add_passes(1, bits_for(n_docs));
     add_passes(0, bits_for(n_terms));
 
     const int64_t n_waves = ceil_div64(nnz, SBW_ELEMS);
-    int32_t *tA = nullptr, *rA = nullptr, *tB = nullptr, *rB = nullptr;
-    float *vA = nullptr, *vB = nullptr;
-    uint32_t* hist = nullptr;
-    int* flags = nullptr;
+    // ONE allocation for the ping-pong buffers, the histogram and the flags (six hipMalloc + hipFree pairs of 4.5 GB each were 2 ms of
+    // the 18 ms the MSMARCO-sized build takes).  The LAST pass writes rows / vals straight into the caller's arrays (terms into tA or
+    // tB), the passes before it alternate between A and B.
+    const size_t e4 = (sizeof(int32_t) * (size_t)nnz + 255) & ~(size_t)255;
+    const size_t hist_bytes = ((sizeof(uint32_t) * (size_t)n_waves << SB_MAXBITS) + 255) & ~(size_t)255;
+    const int n_arrays = np >= 3 ? 6 : np == 2 ? 4 : 1;
+    unsigned char* arena = nullptr;
     int rc = SR_OK;
     auto cleanup = [&]() {
-        void* ptrs[] = {tA, rA, vA, tB, rB, vB, hist, flags};
-        for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+        if (arena) (void)hipFree(arena);
     };
-    // buffer A: output of the odd passes from the end ... simplest ping-pong: the LAST pass writes rows / vals straight into the
-    // caller's arrays (terms into tA or tB), the passes before it alternate between A and B
-    const size_t e4 = sizeof(int32_t) * (size_t)nnz;
-    bool ok = hipMalloc((void**)&tA, e4) == hipSuccess && hipMalloc((void**)&hist, sizeof(uint32_t) * (size_t)n_waves << SB_MAXBITS) == hipSuccess &&
-              hipMalloc((void**)&flags, sizeof(int)) == hipSuccess;
-    if (ok && np >= 2) ok = hipMalloc((void**)&rA, e4) == hipSuccess && hipMalloc((void**)&vA, e4) == hipSuccess && hipMalloc((void**)&tB, e4) == hipSuccess;
-    if (ok && np >= 3) ok = hipMalloc((void**)&rB, e4) == hipSuccess && hipMalloc((void**)&vB, e4) == hipSuccess;
-    if (!ok) {
+    if (hipMalloc((void**)&arena, e4 * n_arrays + hist_bytes + 256) != hipSuccess) {
         (void)hipGetLastError();
-        cleanup();
         sr_set_error("sr_sparse_csr_build: out of device memory (%lld postings, %d passes)", (long long)nnz, np);
         return SR_ERR_NOMEM;
     }
+    int32_t* tA = reinterpret_cast<int32_t*>(arena);
+    int32_t* rA = np >= 2 ? reinterpret_cast<int32_t*>(arena + e4) : nullptr;
+    float* vA = np >= 2 ? reinterpret_cast<float*>(arena + 2 * e4) : nullptr;
+    int32_t* tB = np >= 2 ? reinterpret_cast<int32_t*>(arena + 3 * e4) : nullptr;
+    int32_t* rB = np >= 3 ? reinterpret_cast<int32_t*>(arena + 4 * e4) : nullptr;
+    float* vB = np >= 3 ? reinterpret_cast<float*>(arena + 5 * e4) : nullptr;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(arena + e4 * n_arrays);
+    int* flags = reinterpret_cast<int*>(arena + e4 * n_arrays + hist_bytes);
     do {
         if (hipMemsetAsync(flags, 0, sizeof(int), s) != hipSuccess) { rc = SR_ERR_HIP; break; }
         const int32_t *tin = d_cols, *rin = d_rows;
@@ -324,28 +515,41 @@ extern "C" int sr_sparse_csr_build(const int32_t* d_rows, const int32_t* d_cols,
             a.n = nnz; a.by_row = passes[p].by_row; a.shift = passes[p].shift; a.bits = passes[p].bits;
             a.hist = hist; a.n_waves = n_waves; a.n_terms = n_terms; a.flags = flags; a.check = p == 0; a.row_limit = sort_docs ? n_docs : 0;
             const unsigned grid = (unsigned)ceil_div64(n_waves, SBW_WAVES);
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(grid), dim3(64 * SBW_WAVES), 0, s, a);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(xcd_contiguous_grid(ceil_div64(n_waves, SBW_WAVES))), dim3(64 * SBW_WAVES), 0, s, a);
             if (hipGetLastError() != hipSuccess) { rc = SR_ERR_HIP; break; }
             rc = device_exclusive_scan<uint32_t>(hist, hist, n_waves << a.bits, false, s);
             if (rc != SR_OK) break;
-            if (p == 0) {
-                int h = 0;
-                if (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = SR_ERR_HIP; break; }
-                if (h) {
-                    sr_set_error("sr_sparse_csr_build: invalid postings (%s%s%s)", (h & 1) ? "term outside [0, n_terms); " : "",
-                                 (h & 2) ? "negative doc row; " : "", (h & 4) ? "sort_docs with a doc row >= n_docs" : "");
-                    rc = SR_ERR_INVALID;
-                    break;
+            bool by_tile = true;
+            if (const char* e = sr_dev_getenv("SR_SPARSE_BUILD_TILE")) by_tile = atoi(e) != 0;       // A/B switch: 0 = the per-wave scatter
+            if (by_tile) {
+                constexpr size_t lds = sizeof(uint32_t) * ((SBT_THREADS / 64) + 2) * (1 << SB_MAXBITS) + 4 * (size_t)SBW_ELEMS;
+                static DeviceOnce attr_once;
+                if (bool* slot = attr_once.pending()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&radix_scatter_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                        rc = SR_ERR_HIP;
+                        break;
+                    }
+                    *slot = true;
                 }
+                hipLaunchKernelGGL(radix_scatter_tile_kernel, dim3(xcd_contiguous_grid(n_waves)), dim3(SBT_THREADS), lds, s, a);
+            } else {
+                hipLaunchKernelGGL(radix_scatter_kernel, dim3(grid), dim3(64 * SBW_WAVES), 0, s, a);
             }
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(grid), dim3(64 * SBW_WAVES), 0, s, a);
             if (hipGetLastError() != hipSuccess) { rc = SR_ERR_HIP; break; }
             tin = tout; rin = rout; vin = vout;
             final_terms = tout;
         }
         if (rc != SR_OK) break;
         hipLaunchKernelGGL(csr_indptr_kernel, dim3((unsigned)ceil_div64(n_terms + 1, 256)), dim3(256), 0, s, final_terms, nnz, n_terms, d_indptr);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SR_ERR_HIP;
+        // the range check of the first histogram is read at the end, with everything else: the digits are masked, so postings that fail
+        // it were moved around inside the arrays like any others (no wild write) - the call fails and the outputs are to be discarded
+        int h = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = SR_ERR_HIP; break; }
+        if (h) {
+            sr_set_error("sr_sparse_csr_build: invalid postings (%s%s%s)", (h & 1) ? "term outside [0, n_terms); " : "",
+                         (h & 2) ? "negative doc row; " : "", (h & 4) ? "sort_docs with a doc row >= n_docs" : "");
+            rc = SR_ERR_INVALID;
+        }
     } while (0);
     if (rc == SR_ERR_HIP) sr_set_error("sr_sparse_csr_build: %s", hipGetErrorString(hipGetLastError()));
     cleanup();

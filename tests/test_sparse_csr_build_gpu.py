@@ -39,8 +39,13 @@ def _reference(rows, cols, vals, V, sort_docs):
     (9000, 2000, 30, True),          # doc passes first
     (1, 7, 3, False),
 ])
-def test_csr_build_matches_a_stable_sort(n_docs, V, L0, sort_docs):
+@pytest.mark.parametrize("kernel", ["tile", "wave"])
+def test_csr_build_matches_a_stable_sort(n_docs, V, L0, sort_docs, kernel, monkeypatch):
+    """kernel: the workgroup-per-tile scatter (the product path) and the per-wave scatter it replaced in round 6 (dev switch)."""
     from scaling_retriever_amd.scoring import sparse_csr_build
+    if kernel == "wave":
+        monkeypatch.setenv("SR_DEV_SWITCHES", "1")
+        monkeypatch.setenv("SR_SPARSE_BUILD_TILE", "0")
     rng = np.random.default_rng(n_docs + V)
     rows, cols, vals = _coo(rng, n_docs, V, L0)
     if sort_docs:                    # a merged multi-rank index arrives rank-major inside a term: shuffle the insertion order
@@ -78,6 +83,24 @@ def test_csr_build_keeps_insertion_order_inside_a_term_and_handles_the_edges():
         sparse_csr_build(rows, cols, vals, 4, n_docs=9, sort_docs=True)
     ip, r, v = sparse_csr_build(rows, cols, vals, 4, n_docs=9)              # without sort_docs the rows are payload: any value >= 0
     assert r.tolist() == [1, 5, 5, 1, 9, 0]
+
+
+def test_csr_build_of_views_that_start_anywhere():
+    """The histogram reads whole tiles 16 bytes per lane when the arrays allow it: views that start 4, 8, 12 bytes into an allocation
+    (and a last tile that is not full) take the other path and give the same lists."""
+    from scaling_retriever_amd.scoring import sparse_csr_build
+    rng = np.random.default_rng(11)
+    rows, cols, vals = _coo(rng, 6000, 3000, 25)
+    dev = torch.device("cuda")
+    e_ip, e_rows, e_vals = _reference(rows, cols, vals, 3000, False)
+    for off in (0, 1, 2, 3):
+        pad = np.zeros(off, dtype=np.int32)
+        r = torch.from_numpy(np.concatenate([pad, rows])).to(dev)[off:]
+        c = torch.from_numpy(np.concatenate([pad, cols])).to(dev)[off:]
+        v = torch.from_numpy(np.concatenate([pad.astype(np.float32), vals])).to(dev)[off:]
+        assert r.is_contiguous() and r.data_ptr() % 16 == (4 * off) % 16
+        ip, out_r, out_v = sparse_csr_build(r, c, v, 3000)
+        assert np.array_equal(ip.cpu().numpy(), e_ip) and np.array_equal(out_r.cpu().numpy(), e_rows) and np.array_equal(out_v.cpu().numpy(), e_vals)
 
 
 def test_csr_build_large_and_the_index_it_feeds():
