@@ -631,12 +631,12 @@ def sparse_build_only(indptr, doc_ids, vals, V, N, device):
     t = min(ts)
     n_pass = 2 if V > 512 else 1
     alg_bytes = nnz * (n_pass * (4.0 + 12.0 + 12.0)) + 8.0 * V            # per pass: keys for the histogram, triples in, triples out
-    out = {"workload": f"CSR by term from {nnz} doc-major postings ({N} docs x V = {V}): stable radix sort, {n_pass} passes of 9-bit digits",
+    out = {"workload": f"CSR by term from {nnz} doc-major postings ({N} docs x V = {V}): stable radix sort, {n_pass} passes of 8- and 9-bit digits",
            "postings_per_s": round(nnz / t, 1), "seconds": round(t, 4), "passages_per_s_at_this_L0_d": round(N / t, 1),
            "bit_identical_to_the_source_index": same,
-           "roofline": {"kernel": "radix_scatter_kernel + radix_hist_kernel", "bound": "hbm", "achieved": round(alg_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBPS,
+           "roofline": {"kernel": "radix_scatter_tile_kernel + radix_hist_kernel", "bound": "hbm", "achieved": round(alg_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBPS,
                         "unit": "GB/s", "frac": round(alg_bytes / t / 1e9 / PEAK_HBM_GBPS, 4), "algorithmic_bytes": alg_bytes,
-                        "note": "wall time of the call incl. its allocations and the two exclusive scans; 28 B per posting and pass"},
+                        "note": "wall time of the call incl. its allocation and the two exclusive scans; 28 B per posting and pass"},
            "forward_index_by_doc": {"seconds": round(t_fwd, 4), "postings_per_s": round(nnz / t_fwd, 1),
                                     "note": "the same call with the docs as sort key (24 bits: 3 passes), from term-major input"}}
     log("[sparse index_build]", out)
