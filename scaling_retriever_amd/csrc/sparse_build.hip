@@ -157,13 +157,14 @@ __device__ __forceinline__ int64_t xcd_contiguous(unsigned b, int64_t n_items) {
 }
 static unsigned xcd_contiguous_grid(int64_t n_items) { return (unsigned)(((n_items + 7) / 8) * 8); }
 
-__device__ __forceinline__ int check_posting(const RadixArgs& a, int32_t t, int32_t rw) {
-    int bad = 0;
-    if ((uint32_t)t >= (uint64_t)a.n_terms) bad |= 1;                      // negative or beyond the vocabulary
-    if (rw < 0) bad |= 2;
-    if (a.row_limit > 0 && (int64_t)rw >= a.row_limit) bad |= 4;           // sort_docs: the doc digits cover [0, n_docs) only
-    return bad;
+// The range check of the first pass (a.check): the histogram kernel checks the array it reads (the pass's key), the scatter kernel the other
+// one, which it reads anyway - reading it in the histogram kernel as well was 4.5 GB more at the MSMARCO size.
+__device__ __forceinline__ int check_term(const RadixArgs& a, int32_t t) { return (uint32_t)t >= (uint64_t)a.n_terms ? 1 : 0; }      // negative or beyond the vocabulary
+__device__ __forceinline__ int check_row(const RadixArgs& a, int32_t rw) {
+    return (rw < 0 ? 2 : 0) | (a.row_limit > 0 && (int64_t)rw >= a.row_limit ? 4 : 0);      // 4: sort_docs, the doc digits cover [0, n_docs) only
 }
+__device__ __forceinline__ int check_key(const RadixArgs& a, int32_t key) { return a.by_row ? check_row(a, key) : check_term(a, key); }
+__device__ __forceinline__ int check_other(const RadixArgs& a, int32_t t, int32_t rw) { return a.by_row ? check_term(a, t) : check_row(a, rw); }
 
 __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a) {
     // SBH_COPIES counters per digit and wave, lane l counts in copy l % SBH_COPIES: the high digits of the terms are skewed (half the postings
@@ -178,28 +179,21 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (group < 0 || wid >= a.n_waves) return;
     const int32_t* key = a.by_row ? a.row_in : a.term_in;
-    const int32_t* other = a.by_row ? a.term_in : a.row_in;      // read for the range check only
     const int64_t e0 = wid * SBW_ELEMS;
     const uint32_t mask = (uint32_t)nbins - 1u;
     int bad = 0;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(key) | reinterpret_cast<uintptr_t>(other)) & 15u) == 0;      // a caller's view may start anywhere
+    const bool aligned = (reinterpret_cast<uintptr_t>(key) & 15u) == 0;      // a caller's view may start anywhere
     if (e0 + SBW_ELEMS <= a.n && aligned) {
         // a whole tile: 16 bytes per lane and load, four loads in flight (4 KB per wave - with one dword per lane the kernel waited on
         // 1 KB per wave at a time and read at 2 TB/s)
         const uint4* k4 = reinterpret_cast<const uint4*>(key + e0);
-        const uint4* o4 = reinterpret_cast<const uint4*>(other + e0);
         for (int it = 0; it < SBW_ELEMS / (4 * 64 * 4); ++it) {
             uint4 kv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) kv[u] = k4[(it * 4 + u) * 64 + lane];
             if (a.check) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint4 ov = o4[(it * 4 + u) * 64 + lane];
-                    const uint32_t kk[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bad |= a.by_row ? check_posting(a, (int32_t)oo[c], (int32_t)kk[c]) : check_posting(a, (int32_t)kk[c], (int32_t)oo[c]);
-                }
+                for (int u = 0; u < 4; ++u) bad |= check_key(a, (int32_t)kv[u].x) | check_key(a, (int32_t)kv[u].y) | check_key(a, (int32_t)kv[u].z) | check_key(a, (int32_t)kv[u].w);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -214,7 +208,7 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_hist_kernel(RadixArgs a)
             const int64_t j = e0 + (int64_t)r * 64 + lane;
             if (j < a.n) {
                 const int32_t kv = key[j];
-                if (a.check) bad |= a.by_row ? check_posting(a, other[j], kv) : check_posting(a, kv, other[j]);
+                if (a.check) bad |= check_key(a, kv);
                 atomicAdd(&mine[((uint32_t)kv >> a.shift) & mask], 1u);
             }
         }
@@ -247,6 +241,7 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_scatter_kernel(RadixArgs
         int32_t t = 0, rw = 0;
         float v = 0.f;
         if (live) { t = a.term_in[j]; rw = a.row_in[j]; v = a.val_in[j]; }
+        if (a.check && live) { const int bad = check_other(a, t, rw); if (bad) atomicOr(a.flags, bad); }
         const uint32_t d = live ? (((uint32_t)(a.by_row ? rw : t) >> a.shift) & mask) : 0u;
         // lanes of this round with my digit
         uint64_t same = __ballot(live);
@@ -317,6 +312,13 @@ __global__ __launch_bounds__(SBT_THREADS, 4) void radix_scatter_tile_kernel(Radi
         const bool live = j < a.n;
         t[r] = 0; rw[r] = 0; v[r] = 0.f;
         if (live) { t[r] = a.term_in[j]; rw[r] = a.row_in[j]; v[r] = a.val_in[j]; }
+    }
+    if (a.check) {
+        int bad = 0;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (e0 + (int64_t)r * 64 + lane < a.n) bad |= check_other(a, t[r], rw[r]);
+        if (bad) atomicOr(a.flags, bad);
     }
     // the lanes of a round with my digit: every lane ORs its bit into the wave's 64-bit word of that digit (LDS, in the buffer the
     // exchanges use later; an OR does not depend on the order the hardware takes the lanes in), reads the word back, and the group's
