@@ -103,6 +103,36 @@ def test_csr_build_of_views_that_start_anywhere():
         assert np.array_equal(ip.cpu().numpy(), e_ip) and np.array_equal(out_r.cpu().numpy(), e_rows) and np.array_equal(out_v.cpu().numpy(), e_vals)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_csr_build_random_shapes_around_the_tile_and_digit_boundaries(seed):
+    """Random vocabularies (1 … 21 bits: one to three passes, digits of 1 … 9 bits), posting counts at and around multiples of the
+    8 192-posting tile, skewed and flat term laws, with and without the doc passes: always the stable sort of the triples."""
+    from scaling_retriever_amd.scoring import sparse_csr_build
+    rng = np.random.default_rng(100 + seed)
+    dev = torch.device("cuda")
+    for case in range(6):
+        bits = int(rng.integers(1, 22))
+        V = int(rng.integers(max(2, (1 << bits) // 2 + 1), (1 << bits) + 1)) if bits > 1 else 2
+        nnz = int(rng.choice([1, 63, 64, 65, 1023, 8191, 8192, 8193, 3 * 8192, 5 * 8192 + 17, 70001]))
+        n_docs = int(rng.integers(1, 5000))
+        if rng.random() < 0.5:
+            cols = (rng.random(nnz) ** 4 * V).astype(np.int64).clip(0, V - 1)            # skewed towards the small ids
+        else:
+            cols = rng.integers(0, V, size=nnz)
+        rows = rng.integers(0, n_docs, size=nnz)
+        cols, rows = cols.astype(np.int32), rows.astype(np.int32)
+        vals = rng.random(nnz).astype(np.float32)
+        for sort_docs in (False, True):
+            ip, r, v = sparse_csr_build(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev), torch.from_numpy(vals).to(dev), V,
+                                        n_docs=n_docs, sort_docs=sort_docs)
+            # (equal (term, doc) pairs keep their input order under sort_docs too: lexsort is stable)
+            e_ip, e_rows, e_vals = _reference(rows, cols, vals, V, sort_docs)
+            tag = (seed, case, bits, V, nnz, sort_docs)
+            assert np.array_equal(ip.cpu().numpy(), e_ip), tag
+            assert np.array_equal(r.cpu().numpy(), e_rows), tag
+            assert np.array_equal(v.cpu().numpy(), e_vals), tag
+
+
 def test_csr_build_large_and_the_index_it_feeds():
     """1.3 M docs x 24 postings at V = 128 256 (31 M postings, two 9-bit passes, several thousand waves each): equals the stable sort, and the index built from it
     scores like the oracle."""
