@@ -80,7 +80,7 @@ def test_four_wave_gemm_kernels_use_no_scratch(tmp_path):
     kernels = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size:", notes, flags=re.S):
         body = m.group(2)
-        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:)\s+(\d+)", body)}
+        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:|\.vgpr_count:)\s+(\d+)", body)}
     four_wave = {k: v for k, v in kernels.items() if k.startswith("_Z16gemm_bf16_kernel") and k.endswith("ELi1EEv8GemmArgs")}
     assert len(four_wave) >= 4, sorted(kernels)[:5]
     for name, meta in four_wave.items():
@@ -88,7 +88,7 @@ def test_four_wave_gemm_kernels_use_no_scratch(tmp_path):
 
 
 def _kernel_metadata(obj, tmp_path):
-    """{mangled kernel name: {scratch bytes, spilled VGPRs / SGPRs}} of a built object (llvm-objcopy + clang-offload-bundler + llvm-readelf --notes)."""
+    """{mangled kernel name: {scratch bytes, spilled VGPRs / SGPRs, VGPRs}} of a built object (llvm-objcopy + clang-offload-bundler + llvm-readelf --notes)."""
     import re
     import subprocess
     llvm = "/opt/rocm/lib/llvm/bin"
@@ -119,3 +119,16 @@ def test_dense_split_and_head128_attention_kernels_use_no_scratch(tmp_path):
     assert len(attn) >= 4, sorted(attn)
     for name, meta in attn.items():
         assert meta[".private_segment_fixed_size:"] == 0 and meta[".vgpr_spill_count:"] == 0, (name, meta)
+
+
+def test_index_build_kernels_fit_two_workgroups_per_cu(tmp_path):
+    """radix_scatter_tile_kernel (round 6) is sized for TWO workgroups of 512 threads per CU - one's barriers overlap the other's
+    stores: at most 128 registers per lane, no scratch, and its 56 KB of dynamic LDS twice in the CU's 160 KB (checked where the
+    launch computes it: csrc/sparse_build.hip)."""
+    meta = _kernel_metadata(os.path.join(ROOT, "scaling_retriever_amd", "csrc", "sparse_build.o"), tmp_path)
+    tile = [v for k, v in meta.items() if "radix_scatter_tile_kernel" in k]
+    assert len(tile) == 1, sorted(meta)
+    assert tile[0][".private_segment_fixed_size:"] == 0 and tile[0][".vgpr_spill_count:"] == 0 and tile[0][".vgpr_count:"] <= 128, tile[0]
+    for name, m in meta.items():
+        if "radix_" in name:
+            assert m[".private_segment_fixed_size:"] == 0, (name, m)
