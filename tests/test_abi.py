@@ -80,7 +80,7 @@ def test_four_wave_gemm_kernels_use_no_scratch(tmp_path):
     kernels = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size:", notes, flags=re.S):
         body = m.group(2)
-        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:|\.vgpr_count:)\s+(\d+)", body)}
+        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:)\s+(\d+)", body)}
     four_wave = {k: v for k, v in kernels.items() if k.startswith("_Z16gemm_bf16_kernel") and k.endswith("ELi1EEv8GemmArgs")}
     assert len(four_wave) >= 4, sorted(kernels)[:5]
     for name, meta in four_wave.items():
@@ -101,7 +101,7 @@ def _kernel_metadata(obj, tmp_path):
     notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", dev], capture_output=True, text=True).stdout
     kernels = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size:", notes, flags=re.S):
-        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:)\s+(\d+)", m.group(2))}
+        kernels[m.group(1)] = {key: int(v) for key, v in re.findall(r"(\.private_segment_fixed_size:|\.vgpr_spill_count:|\.sgpr_spill_count:|\.vgpr_count:)\s+(\d+)", m.group(2))}
     return kernels
 
 
