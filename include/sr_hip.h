@@ -201,7 +201,10 @@ int sr_sparse_index_cert_debug(sr_sparse_index* idx, int enable, uint16_t* h_key
  * insertion order.  A stable radix sort by term (this library's kernels) keeps the insertion order inside a term - the
  * reference's posting order; sort_docs = 1 additionally orders every posting list by ascending doc row (needs n_docs >
  * every row), which is what sr_sparse_index_create requires of a merged multi-rank index.  Outputs: d_indptr int64
- * [n_terms + 1], d_out_rows int32 [nnz], d_out_vals fp32 [nnz] (must not alias the inputs).  Synchronises the stream.       */
+ * [n_terms + 1], d_out_rows int32 [nnz], d_out_vals fp32 [nnz] (must not alias the inputs).  Synchronises the stream.
+ * Errors: SR_ERR_INVALID for a term outside [0, n_terms), a negative row, or (sort_docs) a row >= n_docs - reported when the
+ * call returns; the outputs then hold the postings in no defined order (the digits are masked: never a write outside the
+ * arrays).  SR_ERR_NOMEM when the ping-pong buffers (4 bytes x nnz x 4, x 6 with three or more passes) cannot be allocated.  */
 /* Term of every posting of a CSR-by-term index: d_out_terms int32 [nnz][p] = t for d_indptr[t] <= p < d_indptr[t + 1]
  * (the per-term arrays of IndexDictOfArray, inverted_index.py:22-55, flattened back to triples for a re-sort).            */
 int sr_sparse_csr_expand_terms(const int64_t* d_indptr, int64_t n_terms, int64_t nnz, int32_t* d_out_terms,
