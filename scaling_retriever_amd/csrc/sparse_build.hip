@@ -281,6 +281,7 @@ __global__ __launch_bounds__(64 * SBW_WAVES) void radix_scatter_kernel(RadixArgs
 //                                                                                           were the bound, not the arithmetic)
 //   tiles of an XCD contiguous (xcd_contiguous)                                    5.9 ms   = 4.5 TB/s of reads + writes
 #define SBT_THREADS 512
+// (hipcc reads the second launch bound as waves per SIMD: 4 = two workgroups of 8 waves per CU, at most 128 registers per lane)
 __global__ __launch_bounds__(SBT_THREADS, 4) void radix_scatter_tile_kernel(RadixArgs a) {
     constexpr int NW = SBT_THREADS / 64, PER_WAVE = SBW_ELEMS / NW, ROUNDS = PER_WAVE / 64;      // 8 waves x 1 024 postings, 16 rounds
     extern __shared__ __attribute__((aligned(16))) unsigned char sbt_smem[];
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(SBT_THREADS, 4) void radix_scatter_tile_kernel(Radi
     __shared__ uint32_t wtot[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the tiles in flight on an XCD are neighbours: the runs they write for a digit adjoin, and the partly written lines at their ends
-    // meet in that XCD's L2 (with tile = blockIdx.x the neighbours sat on 8 different XCDs: 12.7 ms a pass of 1.12 G postings, now 5.9)
+    // meet in that XCD's L2 (with tile = blockIdx.x the neighbours sat on 8 different XCDs: about 10 ms a pass of 1.12 G postings, now 5.9)
     const int64_t tile = xcd_contiguous(blockIdx.x, a.n_waves);
     if (tile < 0) return;
     const int nbins = 1 << a.bits;
