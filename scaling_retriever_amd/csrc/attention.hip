@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, at_small_blocks(HD, MAXKB)) void attention_sma
 // workgroup per CU - there this kernel also serves the short sequences (128 us per layer at 8B dims and 9.6 k tokens against
 // 745 us for the all-keys-in-registers kernel at one workgroup per CU).
 template <int HD, int CKB>
-__global__ __launch_bounds__(256, CKB <= 3 ? 3 : 2) void attention_long_kernel(AttnArgs a) {
+// (second launch bound = waves per SIMD; head dim 128 needs the 256-register budget of two: at three the 2- and 3-block plans spilled 9-25
+// registers - same rate either way at 8B dims, tools/quick_encode_8b.py in a same-box A/B, but no scratch)
+__global__ __launch_bounds__(256, (CKB <= 3 && HD < 128) ? 3 : 2) void attention_long_kernel(AttnArgs a) {
     constexpr int NCH = HD / 8, NKK = HD / 16, NDB = HD / 32, MAXKB = CKB, KC = CKB * 32, VT_LD = KC + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [KC][HD], chunk-swizzled

@@ -115,8 +115,11 @@ def test_dense_split_and_head128_attention_kernels_use_no_scratch(tmp_path):
     assert len(split) == 2, sorted(split)
     for name, meta in split.items():
         assert meta[".private_segment_fixed_size:"] == 0 and meta[".vgpr_spill_count:"] == 0, (name, meta)
-    attn = {k: v for k, v in _kernel_metadata(os.path.join(csrc, "attention.o"), tmp_path).items() if "attention_small_kernelILi128" in k}
-    assert len(attn) >= 4, sorted(attn)
+    # + the head-128 long kernel's default plans (2 or 3 key blocks per chunk: what an 8B batch with a passage over 64 tokens runs; 9-25
+    # spilled registers until its occupancy bound was lowered to two waves per SIMD as well)
+    attn = {k: v for k, v in _kernel_metadata(os.path.join(csrc, "attention.o"), tmp_path).items()
+            if "attention_small_kernelILi128" in k or "attention_long_kernelILi128ELi2" in k or "attention_long_kernelILi128ELi3" in k}
+    assert len(attn) >= 6, sorted(attn)
     for name, meta in attn.items():
         assert meta[".private_segment_fixed_size:"] == 0 and meta[".vgpr_spill_count:"] == 0, (name, meta)
 
